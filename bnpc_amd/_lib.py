@@ -1,0 +1,281 @@
+"""ctypes binding of include/bnpc_hip.h (libbnpc_hip.so).
+
+The product path has NO CPU fallback: if the shared library is missing or a
+HIP call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libbnpc_hip.so')
+
+MAX_VIEWS = 4
+MAX_TRIALS = 4
+
+_i64 = C.c_int64
+_pd = C.POINTER(C.c_double)
+_pf = C.POINTER(C.c_float)
+_pi64 = C.POINTER(C.c_int64)
+_pi32 = C.POINTER(C.c_int32)
+_ctx = C.c_void_p
+
+
+class MT19937(C.Structure):
+    _fields_ = [('key', C.c_uint32 * 624), ('pos', C.c_int32)]
+
+
+class GibbsState(C.Structure):
+    _fields_ = [('n_cells', _i64), ('ld', _i64), ('n_cols', _i64),
+        ('n_active', _i64), ('pos', _i64), ('new_cell', _i64)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
+SIGNATURES = {
+    'bnpc_last_error': (C.c_char_p, []),
+    'bnpc_abi_version': (C.c_int, []),
+    'bnpc_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'bnpc_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int,
+        C.POINTER(C.c_int)]),
+    'bnpc_create': (C.c_int, [C.c_int, _i64, _i64, _pd, C.POINTER(_ctx)]),
+    'bnpc_create_codes': (C.c_int, [C.c_int, _i64, _i64,
+        C.POINTER(C.c_int8), C.POINTER(_ctx)]),
+    'bnpc_destroy': (C.c_int, [_ctx]),
+    'bnpc_shape': (C.c_int, [_ctx, _pi64, _pi64]),
+    'bnpc_cell_counts': (C.c_int, [_ctx, _pi32, _pi32]),
+    'bnpc_view_set': (C.c_int, [_ctx, C.c_int, _pi64, _i64]),
+    'bnpc_view_size': (C.c_int, [_ctx, C.c_int, _pi64]),
+    'bnpc_ll_theta': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
+        C.c_double, _pd, _i64]),
+    'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
+    'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
+    'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
+        _pi32]),
+    'bnpc_ll_total': (C.c_int, [_ctx, _pf, _i64, _pd, _pd, C.c_int, _pd]),
+    'bnpc_timer_start': (C.c_int, [_ctx]),
+    'bnpc_timer_stop': (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    'bnpc_sync': (C.c_int, [_ctx]),
+    'bnpc_mt_random_sample': (C.c_double, [C.POINTER(MT19937)]),
+    'bnpc_mt_permutation': (C.c_int, [C.POINTER(MT19937), _i64, _pi64]),
+    'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
+        _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
+    'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
+        C.c_double, _pi64, _pi64, _pd]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbnpc_hip.so (once).  Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built. '
+            'Run `python -m bnpc_amd.build` (needs hipcc, no GPU). There is '
+            'no CPU fallback for the product path.')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as err:
+        raise RuntimeError(f'cannot load {LIB_PATH}: {err}') from err
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().bnpc_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'libbnpc_hip {what} failed (code {rc}): {msg}')
+
+
+def ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().bnpc_device_count(C.byref(n)), 'device_count')
+    return n.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(64)
+    cus = C.c_int(0)
+    check(load().bnpc_device_info(device, name, 64, C.byref(cus)),
+        'device_info')
+    return name.value.decode(), cus.value
+
+
+# ---------------------------------------------------------------------------
+# numpy legacy stream <-> C struct
+# ---------------------------------------------------------------------------
+def rng_export():
+    """Snapshot of the global legacy np.random state as an MT19937 struct."""
+    kind, key, pos, has_gauss, cached = np.random.get_state()
+    st = MT19937()
+    C.memmove(st.key, key.ctypes.data, 624 * 4)
+    st.pos = pos
+    return st, (has_gauss, cached)
+
+
+def rng_import(st, extra):
+    """Write an MT19937 struct back into the global legacy np.random state."""
+    key = np.frombuffer(st.key, dtype=np.uint32).copy()
+    np.random.set_state(('MT19937', key, int(st.pos), extra[0], extra[1]))
+
+
+class Context:
+    """Device-resident data of one chain (bnpc_ctx)."""
+
+    def __init__(self, data=None, codes=None, device=0):
+        lib = load()
+        handle = _ctx()
+        if codes is not None:
+            codes = np.ascontiguousarray(codes, dtype=np.int8)
+            N, M = codes.shape
+            check(lib.bnpc_create_codes(device, N, M, ptr(codes, C.c_int8),
+                C.byref(handle)), 'create_codes')
+        else:
+            data = np.ascontiguousarray(data, dtype=np.float64)
+            N, M = data.shape
+            check(lib.bnpc_create(device, N, M, ptr(data, C.c_double),
+                C.byref(handle)), 'create')
+        self._h = handle
+        self._lib = lib
+        self.N, self.M = N, M
+        self.device = device
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.bnpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def cell_counts(self):
+        n1 = np.empty(self.N, dtype=np.int32)
+        n0 = np.empty(self.N, dtype=np.int32)
+        check(self._lib.bnpc_cell_counts(self._h, ptr(n1, C.c_int32),
+            ptr(n0, C.c_int32)), 'cell_counts')
+        return n1, n0
+
+    def view_set(self, view, cells):
+        cells = as_i64(cells)
+        check(self._lib.bnpc_view_set(self._h, view, ptr(cells, C.c_int64),
+            cells.size), 'view_set')
+        return cells.size
+
+    def view_size(self, view):
+        n = _i64(0)
+        check(self._lib.bnpc_view_size(self._h, view, C.byref(n)),
+            'view_size')
+        return n.value
+
+    def ll_theta(self, view, theta, FP, FN, out=None, fetch=True):
+        """(slots x K) float64 log-likelihoods; theta K x M float32.
+
+        `out` may be a C-contiguous (slots, ld >= K) array: columns K..ld are
+        left untouched (room for clusters opened later in a sweep)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        if theta.ndim == 1:
+            theta = theta[None, :]
+        K = theta.shape[0]
+        assert theta.shape[1] == self.M
+        n = self.view_size(view)
+        ld = 0
+        if fetch:
+            if out is None:
+                out = np.empty((n, K), dtype=np.float64)
+            assert out.flags['C_CONTIGUOUS'] and out.shape[0] == n \
+                and out.shape[1] >= K and out.dtype == np.float64
+            ld = out.shape[1]
+            po = ptr(out, C.c_double)
+        else:
+            po = None
+            self._keep = theta      # borrowed until the next sync
+        check(self._lib.bnpc_ll_theta(self._h, view, ptr(theta, C.c_float), K,
+            float(FP), float(FN), po, ld), 'll_theta')
+        return out
+
+    def ll_tables(self, view, L1, L0, out=None):
+        L1 = np.ascontiguousarray(L1, dtype=np.float64)
+        L0 = np.ascontiguousarray(L0, dtype=np.float64)
+        if L1.ndim == 1:
+            L1, L0 = L1[None, :], L0[None, :]
+        K = L1.shape[0]
+        assert L1.shape == L0.shape == (K, self.M)
+        n = self.view_size(view)
+        if out is None:
+            out = np.empty((n, K), dtype=np.float64)
+        check(self._lib.bnpc_ll_tables(self._h, view, ptr(L1, C.c_double),
+            ptr(L0, C.c_double), K, ptr(out, C.c_double), 0), 'll_tables')
+        return out
+
+    def colcounts(self, segments):
+        """segments: list of int arrays of cell ids -> (n1, n0) G x M int32."""
+        G = len(segments)
+        sizes = [len(s) for s in segments]
+        offs = np.zeros(G + 1, dtype=np.int64)
+        np.cumsum(sizes, out=offs[1:])
+        cells = as_i64(np.concatenate([np.asarray(s, dtype=np.int64)
+            for s in segments])) if offs[-1] else np.zeros(1, dtype=np.int64)
+        n1 = np.zeros((G, self.M), dtype=np.int32)
+        n0 = np.zeros((G, self.M), dtype=np.int32)
+        check(self._lib.bnpc_colcounts(self._h, ptr(cells, C.c_int64),
+            ptr(offs, C.c_int64), G, ptr(n1, C.c_int32), ptr(n0, C.c_int32)),
+            'colcounts')
+        return n1, n0
+
+    def colcounts_by_label(self, assignment, ids, fetch=True):
+        assignment = as_i64(assignment)
+        ids = as_i64(ids)
+        K = ids.size
+        if fetch:
+            n1 = np.empty((K, self.M), dtype=np.int32)
+            n0 = np.empty((K, self.M), dtype=np.int32)
+            p1, p0 = ptr(n1, C.c_int32), ptr(n0, C.c_int32)
+        else:
+            n1 = n0 = p1 = p0 = None
+        check(self._lib.bnpc_colcounts_by_label(self._h,
+            ptr(assignment, C.c_int64), ptr(ids, C.c_int64), K, p1, p0),
+            'colcounts_by_label')
+        return n1, n0
+
+    def ll_total(self, theta, FP, FN):
+        """Total log-likelihood(s) under the resident per-cluster counts."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        FP = np.atleast_1d(np.asarray(FP, dtype=np.float64))
+        FN = np.atleast_1d(np.asarray(FN, dtype=np.float64))
+        E = FP.size
+        out = np.empty(E, dtype=np.float64)
+        check(self._lib.bnpc_ll_total(self._h, ptr(theta, C.c_float),
+            theta.shape[0], ptr(FP, C.c_double), ptr(FN, C.c_double), E,
+            ptr(out, C.c_double)), 'll_total')
+        return out
+
+    def timer_start(self):
+        check(self._lib.bnpc_timer_start(self._h), 'timer_start')
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        check(self._lib.bnpc_timer_stop(self._h, C.byref(ms)), 'timer_stop')
+        return ms.value
+
+    def sync(self):
+        check(self._lib.bnpc_sync(self._h), 'sync')

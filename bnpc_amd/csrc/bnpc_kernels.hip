@@ -1,0 +1,838 @@
+// bnpc_kernels.hip - gfx950 (MI355X, CDNA4) kernels and the device half of the
+// C-ABI declared in include/bnpc_hip.h.
+//
+// Design (DESIGN.md sections 3-4), written for wave64 / CDNA4, no MFMA:
+//
+//   * The data matrix lives in HBM twice, as bit planes:
+//       rows [N][W]      {ones, zeros} 64-bit words, cell-major (gather source)
+//       masks[blk][m]    {ones, zeros} 64-bit LANE MASKS over 64 cells
+//     A mask word is exactly an EXEC mask: lane s of the wave owns cell slot
+//     64*blk+s, so "add L1[k][m] to the accumulators of all cells that observed
+//     a 1 at mutation m" is ONE exec-masked v_add_f64 whose mask comes straight
+//     from memory (s_load -> s_and_saveexec) and whose addend is an SGPR pair
+//     (the table element is wave-uniform).  No per-lane bit tests, no selects,
+//     no cross-lane reduction.
+//   * Each lane accumulates its cell's sum over mutations IN INDEX ORDER, so
+//     the result is the reference's strictly sequential bn.nansum
+//     (libs/CRP.py:204) bit for bit once the table elements are equal.
+//   * The per-element logs are hoisted into tables T[g][m][2*KW] (2*K*M logs
+//     instead of N*K*M), laid out so that the 2*KW doubles a wave needs per
+//     mutation are one contiguous run for s_load_dwordx16.
+//   * FP64 throughout (accumulators, tables, outputs).
+//
+// Reference expressions are cited at each kernel (paths relative to
+// /root/reference).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+
+#include "bnpc_hip.h"
+#include "bnpc_internal.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void bnpc_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *bnpc_last_error(void) { return g_err; }
+extern "C" int bnpc_abi_version(void) { return 1; }
+
+#define HIPCHK(expr)                                                         \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            bnpc_set_error("%s failed: %s (%s:%d)", #expr,                   \
+                           hipGetErrorString(e_), __FILE__, __LINE__);       \
+            return 1;                                                        \
+        }                                                                    \
+    } while (0)
+
+#define ARGCHK(cond, msg)                                                    \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            bnpc_set_error("bad argument: %s", msg);                         \
+            return 2;                                                        \
+        }                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct View {
+    DevBuf masks;       // ulonglong2 [nblk][Mpad]
+    int64_t n = 0;      // slots in use
+    int64_t nblk = 0;
+};
+
+struct bnpc_ctx {
+    int device = 0;
+    int64_t N = 0, M = 0;
+    int W = 0;          // 64-bit words per row
+    int Mpad = 0;       // W * 64
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ulonglong2 *rows = nullptr;           // [N][W]
+    std::vector<int32_t> cell_n1, cell_n0;
+    View views[BNPC_MAX_VIEWS];
+    // scratch
+    DevBuf theta, tabs, tab_in, out, cells, chunks, cnt, partial;
+    // resident per-cluster counts of the last bnpc_colcounts_by_label
+    DevBuf lab_cnt;
+    int64_t lab_K = 0;
+    // pinned staging for small D2H
+    void *pin = nullptr;
+    size_t pin_cap = 0;
+};
+
+static int ensure(DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t cap = bytes + bytes / 4 + 256;
+    HIPCHK(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return 0;
+}
+
+static int ensure_pin(bnpc_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pin_cap) return 0;
+    if (c->pin) HIPCHK(hipHostFree(c->pin));
+    c->pin = nullptr;
+    c->pin_cap = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
+    c->pin_cap = cap;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K1: gather rows of a cell list and transpose 64x64 bit tiles into lane masks
+//   replaces `self.data[cells]` (libs/CRP.py:360, 557-560, 636-637, 726-728)
+// one wave per (slot block, row word); lane s loads word w of its cell, then
+// 64 ballots turn bit b of all 64 lanes into the lane mask of mutation 64w+b,
+// which lane b keeps and stores (coalesced 1 KiB per wave).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_transpose(
+    const ulonglong2 *__restrict__ rows, const long long *__restrict__ cells,
+    long long n, int W, ulonglong2 *__restrict__ masks, int Mpad)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (w >= W) return;
+    const long long blk = blockIdx.x;
+    const long long slot = blk * 64 + lane;
+    long long cell = -1;
+    if (slot < n) cell = cells ? cells[slot] : slot;
+    ulonglong2 r = make_ulonglong2(0ull, 0ull);
+    if (cell >= 0) r = rows[(size_t)cell * W + w];
+    ulonglong2 mine = make_ulonglong2(0ull, 0ull);
+#pragma unroll
+    for (int b = 0; b < 64; b++) {
+        unsigned long long mo = __ballot((r.x >> b) & 1ull);
+        unsigned long long mz = __ballot((r.y >> b) & 1ull);
+        if (lane == b) {
+            mine.x = mo;
+            mine.y = mz;
+        }
+    }
+    masks[(size_t)blk * Mpad + (size_t)w * 64 + lane] = mine;
+}
+
+// ---------------------------------------------------------------------------
+// K4a: element tables from float32 parameters
+//   L1 = log(theta*(1-FN) + (1-theta)*FP)      value of an observed 1
+//   L0 = log(theta*FN     + (1-theta)*(1-FP))  value of an observed 0
+//   = the argument of np.log in CRP._calc_ll (libs/CRP.py:198-200) with
+//     _Bernoulli_FN/_FP (libs/CRP.py:207-212) evaluated at x = 1 and x = 0;
+//     theta is float32, (1 - theta) is float32 arithmetic, products and sum
+//     float64, each rounded separately (compiled with -ffp-contract=off).
+// layout T[g][m][2*KW]: [0,KW) = L1 of clusters g*KW.., [KW,2KW) = L0.
+// ---------------------------------------------------------------------------
+template <int KW>
+__global__ __launch_bounds__(256) void k_tables_theta(
+    const float *__restrict__ theta, int K, int M, double FP, double FN,
+    double *__restrict__ T)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (m >= M) return;
+    const double pFN1 = 1.0 - FN;   // (1-FN)**1 * FN**0
+    const double pFP0 = 1.0 - FP;   // (1-FP)**1 * FP**0
+    double *t = T + ((size_t)g * M + m) * (2 * KW);
+#pragma unroll
+    for (int j = 0; j < KW; j++) {
+        const int k = g * KW + j;
+        double l1 = 0.0, l0 = 0.0;
+        if (k < K) {
+            const float th = theta[(size_t)k * M + m];
+            const double th64 = (double)th;
+            const double om64 = (double)(1.0f - th);
+            l1 = log(th64 * pFN1 + om64 * FP);
+            l0 = log(th64 * FN + om64 * pFP0);
+        }
+        t[j] = l1;
+        t[KW + j] = l0;
+    }
+}
+
+// K4b: re-layout caller-built tables L1/L0 [K][M] into T[g][m][2*KW]
+template <int KW>
+__global__ __launch_bounds__(256) void k_tables_relayout(
+    const double *__restrict__ L1, const double *__restrict__ L0, int K, int M,
+    double *__restrict__ T)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (m >= M) return;
+    double *t = T + ((size_t)g * M + m) * (2 * KW);
+#pragma unroll
+    for (int j = 0; j < KW; j++) {
+        const int k = g * KW + j;
+        t[j] = (k < K) ? L1[(size_t)k * M + m] : 0.0;
+        t[KW + j] = (k < K) ? L0[(size_t)k * M + m] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: the cells x clusters x mutations op
+//   out[s][k] = sum_m [x_sm = 1] L1[k][m] + [x_sm = 0] L0[k][m]
+//   = CRP._calc_ll(data[[cell]], parameters[cl_ids]) for every cell at once
+//     (libs/CRP.py:197-204, called from get_lpost_single :223-227 in the
+//     Gibbs sweep :270 and from _rg_get_ll :635-638)
+// lane <-> cell slot, wave <-> (64-slot block, group of KW clusters);
+// masks and table elements are wave-uniform -> scalar loads; the adds are
+// exec-masked v_add_f64 with an SGPR-pair addend; m runs sequentially.
+// ---------------------------------------------------------------------------
+template <int KW>
+__global__ __launch_bounds__(256) void k_ll(
+    const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
+    long long nblk, const double *__restrict__ T, int K, long long ldo,
+    double *__restrict__ out)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long long blk = (long long)blockIdx.x * 4 + wave;
+    const int g = blockIdx.y;
+    if (blk >= nblk) return;     // whole wave leaves together
+
+    const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
+    const double *__restrict__ t = T + (size_t)g * M * (2 * KW);
+
+    double acc[KW];
+#pragma unroll
+    for (int j = 0; j < KW; j++) acc[j] = 0.0;
+
+    for (int m = 0; m < M; m++) {
+        const ulonglong2 p = mk[m];
+        const double *__restrict__ tm = t + (size_t)m * (2 * KW);
+        if (__builtin_amdgcn_inverse_ballot_w64(p.x)) {
+#pragma unroll
+            for (int j = 0; j < KW; j++) acc[j] += tm[j];
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(p.y)) {
+#pragma unroll
+            for (int j = 0; j < KW; j++) acc[j] += tm[KW + j];
+        }
+    }
+
+    const long long slot = blk * 64 + lane;
+    if (slot < n) {
+        double *o = out + (size_t)slot * ldo + (size_t)g * KW;
+#pragma unroll
+        for (int j = 0; j < KW; j++)
+            if (g * KW + j < K) o[j] = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: column counts of 1s and 0s over chunks of cell segments
+//   n1[g][m] = #{c in segment g : x_cm = 1},  n0 likewise
+//   = the sums over a cell subset inside CRP._get_log_A (libs/CRP.py:359-368),
+//     CRP._init_cl_params_new (libs/CRP.py:183-188) and the flat sums of
+//     CRP._get_ll_ratio (libs/CRP.py:716-733), as exact integers.
+// thread <-> mutation; block <-> (chunk of <= 256 cells of one segment, 256
+// mutations); a row word is shared by the 64 lanes of a wave (broadcast load).
+// ---------------------------------------------------------------------------
+struct Chunk {
+    long long begin, end;   // range in the cells[] list
+    long long seg;
+};
+
+__global__ __launch_bounds__(256) void k_colcounts(
+    const ulonglong2 *__restrict__ rows, int W, int M,
+    const long long *__restrict__ cells, const Chunk *__restrict__ chunks,
+    int *__restrict__ n1, int *__restrict__ n0)
+{
+    const Chunk ch = chunks[blockIdx.y];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int w = m >> 6, b = m & 63;
+    int c1 = 0, c0 = 0;
+    for (long long i = ch.begin; i < ch.end; i++) {
+        const long long cell = cells[i];
+        const ulonglong2 r = rows[(size_t)cell * W + w];
+        c1 += (int)((r.x >> b) & 1ull);
+        c0 += (int)((r.y >> b) & 1ull);
+    }
+    if (c1) atomicAdd(&n1[(size_t)ch.seg * M + m], c1);
+    if (c0) atomicAdd(&n0[(size_t)ch.seg * M + m], c0);
+}
+
+// ---------------------------------------------------------------------------
+// K6: total log-likelihood from per-cluster counts, up to 4 trial error pairs
+//   out[e] = sum_{k,m} n1[k][m]*L1_e(theta[k][m]) + n0[k][m]*L0_e(theta[k][m])
+//   = CRP.get_ll_full (libs/CRP.py:237-238) and
+//     CRP_errors_learning.get_ll_full_error (libs/CRP_learning_errors.py:58-63)
+// fixed grid, fixed per-thread order, fixed reduction tree -> deterministic.
+// ---------------------------------------------------------------------------
+#define TOTAL_BLOCKS 256
+
+__global__ __launch_bounds__(256) void k_ll_total(
+    const float *__restrict__ theta, const int *__restrict__ n1,
+    const int *__restrict__ n0, long long KM, int E, double FP0, double FN0,
+    double FP1, double FN1, double FP2, double FN2, double FP3, double FN3,
+    double *__restrict__ partial)
+{
+    const double FPs[4] = {FP0, FP1, FP2, FP3};
+    const double FNs[4] = {FN0, FN1, FN2, FN3};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < KM;
+         i += stride) {
+        const int c1 = n1[i], c0 = n0[i];
+        if ((c1 | c0) == 0) continue;
+        const float th = theta[i];
+        const double th64 = (double)th;
+        const double om64 = (double)(1.0f - th);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (e < E) {
+                const double l1 = log(th64 * (1.0 - FNs[e]) + om64 * FPs[e]);
+                const double l0 = log(th64 * FNs[e] + om64 * (1.0 - FPs[e]));
+                acc[e] += (double)c1 * l1 + (double)c0 * l0;
+            }
+        }
+    }
+    __shared__ double red[4][256];
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[e][threadIdx.x] = acc[e];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                red[e][threadIdx.x] += red[e][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
+        red[threadIdx.x][0];
+}
+
+// ---------------------------------------------------------------------------
+// host side of the C-ABI
+// ---------------------------------------------------------------------------
+extern "C" int bnpc_device_count(int *count)
+{
+    ARGCHK(count, "count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return 0;
+}
+
+extern "C" int bnpc_device_info(int device, char *name, int len, int *cus)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (name && len > 0) {
+        strncpy(name, prop.gcnArchName, len - 1);
+        name[len - 1] = 0;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    return 0;
+}
+
+static int build_view(bnpc_ctx *c, int view, const long long *d_cells,
+                      int64_t n)
+{
+    View &v = c->views[view];
+    v.n = n;
+    v.nblk = (n + 63) / 64;
+    if (n == 0) return 0;
+    if (ensure(v.masks, (size_t)v.nblk * c->Mpad * sizeof(ulonglong2)))
+        return 1;
+    dim3 grid((unsigned)v.nblk, (unsigned)((c->W + 3) / 4));
+    hipLaunchKernelGGL(k_gather_transpose, grid, dim3(256), 0, c->stream,
+                       c->rows, d_cells, (long long)n, c->W,
+                       (ulonglong2 *)v.masks.p, c->Mpad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename GetCode>
+static int create_impl(int device, int64_t N, int64_t M, GetCode code,
+                       bnpc_ctx **out)
+{
+    ARGCHK(out, "out is NULL");
+    ARGCHK(N > 0 && M > 0, "N and M must be positive");
+    ARGCHK(M < (1ll << 30) && N < (1ll << 40), "matrix too large");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    bnpc_ctx *c = new bnpc_ctx();
+    c->device = device;
+    c->N = N;
+    c->M = M;
+    c->W = (int)((M + 63) / 64);
+    c->Mpad = c->W * 64;
+
+    // pack on the host: 2 bits per entry
+    std::vector<ulonglong2> rows((size_t)N * c->W);
+    c->cell_n1.assign(N, 0);
+    c->cell_n0.assign(N, 0);
+    for (int64_t i = 0; i < N; i++) {
+        int32_t s1 = 0, s0 = 0;
+        for (int w = 0; w < c->W; w++) {
+            unsigned long long o = 0, z = 0;
+            const int64_t m0 = (int64_t)w * 64;
+            const int64_t m1 = std::min<int64_t>(M, m0 + 64);
+            for (int64_t m = m0; m < m1; m++) {
+                const int v = code(i, m);
+                if (v == 1) o |= 1ull << (m - m0);
+                else if (v == 0) z |= 1ull << (m - m0);
+                else if (v != 3) {
+                    delete c;
+                    bnpc_set_error("data[%lld,%lld] is not 0, 1 or missing",
+                                   (long long)i, (long long)m);
+                    return 2;
+                }
+            }
+            rows[(size_t)i * c->W + w] = make_ulonglong2(o, z);
+            s1 += __builtin_popcountll(o);
+            s0 += __builtin_popcountll(z);
+        }
+        c->cell_n1[i] = s1;
+        c->cell_n0[i] = s0;
+    }
+
+#define CRCHK(expr)                                                          \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            bnpc_set_error("%s failed: %s", #expr, hipGetErrorString(e_));   \
+            bnpc_destroy(c);                                                 \
+            return 1;                                                        \
+        }                                                                    \
+    } while (0)
+    CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRCHK(hipEventCreate(&c->ev0));
+    CRCHK(hipEventCreate(&c->ev1));
+    CRCHK(hipMalloc((void **)&c->rows, rows.size() * sizeof(ulonglong2)));
+    CRCHK(hipMemcpyAsync(c->rows, rows.data(),
+                         rows.size() * sizeof(ulonglong2),
+                         hipMemcpyHostToDevice, c->stream));
+    if (build_view(c, 0, nullptr, N)) {
+        bnpc_destroy(c);
+        return 1;
+    }
+    CRCHK(hipStreamSynchronize(c->stream));
+#undef CRCHK
+    *out = c;
+    return 0;
+}
+
+extern "C" int bnpc_create(int device, int64_t N, int64_t M,
+                           const double *data_nan, bnpc_ctx **out)
+{
+    ARGCHK(data_nan, "data is NULL");
+    return create_impl(device, N, M, [=](int64_t i, int64_t m) -> int {
+        const double v = data_nan[(size_t)i * M + m];
+        if (v != v) return 3;
+        if (v == 1.0) return 1;
+        if (v == 0.0) return 0;
+        return -1;
+    }, out);
+}
+
+extern "C" int bnpc_create_codes(int device, int64_t N, int64_t M,
+                                 const int8_t *codes, bnpc_ctx **out)
+{
+    ARGCHK(codes, "codes is NULL");
+    return create_impl(device, N, M, [=](int64_t i, int64_t m) -> int {
+        const int v = codes[(size_t)i * M + m];
+        return v == 2 ? 1 : v;      // 2 (homozygous) -> 1, dpmmIO.py:93
+    }, out);
+}
+
+extern "C" int bnpc_destroy(bnpc_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
+                      &c->chunks, &c->cnt, &c->partial, &c->lab_cnt};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (View &v : c->views)
+        if (v.masks.p) (void)hipFree(v.masks.p);
+    if (c->rows) (void)hipFree(c->rows);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int bnpc_shape(const bnpc_ctx *c, int64_t *N, int64_t *M)
+{
+    ARGCHK(c, "ctx is NULL");
+    if (N) *N = c->N;
+    if (M) *M = c->M;
+    return 0;
+}
+
+extern "C" int bnpc_cell_counts(bnpc_ctx *c, int32_t *n1, int32_t *n0)
+{
+    ARGCHK(c && n1 && n0, "NULL argument");
+    memcpy(n1, c->cell_n1.data(), c->N * sizeof(int32_t));
+    memcpy(n0, c->cell_n0.data(), c->N * sizeof(int32_t));
+    return 0;
+}
+
+extern "C" int bnpc_view_set(bnpc_ctx *c, int view, const int64_t *cells,
+                             int64_t n)
+{
+    ARGCHK(c, "ctx is NULL");
+    ARGCHK(view >= 1 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(n >= 0 && (n == 0 || cells), "cells is NULL");
+    for (int64_t i = 0; i < n; i++)
+        ARGCHK(cells[i] >= 0 && cells[i] < c->N, "cell index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) {
+        c->views[view].n = 0;
+        c->views[view].nblk = 0;
+        return 0;
+    }
+    if (ensure(c->cells, n * sizeof(long long))) return 1;
+    HIPCHK(hipMemcpyAsync(c->cells.p, cells, n * sizeof(long long),
+                          hipMemcpyHostToDevice, c->stream));
+    if (build_view(c, view, (const long long *)c->cells.p, n)) return 1;
+    // the caller's buffer is only borrowed: finish the copy before returning
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bnpc_view_size(const bnpc_ctx *c, int view, int64_t *n)
+{
+    ARGCHK(c && n, "NULL argument");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    *n = c->views[view].n;
+    return 0;
+}
+
+// choose clusters-per-wave so that the launch fills the chip
+static int pick_kw(int64_t nblk, int64_t K)
+{
+    const int64_t wgs = (nblk + 3) / 4;
+    const int kws[] = {8, 4, 2, 1};
+    for (int kw : kws) {
+        if (kw > 1 && K < kw) continue;
+        if (wgs * ((K + kw - 1) / kw) >= 1024) return kw;
+    }
+    return K >= 2 ? (K >= 16 ? 2 : 1) : 1;
+}
+
+template <int KW>
+static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
+                     bool from_theta, double FP, double FN, double *d_out)
+{
+    const int64_t G = (K + KW - 1) / KW;
+    ARGCHK(G <= 65535, "too many cluster groups for one launch");
+    if (ensure(c->tabs, (size_t)G * c->M * 2 * KW * sizeof(double))) return 1;
+    dim3 tgrid((unsigned)((c->M + 255) / 256), (unsigned)G);
+    if (from_theta)
+        hipLaunchKernelGGL(k_tables_theta<KW>, tgrid, dim3(256), 0, c->stream,
+                           (const float *)c->theta.p, (int)K, (int)c->M, FP,
+                           FN, (double *)c->tabs.p);
+    else
+        hipLaunchKernelGGL(k_tables_relayout<KW>, tgrid, dim3(256), 0,
+                           c->stream, (const double *)c->tab_in.p,
+                           (const double *)c->tab_in.p + (size_t)K * c->M,
+                           (int)K, (int)c->M, (double *)c->tabs.p);
+    HIPCHK(hipGetLastError());
+    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)G);
+    hipLaunchKernelGGL(k_ll<KW>, grid, dim3(256), 0, c->stream,
+                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
+                       (long long)v.n, (long long)v.nblk,
+                       (const double *)c->tabs.p, (int)K, (long long)ldo,
+                       d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
+                     bool from_theta, double FP, double FN, double *out)
+{
+    const View &v = c->views[view];
+    if (v.n == 0 || K == 0) return 0;
+    if (ldo == 0) ldo = K;
+    ARGCHK(ldo >= K, "ldo smaller than K");
+    const size_t out_bytes = (size_t)v.n * ldo * sizeof(double);
+    if (ensure(c->out, out_bytes)) return 1;
+    int kw = pick_kw(v.nblk, K);
+    const char *force = getenv("BNPC_KW");
+    if (force) {
+        int f = atoi(force);
+        if (f == 1 || f == 2 || f == 4 || f == 8) kw = f;
+    }
+    int rc;
+    switch (kw) {
+    case 8: rc = launch_ll<8>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
+    case 4: rc = launch_ll<4>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
+    case 2: rc = launch_ll<2>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
+    default: rc = launch_ll<1>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
+    }
+    if (rc) return rc;
+    if (out) {
+        HIPCHK(hipMemcpyAsync(out, c->out.p, out_bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
+                             int64_t K, double FP, double FN, double *out,
+                             int64_t ldo)
+{
+    ARGCHK(c, "ctx is NULL");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(K >= 0 && (K == 0 || theta), "theta is NULL");
+    ARGCHK(FP > 0.0 && FP < 1.0 && FN > 0.0 && FN < 1.0,
+           "error rates must lie in (0, 1)");
+    HIPCHK(hipSetDevice(c->device));
+    if (K == 0) return 0;
+    const size_t bytes = (size_t)K * c->M * sizeof(float);
+    if (ensure(c->theta, bytes)) return 1;
+    HIPCHK(hipMemcpyAsync(c->theta.p, theta, bytes, hipMemcpyHostToDevice,
+                          c->stream));
+    return ll_common(c, view, K, ldo, true, FP, FN, out);
+}
+
+extern "C" int bnpc_ll_tables(bnpc_ctx *c, int view, const double *L1,
+                              const double *L0, int64_t K, double *out,
+                              int64_t ldo)
+{
+    ARGCHK(c, "ctx is NULL");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(K >= 0 && (K == 0 || (L1 && L0)), "table is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (K == 0) return 0;
+    const size_t bytes = (size_t)K * c->M * sizeof(double);
+    if (ensure(c->tab_in, 2 * bytes)) return 1;
+    HIPCHK(hipMemcpyAsync(c->tab_in.p, L1, bytes, hipMemcpyHostToDevice,
+                          c->stream));
+    HIPCHK(hipMemcpyAsync((char *)c->tab_in.p + bytes, L0, bytes,
+                          hipMemcpyHostToDevice, c->stream));
+    return ll_common(c, view, K, ldo, false, 0.0, 0.0, out);
+}
+
+// ---- column counts ---------------------------------------------------------
+static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
+                            const int64_t *seg_offsets, int64_t G,
+                            DevBuf &cnt)
+{
+    const size_t cnt_bytes = (size_t)2 * G * c->M * sizeof(int32_t);
+    if (ensure(cnt, cnt_bytes)) return 1;
+    HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_bytes, c->stream));
+    std::vector<Chunk> chunks;
+    const int64_t CH = 256;
+    for (int64_t g = 0; g < G; g++)
+        for (int64_t b = seg_offsets[g]; b < seg_offsets[g + 1]; b += CH)
+            chunks.push_back(
+                {(long long)b,
+                 (long long)std::min<int64_t>(seg_offsets[g + 1], b + CH),
+                 (long long)g});
+    if (chunks.empty()) return 0;
+    if (ensure(c->cells, n_cells * sizeof(long long))) return 1;
+    if (ensure(c->chunks, chunks.size() * sizeof(Chunk))) return 1;
+    HIPCHK(hipMemcpyAsync(c->cells.p, cells, n_cells * sizeof(long long),
+                          hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->chunks.p, chunks.data(),
+                          chunks.size() * sizeof(Chunk),
+                          hipMemcpyHostToDevice, c->stream));
+    int *n1 = (int *)cnt.p;
+    int *n0 = n1 + (size_t)G * c->M;
+    // the chunk list lives in a std::vector: finish the copy before it dies
+    const size_t maxy = 65535;
+    for (size_t off = 0; off < chunks.size(); off += maxy) {
+        const size_t ny = std::min(maxy, chunks.size() - off);
+        dim3 grid((unsigned)((c->M + 255) / 256), (unsigned)ny);
+        hipLaunchKernelGGL(k_colcounts, grid, dim3(256), 0, c->stream,
+                           c->rows, c->W, (int)c->M,
+                           (const long long *)c->cells.p,
+                           (const Chunk *)c->chunks.p + off, n1, n0);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bnpc_colcounts(bnpc_ctx *c, const int64_t *cells,
+                              const int64_t *seg_offsets, int64_t G,
+                              int32_t *n1, int32_t *n0)
+{
+    ARGCHK(c && seg_offsets && n1 && n0, "NULL argument");
+    ARGCHK(G >= 0, "G negative");
+    if (G == 0) return 0;
+    ARGCHK(seg_offsets[0] == 0, "seg_offsets[0] must be 0");
+    const int64_t n = seg_offsets[G];
+    for (int64_t g = 0; g < G; g++)
+        ARGCHK(seg_offsets[g] <= seg_offsets[g + 1], "seg_offsets not sorted");
+    ARGCHK(n == 0 || cells, "cells is NULL");
+    for (int64_t i = 0; i < n; i++)
+        ARGCHK(cells[i] >= 0 && cells[i] < c->N, "cell index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    if (colcounts_device(c, cells, n, seg_offsets, G, c->cnt)) return 1;
+    const size_t half = (size_t)G * c->M * sizeof(int32_t);
+    HIPCHK(hipMemcpyAsync(n1, c->cnt.p, half, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipMemcpyAsync(n0, (char *)c->cnt.p + half, half,
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
+                                       const int64_t *ids, int64_t K,
+                                       int32_t *n1, int32_t *n0)
+{
+    ARGCHK(c && assignment && ids, "NULL argument");
+    ARGCHK(K > 0, "K must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    // counting sort of the cells by the position of their label in ids[]
+    int64_t max_id = 0;
+    for (int64_t g = 0; g < K; g++) {
+        ARGCHK(ids[g] >= 0, "negative cluster id");
+        max_id = std::max(max_id, ids[g]);
+    }
+    std::vector<int64_t> pos(max_id + 1, -1);
+    for (int64_t g = 0; g < K; g++) {
+        ARGCHK(pos[ids[g]] < 0, "duplicate cluster id");
+        pos[ids[g]] = g;
+    }
+    std::vector<int64_t> offs(K + 1, 0);
+    for (int64_t i = 0; i < c->N; i++) {
+        const int64_t a = assignment[i];
+        ARGCHK(a >= 0 && a <= max_id && pos[a] >= 0,
+               "assignment holds an id that is not in ids");
+        offs[pos[a] + 1]++;
+    }
+    for (int64_t g = 0; g < K; g++) offs[g + 1] += offs[g];
+    std::vector<int64_t> cells(c->N), fill(offs.begin(), offs.end() - 1);
+    for (int64_t i = 0; i < c->N; i++)
+        cells[fill[pos[assignment[i]]]++] = i;
+    if (colcounts_device(c, cells.data(), c->N, offs.data(), K, c->lab_cnt))
+        return 1;
+    c->lab_K = K;
+    if (n1 && n0) {
+        const size_t half = (size_t)K * c->M * sizeof(int32_t);
+        HIPCHK(hipMemcpyAsync(n1, c->lab_cnt.p, half, hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipMemcpyAsync(n0, (char *)c->lab_cnt.p + half, half,
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
+                             const double *FP, const double *FN, int E,
+                             double *out)
+{
+    ARGCHK(c && theta && FP && FN && out, "NULL argument");
+    ARGCHK(E >= 1 && E <= BNPC_MAX_TRIALS, "E out of range");
+    ARGCHK(K == c->lab_K && K > 0,
+           "K does not match the resident counts (call "
+           "bnpc_colcounts_by_label first)");
+    for (int e = 0; e < E; e++)
+        ARGCHK(FP[e] > 0.0 && FP[e] < 1.0 && FN[e] > 0.0 && FN[e] < 1.0,
+               "error rates must lie in (0, 1)");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)K * c->M * sizeof(float);
+    if (ensure(c->theta, bytes)) return 1;
+    if (ensure(c->partial, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
+    if (ensure_pin(c, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
+    HIPCHK(hipMemcpyAsync(c->theta.p, theta, bytes, hipMemcpyHostToDevice,
+                          c->stream));
+    double fp[4] = {0.5, 0.5, 0.5, 0.5}, fn[4] = {0.5, 0.5, 0.5, 0.5};
+    for (int e = 0; e < E; e++) {
+        fp[e] = FP[e];
+        fn[e] = FN[e];
+    }
+    const int *n1 = (const int *)c->lab_cnt.p;
+    const int *n0 = n1 + (size_t)K * c->M;
+    hipLaunchKernelGGL(k_ll_total, dim3(TOTAL_BLOCKS), dim3(256), 0, c->stream,
+                       (const float *)c->theta.p, n1, n0,
+                       (long long)(K * c->M), E, fp[0], fn[0], fp[1], fn[1],
+                       fp[2], fn[2], fp[3], fn[3], (double *)c->partial.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->pin, c->partial.p,
+                          TOTAL_BLOCKS * 4 * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double *p = (const double *)c->pin;
+    for (int e = 0; e < E; e++) {
+        double s = 0.0;
+        for (int b = 0; b < TOTAL_BLOCKS; b++) s += p[b * 4 + e];
+        out[e] = s;
+    }
+    return 0;
+}
+
+extern "C" int bnpc_timer_start(bnpc_ctx *c)
+{
+    ARGCHK(c, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+extern "C" int bnpc_timer_stop(bnpc_ctx *c, float *ms)
+{
+    ARGCHK(c && ms, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+extern "C" int bnpc_sync(bnpc_ctx *c)
+{
+    ARGCHK(c, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}

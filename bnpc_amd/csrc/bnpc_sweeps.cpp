@@ -1,0 +1,276 @@
+// bnpc_sweeps.cpp - the sequential halves of the sampler moves, native.
+//
+// After the cells x clusters x mutations op runs on the GPU, what remains of a
+// Gibbs sweep is a loop over cells that is sequential by construction (cluster
+// sizes and newly opened clusters feed forward): CRP.update_assignments_Gibbs,
+// /root/reference/libs/CRP.py:260-288.  In Python that loop costs 100-200 us
+// per cell ("Amdahl on the host"); here it is O(K) flops
+// per cell.  To keep the assignment TRAJECTORY identical, the loop draws from
+// an exact replica of NumPy's legacy global stream (MT19937 + the legacy
+// random_sample / random_interval / choice(p=) algorithms), whose state is
+// exchanged with np.random.get_state()/set_state().
+//
+// NumPy is a third-party dependency of the reference (unpinned, implied by
+// requirements.txt:1-5); the algorithms restated here are those of
+// numpy/random/_legacy (mt19937 genrand, legacy_double, random_interval,
+// RandomState.choice), pinned by golden vectors captured from NumPy itself
+// (tests/golden/rng.npz, tests/test_native_sweeps.py).
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "bnpc_hip.h"
+#include "bnpc_internal.h"
+
+// ---------------------------------------------------------------------------
+// MT19937 (Matsumoto & Nishimura), state layout of np.random.get_state()
+// ---------------------------------------------------------------------------
+static inline void mt_refill(bnpc_mt19937 *s)
+{
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
+    uint32_t *k = s->key;
+    int i;
+    uint32_t y;
+    for (i = 0; i < 624 - 397; i++) {
+        y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+        k[i] = k[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+    }
+    for (; i < 623; i++) {
+        y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+        k[i] = k[i + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+    }
+    y = (k[623] & UPPER) | (k[0] & LOWER);
+    k[623] = k[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+    s->pos = 0;
+}
+
+static inline uint32_t mt_next32(bnpc_mt19937 *s)
+{
+    if (s->pos >= 624) mt_refill(s);
+    uint32_t y = s->key[s->pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+static inline double mt_double(bnpc_mt19937 *s)
+{
+    const int32_t a = (int32_t)(mt_next32(s) >> 5);
+    const int32_t b = (int32_t)(mt_next32(s) >> 6);
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+// legacy random_interval: uniform integer in [0, max], masked rejection
+static inline uint64_t mt_interval(bnpc_mt19937 *s, uint64_t max)
+{
+    if (max == 0) return 0;
+    uint64_t mask = max;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    mask |= mask >> 32;
+    uint64_t v;
+    if (max <= 0xffffffffull) {
+        while ((v = (mt_next32(s) & mask)) > max) {}
+    } else {
+        for (;;) {
+            const uint64_t hi = mt_next32(s), lo = mt_next32(s);
+            v = ((hi << 32) | lo) & mask;
+            if (v <= max) break;
+        }
+    }
+    return v;
+}
+
+extern "C" double bnpc_mt_random_sample(bnpc_mt19937 *rng)
+{
+    return mt_double(rng);
+}
+
+extern "C" int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out)
+{
+    if (!rng || (n > 0 && !out)) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    for (int64_t i = 0; i < n; i++) out[i] = i;
+    for (int64_t i = n - 1; i >= 1; i--) {
+        const int64_t j = (int64_t)mt_interval(rng, (uint64_t)i);
+        const int64_t t = out[i];
+        out[i] = out[j];
+        out[j] = t;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Gibbs sweep
+// ---------------------------------------------------------------------------
+static const double LOG_EPS = -34.538776394910684;   // np.log(1e-15)
+
+extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
+                                const int64_t *perm, const double *ll,
+                                const double *post_new,
+                                const double *crp_prior, int64_t *assignment,
+                                int64_t *col_of_id, int64_t *col_id,
+                                int64_t *col_size, int64_t *order,
+                                double *scratch)
+{
+    if (!st || !rng || !perm || !ll || !post_new || !crp_prior ||
+        !assignment || !col_of_id || !col_id || !col_size || !order ||
+        !scratch) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    const int64_t N = st->n_cells, ld = st->ld;
+    double *post = scratch;             // ld + 1
+    double *cdf = scratch + ld + 1;     // ld + 1
+    st->new_cell = -1;
+
+    while (st->pos < N) {
+        const int64_t cell = perm[st->pos];
+        if (cell < 0 || cell >= N) {
+            bnpc_set_error("perm[%lld] out of range", (long long)st->pos);
+            return 2;
+        }
+        // remove the cell from its cluster (CRP.py:262-266)
+        const int64_t old_id = assignment[cell];
+        const int64_t old_col = (old_id >= 0 && old_id < N) ?
+            col_of_id[old_id] : -1;
+        if (old_col < 0 || old_col >= st->n_cols || col_size[old_col] < 1) {
+            bnpc_set_error("cell %lld sits in unknown cluster %lld",
+                           (long long)cell, (long long)old_id);
+            return 3;
+        }
+        if (col_size[old_col] == 1) {
+            int64_t a = 0;
+            while (a < st->n_active && order[a] != old_col) a++;
+            memmove(order + a, order + a + 1,
+                    (size_t)(st->n_active - a - 1) * sizeof(int64_t));
+            st->n_active--;
+            col_size[old_col] = 0;
+            col_of_id[old_id] = -1;
+        } else {
+            col_size[old_col]--;
+        }
+
+        // log posterior of joining each live cluster / a new one (:268-274)
+        const int64_t A = st->n_active;
+        const double *row = ll + (size_t)cell * ld;
+        int64_t top = 0;
+        for (int64_t a = 0; a < A; a++) {
+            const int64_t c = order[a];
+            post[a] = row[c] + crp_prior[col_size[c]];
+            if (post[a] > post[top]) top = a;
+        }
+        post[A] = post_new[cell];
+        if (post[A] > post[top]) top = A;
+
+        // _normalize_log_probs (CRP.py:88-100)
+        const double ptop = post[top];
+        double tail = 0.0;
+        for (int64_t a = 0; a <= A; a++)
+            if (a != top) tail += exp(post[a] - ptop);
+        const double lnorm = log1p(tail);
+        // choice(p=): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, right)
+        double run = 0.0;
+        for (int64_t a = 0; a <= A; a++) {
+            double v = post[a] - ptop - lnorm;
+            if (v < LOG_EPS) v = LOG_EPS;
+            if (v > 0.0) v = 0.0;
+            run += exp(v);
+            cdf[a] = run;
+        }
+        const double total = cdf[A];
+        const double u = mt_double(rng);
+        int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cdf[mid] / total > u) hi = mid;
+            else lo = mid + 1;
+        }
+        int64_t pick = lo;
+        if (pick > A) pick = A;
+
+        st->pos++;
+        if (pick == A) {                  // open a new cluster in the caller
+            st->new_cell = cell;
+            return 0;
+        }
+        const int64_t c = order[pick];
+        assignment[cell] = col_id[c];
+        col_size[c]++;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// restricted Gibbs 2-way scans (CRP.py:609-632 and :800-820)
+// ---------------------------------------------------------------------------
+extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
+                            const double *ll, double DP_a,
+                            int64_t *rg_assignment, const int64_t *target,
+                            double *log_prob)
+{
+    if ((mode == 0 && !rng) || (S > 0 && (!ll || !rg_assignment)) ||
+        (mode == 1 && S > 0 && !target) || !log_prob) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    const int64_t n = S + 2;
+    const double lden = log((double)(n - 1) + DP_a);
+    std::vector<int64_t> perm(S);
+    std::vector<double> prob(S, 0.0);
+    if (mode == 0) {
+        bnpc_mt_permutation(rng, S, perm.data());
+    } else {
+        for (int64_t s = 0; s < S; s++) perm[s] = s;
+    }
+    int64_t ones = 0;
+    for (int64_t s = 0; s < S; s++) ones += (rg_assignment[s] == 1);
+
+    for (int64_t t = 0; t < S; t++) {
+        const int64_t cell = perm[t];
+        // take the cell out: n_j = sum(rg) + 2 with rg[cell] = -1
+        ones -= (rg_assignment[cell] == 1);
+        const int64_t n_j = ones + 1;
+        const int64_t n_i = n - n_j - 1;
+        const double p0 = ll[2 * cell] + (log((double)n_i) - lden);
+        const double p1 = ll[2 * cell + 1] + (log((double)n_j) - lden);
+        // _normalize_log for two entries; first maximum wins ties
+        double l0, l1;
+        if (p1 > p0) {
+            const double z = log1p(exp(p0 - p1));
+            l0 = p0 - p1 - z;
+            l1 = p1 - p1 - z;
+        } else {
+            const double z = log1p(exp(p1 - p0));
+            l0 = p0 - p0 - z;
+            l1 = p1 - p0 - z;
+        }
+        int64_t pick;
+        if (mode == 0) {
+            // np.random.choice([0, 1], p=np.exp(log_probs))
+            const double e0 = exp(l0), e1 = exp(l1);
+            const double c0 = e0, c1 = e0 + e1;
+            const double u = mt_double(rng);
+            pick = (c0 / c1 > u) ? 0 : 1;
+            if (!(c1 / c1 > u)) pick = 1;
+        } else {
+            pick = target[cell] ? 1 : 0;
+        }
+        rg_assignment[cell] = pick;
+        ones += (pick == 1);
+        prob[cell] = pick ? l1 : l0;
+    }
+    double sum = 0.0;
+    for (int64_t s = 0; s < S; s++) sum += prob[s];
+    *log_prob = sum;
+    return 0;
+}

@@ -1,0 +1,903 @@
+"""GPU-backed mirror of the reference's model classes.
+
+Same public surface, attributes, return values and consumption order of the
+global legacy ``np.random`` stream as
+
+    CRP                   /root/reference/libs/CRP.py:17-820
+    CRP_errors_learning   /root/reference/libs/CRP_learning_errors.py:17-111
+
+so that the sampler driver (libs/MCMC.py, or bnpc_amd.mcmc) runs unchanged on
+top.  Underneath, every cells x mutations (x clusters) array expression of the
+reference is one of four device primitives of libbnpc_hip.so
+(include/bnpc_hip.h):
+
+    ll_theta / ll_tables   per-cell log-likelihood sums  (_calc_ll, axis=1)
+    colcounts(_by_label)   per-subset counts of 1s / 0s per mutation; every
+                           sum over CELLS of log(theta*P1 + (1-theta)*P0) is
+                           then n1*L1(theta) + n0*L0(theta), O(M) on the host
+    ll_total               the flat total (get_ll_full, get_ll_full_error)
+    gibbs_sweep / rg_scan  the sequential per-cell loops, native, on an exact
+                           replica of NumPy's legacy MT19937 stream
+
+Host NumPy arrays stay the source of truth for ``assignment``, ``parameters``
+and ``cells_per_cluster`` (the driver reads them, MCMC.py:255-282); the
+device context is created lazily in the worker process (after fork) and is
+dropped on pickle/deepcopy (MCMC.py:115-128).
+
+There is no CPU fallback: without the HIP library / a GPU the first device
+call raises RuntimeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+from scipy.special import gamma as _gamma_fn, gammaln
+from scipy.stats import beta as _beta_dist, truncnorm
+from scipy.stats import gamma as _gamma_dist
+
+from bnpc_amd import _lib
+
+# the reference traps these and uses FloatingPointError as control flow
+# (libs/CRP.py:10)
+np.seterr(divide='raise', over='ignore', under='ignore', invalid='raise')
+
+EPSILON = np.finfo(np.float64).resolution
+TMIN = 1e-5
+TMAX = 1 - TMIN
+log_EPSILON = np.log(EPSILON)
+
+VIEW_ALL = 0      # identity view: all cells
+VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
+
+
+class CRP:
+    """DPMM of Bernoulli profiles with fixed error rates (libs/CRP.py:17)."""
+
+    def __init__(self, data, DP_alpha=-1, param_beta=[1, 1],
+                FN_error=EPSILON, FP_error=EPSILON):
+        self.data = data
+        self.cells_total, self.muts_total = data.shape
+
+        self.p, self.q = param_beta
+        self.param_prior = _beta_dist(self.p, self.q)
+        self.beta_prior_uniform = bool(self.p == self.q == 1)
+        m0 = self.beta_fct(self.p, self.q + 1)
+        m1 = self.beta_fct(self.p + 1, self.q)
+        self._beta_mix_const = np.array([m0, m1]) / (m0 + m1)
+
+        self.FP = FP_error
+        self.FN = FN_error
+
+        try:
+            neg = DP_alpha[0] < 0 or DP_alpha[1] < 0
+        except TypeError:
+            neg = True
+        self.DP_a_gamma = (np.sqrt(self.cells_total), 1) if neg else DP_alpha
+        self.DP_a_prior = _gamma_dist(*self.DP_a_gamma)
+        self.DP_a = self.DP_a_prior.mean()
+
+        self.CRP_prior = None
+        self.assignment = None
+        self.parameters = None
+        self.cells_per_cluster = None
+        self.param_proposal_sd = np.array([0.1, 0.25, 0.5])
+
+        self._reset_device_state()
+
+    # ---------------------------------------------------------- life cycle
+    def _reset_device_state(self):
+        self._ctx = None
+        self._newcl = None          # ((FP, FN), per-cell sums)
+        self._lab = None            # per-cluster column counts cache
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_ctx'] = None
+        state['_newcl'] = None
+        state['_lab'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def _dev(self):
+        """The device context of this chain, created on first use."""
+        if self._ctx is None:
+            device = int(os.environ.get('BNPC_DEVICE', '0'))
+            self._ctx = _lib.Context(data=self.data, device=device)
+        return self._ctx
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+        self._reset_device_state()
+
+    def __str__(self):
+        return ('\nDPMM with:\n'
+            f'\t{self.cells_total} cells\n\t{self.muts_total} mutations\n'
+            f'\tFixed FN rate: {self.FN}\n\tFixed FP rate: {self.FP}\n'
+            '\n\tPriors:\n'
+            f'\tParams.:\tBeta({self.p},{self.q})\n'
+            f'\tCRP a_0:\tGamma({self.DP_a_gamma[0]:.1f},'
+            f'{self.DP_a_gamma[1]})\n')
+
+    # -------------------------------------------------------------- statics
+    @staticmethod
+    def beta_fct(p, q):
+        return _gamma_fn(p) * _gamma_fn(q) / _gamma_fn(p + q)
+
+    @staticmethod
+    def log_CRP_prior(n_i, n, a, dtype=np.float64):
+        return np.log(n_i, dtype=dtype) - np.log(n - 1 + a, dtype=dtype)
+
+    @staticmethod
+    def _normalize_log_probs(probs):
+        """libs/CRP.py:88-100 (host; the sweep uses the native replica)."""
+        top = int(np.nanargmax(probs))
+        others = np.arange(probs.size) != top
+        shifted = probs[others] - probs[top]
+        try:
+            tail = np.exp(shifted)
+        except FloatingPointError:
+            tail = np.exp(np.clip(shifted, log_EPSILON, 0))
+        lnorm = probs - probs[top] - np.log1p(np.cumsum(tail)[-1]
+            if tail.size else 0.0)
+        return np.exp(np.clip(lnorm, log_EPSILON, 0))
+
+    @staticmethod
+    def _normalize_log(probs):
+        """libs/CRP.py:103-116"""
+        top = int(np.nanargmax(probs))
+        others = np.arange(probs.size) != top
+        try:
+            tail = np.exp(probs[others] - probs[top])
+            res = probs - probs[top] - np.log1p(np.cumsum(tail)[-1])
+        except FloatingPointError:
+            if probs[0] > probs[1]:
+                return np.array([0, log_EPSILON])
+            return np.array([log_EPSILON, 0])
+        return res
+
+    # ----------------------------------------------------- element tables
+    def _tables(self, theta, FP=None, FN=None):
+        """The two values log(theta*P(x|1) + (1-theta)*P(x|0)) can take:
+        L1 for an observed 1, L0 for an observed 0 (libs/CRP.py:198-200 with
+        :207-212 at x = 1 / x = 0).  (1 - theta) is evaluated in theta's own
+        dtype (float32 for cluster parameters), everything else in float64."""
+        FP = self.FP if FP is None else FP
+        FN = self.FN if FN is None else FN
+        theta = np.asarray(theta)
+        t64 = theta.astype(np.float64)
+        om64 = (1 - theta).astype(np.float64)
+        L1 = np.log(t64 * (1 - FN) + om64 * FP)
+        L0 = np.log(t64 * FN + om64 * (1 - FP))
+        return L1, L0
+
+    def _subset_ll(self, theta, counts, FP=None, FN=None):
+        """sum over the cells of a subset of the per-element log-likelihood,
+        per mutation: n1*L1 + n0*L0 (the bn.nansum(axis=0) of
+        libs/CRP.py:363-368)."""
+        L1, L0 = self._tables(theta, FP, FN)
+        return counts[0] * L1 + counts[1] * L0
+
+    def _counts_of(self, cells):
+        """(n1, n0) float64 M-vectors: observed 1s / 0s per mutation."""
+        cells = np.asarray(cells, dtype=np.int64).reshape(-1)
+        if cells.size <= 2:
+            sub = self.data[cells]
+            return (np.nansum(sub, axis=0),
+                np.nansum(1 - sub, axis=0))
+        n1, n0 = self._dev().colcounts([cells])
+        return n1[0].astype(np.float64), n0[0].astype(np.float64)
+
+    # ----------------------------------------------------------------- init
+    def init(self, mode='random', assign=False):
+        """libs/CRP.py:119-152"""
+        self._newcl = None
+        self._lab = None
+        N = self.cells_total
+        if assign:
+            labels = np.array(assign)
+        elif mode == 'separate':
+            labels = np.arange(N, dtype=int)
+        elif mode == 'together':
+            labels = np.zeros(N, dtype=int)
+        elif mode == 'random':
+            labels = np.random.randint(0, high=N, size=N)
+        else:
+            raise TypeError(f'Unsupported Initialization: {mode}')
+        _, inv, counts = np.unique(labels, return_inverse=True,
+            return_counts=True)
+        self.assignment = np.ascontiguousarray(inv.reshape(-1), dtype=np.int64)
+        self.cells_per_cluster = {i: c for i, c in enumerate(counts)}
+        self.parameters = self._init_cl_params('assign' if assign else mode)
+        self.init_DP_prior()
+
+    def _init_cl_params(self, mode='random', fkt=1):
+        """libs/CRP.py:155-180.  Rows of unpopulated ids hold TMIN (a zero
+        clipped), as in the reference."""
+        N, M = self.data.shape
+        params = np.full((N, M), np.float32(TMIN), dtype=np.float32)
+        if mode == 'separate':
+            draw = np.random.beta(
+                np.nan_to_num(self.p + self.data * fkt,
+                    nan=self._beta_mix_const[0]),
+                np.nan_to_num(self.q + (1 - self.data) * fkt,
+                    nan=self._beta_mix_const[1]))
+            params = np.clip(draw, TMIN, TMAX).astype(np.float32)
+        elif mode == 'together':
+            n1, n0 = self._counts_of(np.arange(N))
+            params[0] = self._beta_draw(n1 * fkt, n0 * fkt)
+        elif mode == 'assign':
+            ids = list(self.cells_per_cluster)
+            n1, n0 = self._dev().colcounts_by_label(self.assignment, ids)
+            for row, cl in enumerate(ids):
+                params[cl] = self._beta_draw(n1[row] * fkt, n0[row] * fkt)
+        elif mode == 'random':
+            k = np.unique(self.assignment)
+            draw = np.random.uniform(size=(k.size, M))
+            params[k] = np.clip(draw, TMIN, TMAX).astype(np.float32)
+        return params
+
+    def _beta_draw(self, n1, n0):
+        draw = np.random.beta(self.p + n1, self.q + n0)
+        return np.clip(draw, TMIN, TMAX).astype(np.float32)
+
+    def _init_cl_params_new(self, i, fkt=1):
+        """Beta draw from the column counts of cells i (libs/CRP.py:183-188)."""
+        n1, n0 = self._counts_of(i)
+        return self._beta_draw(n1 * fkt, n0 * fkt)
+
+    def init_DP_prior(self):
+        """libs/CRP.py:191-194"""
+        sizes = np.append(np.arange(1, self.cells_total + 1), self.DP_a)
+        self.CRP_prior = np.append(
+            0, self.log_CRP_prior(sizes, self.cells_total, self.DP_a))
+
+    # ------------------------------------------------- likelihood surface
+    def _Bernoulli_FN(self, x):
+        return (1 - self.FN) ** x * self.FN ** (1 - x)
+
+    def _Bernoulli_FP(self, x):
+        return (1 - self.FP) ** (1 - x) * self.FP ** x
+
+    def _calc_ll(self, x, theta, flat=False):
+        """Host form of libs/CRP.py:197-204 for callers that hand in raw
+        rows; the sampler itself never takes this route."""
+        mixed = theta * self._Bernoulli_FN(x) \
+            + (1 - theta) * self._Bernoulli_FP(x)
+        ll = np.nan_to_num(np.log(mixed), nan=0.0)
+        if flat:
+            return np.cumsum(ll.ravel())[-1] if ll.size else 0.0
+        return np.cumsum(ll, axis=1)[:, -1]
+
+    def get_lpost_single(self, cell_id, cl_ids):
+        """libs/CRP.py:223-227 (one cell; the sweep evaluates all at once)."""
+        ctx = self._dev()
+        ctx.view_set(VIEW_MOVE + 1, [cell_id])
+        ll = ctx.ll_theta(VIEW_MOVE + 1, self.parameters[cl_ids], self.FP,
+            self.FN)[0]
+        sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
+        return ll + self.CRP_prior[sizes]
+
+    def _new_cluster_ll(self):
+        """Per-cell sum over mutations of log(mix1*P(x|1) + mix0*P(x|0)):
+        an m-sequential device sum over constant tables, cached per (FP, FN)."""
+        key = (self.FP, self.FN)
+        if self._newcl is None or self._newcl[0] != key:
+            mix0, mix1 = self._beta_mix_const
+            c1 = np.log(np.array([mix1 * (1 - self.FN) + mix0 * self.FP]))[0]
+            c0 = np.log(np.array([mix1 * self.FN + mix0 * (1 - self.FP)]))[0]
+            M = self.muts_total
+            ll = self._dev().ll_tables(VIEW_ALL, np.full((1, M), c1),
+                np.full((1, M), c0))[:, 0]
+            self._newcl = (key, ll)
+        return self._newcl[1]
+
+    def get_lpost_single_new_cluster(self):
+        """libs/CRP.py:230-234"""
+        return self._new_cluster_ll() + self.CRP_prior[-1]
+
+    # per-cluster column counts, valid while the assignment is unchanged
+    def _label_counts(self):
+        ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
+        lab = self._lab
+        if lab is not None and np.array_equal(lab['ids'], ids) \
+                and np.array_equal(lab['assignment'], self.assignment):
+            return lab
+        n1, n0 = self._dev().colcounts_by_label(self.assignment, ids)
+        self._lab = {'ids': ids, 'assignment': self.assignment.copy(),
+            'n1': n1, 'n0': n0}
+        return self._lab
+
+    def _ll_total(self, FP, FN):
+        lab = self._label_counts()
+        return self._dev().ll_total(self.parameters[lab['ids']], FP, FN)
+
+    def get_ll_full(self):
+        """libs/CRP.py:237-238"""
+        return float(self._ll_total([self.FP], [self.FN])[0])
+
+    def get_lprior_full(self):
+        """libs/CRP.py:241-251"""
+        sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
+        lprior = self.DP_a_prior.logpdf(self.DP_a) \
+            + np.cumsum(self.CRP_prior[sizes])[-1]
+        if not self.beta_prior_uniform:
+            ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
+            lprior += np.cumsum(
+                self.param_prior.logpdf(self.parameters[ids]).ravel())[-1]
+        return lprior
+
+    # ---------------------------------------------------------------- Gibbs
+    def update_assignments_Gibbs(self):
+        """libs/CRP.py:254-288: one launch for the N x K log-likelihood
+        matrix, then the native sequential sweep; Python only opens new
+        clusters (rare)."""
+        lib = _lib.load()
+        ctx = self._dev()
+        N = self.cells_total
+        post_new = np.ascontiguousarray(self.get_lpost_single_new_cluster())
+        perm = _lib.as_i64(np.random.permutation(N))
+
+        ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
+        sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
+        K = ids.size
+        ld = K + 16
+        ll = np.empty((N, ld), dtype=np.float64)
+        ctx.ll_theta(VIEW_ALL, self.parameters[ids], self.FP, self.FN, out=ll)
+
+        assignment = _lib.as_i64(self.assignment)
+        col_of_id = np.full(N, -1, dtype=np.int64)
+        col_of_id[ids] = np.arange(K)
+        col_id = np.full(ld, -1, dtype=np.int64)
+        col_id[:K] = ids
+        col_size = np.zeros(ld, dtype=np.int64)
+        col_size[:K] = sizes
+        order = np.zeros(ld, dtype=np.int64)
+        order[:K] = np.arange(K)
+        scratch = np.empty(2 * (ld + 1), dtype=np.float64)
+        crp_prior = np.ascontiguousarray(self.CRP_prior, dtype=np.float64)
+
+        st = _lib.GibbsState(N, ld, K, K, 0, -1)
+        rng, extra = _lib.rng_export()
+        i64, f64 = C.c_int64, C.c_double
+        while True:
+            _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), C.byref(rng),
+                _lib.ptr(perm, i64), _lib.ptr(ll, f64),
+                _lib.ptr(post_new, f64), _lib.ptr(crp_prior, f64),
+                _lib.ptr(assignment, i64), _lib.ptr(col_of_id, i64),
+                _lib.ptr(col_id, i64), _lib.ptr(col_size, i64),
+                _lib.ptr(order, i64), _lib.ptr(scratch, f64)), 'gibbs_sweep')
+            if st.new_cell < 0:
+                break
+            # open a new cluster for this cell (libs/CRP.py:281-282, 291-299)
+            cell = int(st.new_cell)
+            _lib.rng_import(rng, extra)
+            new_id = int(np.flatnonzero(col_of_id < 0)[0])
+            self.parameters[new_id] = self._init_cl_params_new([cell])
+            rng, extra = _lib.rng_export()
+            if st.n_cols == ld:
+                grow = max(16, ld // 4)
+                ll = np.concatenate(
+                    [ll, np.empty((N, grow), dtype=np.float64)], axis=1)
+                col_id = np.concatenate([col_id, np.full(grow, -1, np.int64)])
+                col_size = np.concatenate([col_size, np.zeros(grow, np.int64)])
+                order = np.concatenate([order, np.zeros(grow, np.int64)])
+                ld += grow
+                scratch = np.empty(2 * (ld + 1), dtype=np.float64)
+                st.ld = ld
+            col = int(st.n_cols)
+            ll[:, col] = ctx.ll_theta(VIEW_ALL, self.parameters[[new_id]],
+                self.FP, self.FN)[:, 0]
+            col_id[col] = new_id
+            col_size[col] = 1
+            col_of_id[new_id] = col
+            order[st.n_active] = col
+            st.n_active += 1
+            st.n_cols += 1
+            assignment[cell] = new_id
+        _lib.rng_import(rng, extra)
+
+        self.assignment = assignment
+        live = order[:st.n_active]
+        self.cells_per_cluster = {
+            int(col_id[c]): int(col_size[c]) for c in live}
+
+    def init_new_cluster(self, cell_id):
+        """libs/CRP.py:291-294"""
+        cl = self.get_empty_cluster()
+        self.parameters[cl] = self._init_cl_params_new([cell_id])
+        return cl
+
+    def get_empty_cluster(self):
+        """libs/CRP.py:297-299"""
+        i = 0
+        while i in self.cells_per_cluster:
+            i += 1
+        return i
+
+    # ------------------------------------------------- cluster parameters
+    def update_parameters(self, step_no=None):
+        """libs/CRP.py:302-311; the per-cluster sums over cells come from one
+        column-count launch that is reused by get_ll_full / the error update."""
+        lab = self._label_counts()
+        declined = np.zeros(len(self.cells_per_cluster), dtype=int)
+        for n, cl in enumerate(self.cells_per_cluster):
+            self.parameters[cl], _, declined[n] = self.MH_cluster_params(
+                self.parameters[cl], None,
+                counts=(lab['n1'][n], lab['n0'][n]))
+        return declined.sum(), (self.muts_total - declined).sum()
+
+    def MH_cluster_params(self, old_params, cells, trans_prob=False,
+                counts=None):
+        """libs/CRP.py:314-344 (draw order: choice(sd) -> truncnorm.rvs ->
+        random(M))."""
+        M = self.muts_total
+        if counts is None:
+            counts = self._counts_of(cells)
+        std = np.random.choice(self.param_proposal_sd, size=M)
+        a = (TMIN - old_params) / std
+        b = (TMAX - old_params) / std
+        new_params = truncnorm.rvs(
+            a, b, loc=old_params, scale=std, size=M).astype(np.float32)
+
+        A = self._get_log_A(new_params, old_params, cells, a, b, std,
+            trans_prob, counts=counts)
+        u = np.log(np.random.random(M))
+        decline = u >= A
+        new_params[decline] = old_params[decline]
+
+        if trans_prob:
+            A[decline] = np.log(-1 * np.expm1(A[decline]))
+            return new_params, np.cumsum(A)[-1], decline.sum()
+        return new_params, np.nan, decline.sum()
+
+    def _get_log_A(self, new_params, old_params, cells, a, b, std, clip=False,
+                counts=None):
+        """libs/CRP.py:347-383"""
+        if counts is None:
+            counts = self._counts_of(cells)
+        fwd = truncnorm.logpdf(new_params, a, b, loc=old_params, scale=std)
+        a_rev = (TMIN - new_params) / std
+        b_rev = (TMAX - new_params) / std
+        rev = truncnorm.logpdf(old_params, a_rev, b_rev, loc=new_params,
+            scale=std)
+
+        new_ll = self._subset_ll(new_params, counts)
+        old_ll = self._subset_ll(old_params, counts)
+
+        if self.beta_prior_uniform:
+            new_prior = old_prior = 0
+        else:
+            new_prior = self.param_prior.logpdf(new_params)
+            old_prior = self.param_prior.logpdf(old_params)
+
+        A = new_ll + new_prior - old_ll - old_prior + rev - fwd
+        if clip:
+            return np.clip(A, a_min=None, a_max=0)
+        return A
+
+    # ------------------------------------------------------------- DP alpha
+    def update_DP_alpha(self):
+        """libs/CRP.py:386-410"""
+        k = len(self.cells_per_cluster)
+        shape0, rate0 = self.DP_a_gamma
+        eta = np.random.beta(self.DP_a + 1, self.cells_total)
+        w = (shape0 + k - 1) / (self.cells_total * (rate0 - np.log(eta)))
+        pi_eta = w / (1 + w)
+        if np.random.random() < pi_eta:
+            new_alpha = np.random.gamma(shape0 + k, rate0 - np.log(eta))
+        else:
+            new_alpha = np.random.gamma(shape0 + k - 1, rate0 - np.log(eta))
+        self.DP_a = max(1 + EPSILON, new_alpha)
+        self.init_DP_prior()
+
+    # ----------------------------------------------------------- split/merge
+    def update_assignments_split_merge(self, ratios=[.75, .25], step_no=5):
+        """libs/CRP.py:417-431"""
+        K = len(self.cells_per_cluster)
+        if K == 1:
+            return (self.do_split_move(step_no), 0)
+        if K == self.cells_total:
+            return (self.do_merge_move(step_no), 1)
+        move = np.random.choice([0, 1], p=ratios)
+        if move == 0:
+            return (self.do_split_move(step_no), move)
+        return (self.do_merge_move(step_no), move)
+
+    def do_split_move(self, step_no=5):
+        """libs/CRP.py:434-481"""
+        ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
+        sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
+        probs = sizes / sizes.sum()
+        while True:
+            cl = np.random.choice(ids, p=probs)
+            cells = np.argwhere(self.assignment == cl).flatten()
+            if cells.size != 1:
+                break
+        ai, aj = np.random.choice(cells.size, size=2, replace=False)
+        cells[0], cells[ai] = cells[ai], cells[0]
+        cells[-1], cells[aj] = cells[aj], cells[-1]
+
+        pos = np.argwhere(ids == cl).flatten()
+        ltrans = np.log(probs[pos]) \
+            - np.log(self.cells_per_cluster[cl]) \
+            - np.log(self.cells_per_cluster[cl] - 1)
+        size_data = (ltrans, np.delete(sizes, pos))
+
+        accept, new_assign, new_params = self.run_rg_nc(
+            'split', cells, size_data, step_no)
+        if not accept:
+            return [0, 1]
+        new_cl = self.get_empty_cluster()
+        self.parameters[cl] = new_params[0]
+        self.parameters[new_cl] = new_params[1]
+        moved = np.append(cells[1:-1][np.where(new_assign == 1)], cells[-1])
+        self.assignment[moved] = new_cl
+        self.cells_per_cluster[cl] -= moved.size
+        self.cells_per_cluster[new_cl] = moved.size
+        return [1, 0]
+
+    def do_merge_move(self, step_no=5):
+        """libs/CRP.py:484-524"""
+        ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
+        sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
+        inv = 1 / sizes
+        probs = inv / inv.sum()
+        cl_i, cl_j = np.random.choice(ids, p=probs, size=2, replace=False)
+
+        cells_i = np.argwhere(self.assignment == cl_i).flatten()
+        ai = np.random.choice(cells_i.size)
+        cells_i[0], cells_i[ai] = cells_i[ai], cells_i[0]
+        cells_j = np.argwhere(self.assignment == cl_j).flatten()
+        aj = np.random.choice(cells_j.size)
+        cells_j[-1], cells_j[aj] = cells_j[aj], cells_j[-1]
+        cells = np.concatenate((cells_i, cells_j)).flatten()
+
+        pos = np.argwhere((ids == cl_j) | (ids == cl_i)).flatten()
+        size_data = np.cumsum(np.log(probs[pos]))[-1] \
+            - np.cumsum(np.log(sizes[pos]))[-1]
+
+        accept, new_params = self.run_rg_nc('merge', cells, size_data, step_no)
+        if not accept:
+            return [0, 1]
+        self.parameters[cl_i] = new_params
+        self.assignment[cells_j] = cl_i
+        self.cells_per_cluster[cl_i] += cells_j.size
+        del self.cells_per_cluster[cl_j]
+        return [1, 0]
+
+    # -- restricted Gibbs (Jain & Neal 2007), libs/CRP.py:527-820 ----------
+    def run_rg_nc(self, move, cells, size_data, scan_no):
+        """libs/CRP.py:527-544.  The non-anchor cells of the move are gathered
+        ONCE into a device slot view and re-used by every scan; the counts of
+        the merged cluster are those of the two halves added."""
+        self._rg_S = cells[1:-1]
+        self._rg_counts = None
+        if self._rg_S.size:
+            self._dev().view_set(VIEW_MOVE, self._rg_S)
+        self._rg_init_split(cells)
+        self.rg_params_merge = self._beta_draw(*self._rg_all_counts(cells))
+        for _ in range(scan_no):
+            self._rg_scan_split(cells)
+            self._rg_scan_merge(cells)
+        if move == 'split':
+            return self._do_rg_split_MH(cells, size_data)
+        return self._do_rg_merge_MH(cells, size_data)
+
+    def _rg_members(self, cells, which):
+        S = cells[1:-1]
+        anchor = cells[0] if which == 0 else cells[-1]
+        return np.append(S[np.argwhere(self.rg_assignment == which)], anchor)
+
+    def _rg_split_counts(self, cells):
+        """Column counts of the two launch clusters for the CURRENT
+        rg_assignment: one launch, cached until the assignment changes."""
+        key = np.asarray(self.rg_assignment, dtype=np.int64).tobytes()
+        if self._rg_counts is None or self._rg_counts[0] != key:
+            members = [self._rg_members(cells, 0), self._rg_members(cells, 1)]
+            if cells.size <= 4:
+                cnt = [self._counts_of(m) for m in members]
+            else:
+                n1, n0 = self._dev().colcounts(members)
+                cnt = [(n1[g].astype(np.float64), n0[g].astype(np.float64))
+                    for g in range(2)]
+            self._rg_counts = (key, cnt)
+        return self._rg_counts[1]
+
+    def _rg_all_counts(self, cells):
+        ci, cj = self._rg_split_counts(cells)
+        return ci[0] + cj[0], ci[1] + cj[1]
+
+    def _rg_init_split(self, cells, random=False):
+        """libs/CRP.py:547-567.  `ll_j > ll_i` is the one DISCRETE decision on
+        the path, so these two sums are reproduced bit for bit: tables built
+        by the same NumPy expression as the reference's elements, summed in
+        mutation order by the device."""
+        i, j, S = cells[0], cells[-1], cells[1:-1]
+        if S.size == 0:
+            self.rg_assignment = np.array([], dtype=np.int64)
+        elif random:
+            self.rg_assignment = np.random.choice([0, 1], size=(S.size)) \
+                .astype(np.int64)
+        else:
+            fill = self._beta_mix_const[0]
+            anchors = np.nan_to_num(self.data[[i, j]], nan=fill)
+            L1, L0 = self._tables(anchors)
+            ll = self._dev().ll_tables(VIEW_MOVE, L1, L0)
+            self.rg_assignment = np.where(ll[:, 1] > ll[:, 0], 1, 0) \
+                .astype(np.int64)
+        self._rg_counts = None
+        ci, cj = self._rg_split_counts(cells)
+        par_i = self._beta_draw(*ci)
+        par_j = self._beta_draw(*cj)
+        self.rg_params_split = np.stack([par_i, par_j])
+
+    def _rg_scan_split(self, cells, trans_prob=False):
+        """libs/CRP.py:570-578"""
+        if cells.size == 2:
+            prob_cl = 0
+        else:
+            prob_cl = self._rg_scan_assign(cells, trans_prob)
+        prob_par = self._rg_scan_params(cells, trans_prob)
+        if trans_prob:
+            return prob_cl + prob_par
+
+    def _rg_scan_merge(self, cells, trans_prob=False):
+        """libs/CRP.py:581-587"""
+        self.rg_params_merge, prob, _ = self.MH_cluster_params(
+            self.rg_params_merge, cells, trans_prob,
+            counts=self._rg_all_counts(cells))
+        if trans_prob:
+            return prob
+
+    def _rg_scan_params(self, cells, trans_prob=False):
+        """libs/CRP.py:590-606"""
+        cnt = self._rg_split_counts(cells)
+        prob = np.zeros(2)
+        for cl in range(2):
+            self.rg_params_split[cl], prob[cl], _ = self.MH_cluster_params(
+                self.rg_params_split[cl], None, trans_prob, counts=cnt[cl])
+        if trans_prob:
+            return prob.sum()
+
+    def _rg_native_scan(self, mode, ll, target=None):
+        lib = _lib.load()
+        S = ll.shape[0]
+        rg = _lib.as_i64(self.rg_assignment)
+        out = C.c_double(0.0)
+        ll = np.ascontiguousarray(ll, dtype=np.float64)
+        i64, f64 = C.c_int64, C.c_double
+        if mode == 0:
+            rng, extra = _lib.rng_export()
+            _lib.check(lib.bnpc_rg_scan(C.byref(rng), 0, S, _lib.ptr(ll, f64),
+                float(self.DP_a), _lib.ptr(rg, i64), None, C.byref(out)),
+                'rg_scan')
+            _lib.rng_import(rng, extra)
+        else:
+            target = _lib.as_i64(target)
+            _lib.check(lib.bnpc_rg_scan(None, 1, S, _lib.ptr(ll, f64),
+                float(self.DP_a), _lib.ptr(rg, i64), _lib.ptr(target, i64),
+                C.byref(out)), 'rg_scan')
+        self.rg_assignment = rg
+        self._rg_counts = None
+        return out.value
+
+    def _rg_scan_assign(self, cells, trans_prob=False):
+        """libs/CRP.py:609-632"""
+        ll = self._rg_get_ll(cells[1:-1], self.rg_params_split)
+        prob = self._rg_native_scan(0, ll)
+        if trans_prob:
+            return prob
+
+    def _rg_get_ll(self, cells, params):
+        """libs/CRP.py:635-638: (|cells| x 2) in one launch on the move's
+        slot view (cells must be the move's non-anchor cells)."""
+        theta = np.stack([params[0], params[1]]).astype(np.float32)
+        if not (self._rg_S.size == len(cells)
+                and np.array_equal(self._rg_S, cells)):
+            self._rg_S = np.asarray(cells)
+            self._dev().view_set(VIEW_MOVE, self._rg_S)
+        return self._dev().ll_theta(VIEW_MOVE, theta, self.FP, self.FN)
+
+    def _do_rg_split_MH(self, cells, size_data):
+        """libs/CRP.py:641-653"""
+        A = self._get_trans_prob_ratio_split(cells) \
+            + self._get_lprior_ratio_split(cells) \
+            + self._get_ll_ratio(cells, 'split') \
+            + self._get_ltrans_prob_size_ratio_split(*size_data)
+        if np.unique(self.rg_assignment).size == 1:
+            return (False, [], [])
+        if np.log(np.random.random()) < A:
+            return (True, self.rg_assignment, self.rg_params_split)
+        return (False, [], [])
+
+    def _do_rg_merge_MH(self, cells, size_data):
+        """libs/CRP.py:656-665"""
+        A = self._get_trans_prob_ratio_merge(cells) \
+            + self._get_lprior_ratio_merge(cells) \
+            + self._get_ll_ratio(cells, 'merge') \
+            + self._get_ltrans_prob_size_ratio_merge(size_data)
+        if np.log(np.random.random()) < A:
+            return (True, self.rg_params_merge)
+        return (False, [])
+
+    def _get_trans_prob_ratio_split(self, cells):
+        """libs/CRP.py:668-682"""
+        gs_split = self._rg_scan_split(cells, trans_prob=True)
+        std = np.random.choice(self.param_proposal_sd, size=self.muts_total)
+        a = (TMIN - self.rg_params_merge) / std
+        b = (TMAX - self.rg_params_merge) / std
+        gs_merge = np.cumsum(self._get_log_A(
+            self.parameters[self.assignment[cells[0]]], self.rg_params_merge,
+            cells, a, b, std, True, counts=self._rg_all_counts(cells)))[-1]
+        return gs_merge - gs_split
+
+    def _get_trans_prob_ratio_merge(self, cells):
+        """libs/CRP.py:685-692"""
+        gs_merge = self._rg_scan_merge(cells, trans_prob=True)
+        gs_split = self._rg_get_split_prob(cells)
+        return gs_split - gs_merge
+
+    def _rg_sizes(self):
+        n = self.rg_assignment.size + 2
+        n_j = int(np.sum(self.rg_assignment)) + 1
+        return n, n - n_j, n_j
+
+    def _get_lprior_ratio_split(self, cells):
+        """libs/CRP.py:695-713"""
+        n, n_i, n_j = self._rg_sizes()
+        ratio = np.log(self.DP_a) - gammaln(n)
+        if n_i > 0:
+            ratio += gammaln(n_j)
+        if n_j > 0:
+            ratio += gammaln(n_i)
+        if not self.beta_prior_uniform:
+            cl = self.assignment[cells[0]]
+            ratio += np.cumsum(self.param_prior.logpdf(
+                    self.rg_params_split).ravel())[-1] \
+                - np.cumsum(self.param_prior.logpdf(self.parameters[cl]))[-1]
+        return ratio
+
+    def _get_ll_ratio(self, cells, move):
+        """libs/CRP.py:716-733: three flat sums = counts . tables"""
+        ci, cj = self._rg_split_counts(cells)
+        call = (ci[0] + cj[0], ci[1] + cj[1])
+        ll_i = self._subset_ll(self.rg_params_split[0], ci).sum()
+        ll_j = self._subset_ll(self.rg_params_split[1], cj).sum()
+        ll_all = self._subset_ll(self.rg_params_merge, call).sum()
+        if move == 'split':
+            return ll_i + ll_j - ll_all
+        return ll_all - ll_i - ll_j
+
+    def _get_lprior_ratio_merge(self, cells):
+        """libs/CRP.py:736-754"""
+        n, n_i, n_j = self._rg_sizes()
+        n = cells.size
+        ratio = gammaln(n) - np.log(self.DP_a)
+        if n_i > 0:
+            ratio -= gammaln(n_i)
+        if n_j > 0:
+            ratio -= gammaln(n_j)
+        if not self.beta_prior_uniform:
+            cls = self.assignment[[cells[0], cells[-1]]]
+            ratio += np.cumsum(
+                    self.param_prior.logpdf(self.rg_params_merge))[-1] \
+                - np.cumsum(self.param_prior.logpdf(
+                    self.parameters[cls]).ravel())[-1]
+        return ratio
+
+    def _get_ltrans_prob_size_ratio_split(self, ltrans_prob_size, cluster_size):
+        """libs/CRP.py:757-764"""
+        _, n_i, n_j = self._rg_sizes()
+        norm = np.cumsum(1 / np.append(cluster_size, [n_i, n_j]))[-1]
+        rev = np.log(1 / n_i / norm) + np.log(1 / n_j / norm)
+        return rev - ltrans_prob_size[0]
+
+    def _get_ltrans_prob_size_ratio_merge(self, trans_prob_size):
+        """libs/CRP.py:767-774"""
+        try:
+            rev = -np.log(self.cells_total) \
+                - np.log(self.rg_assignment.size - 1)
+        except FloatingPointError:
+            rev = -np.log(self.cells_total)
+        return rev - trans_prob_size
+
+    def _rg_get_split_prob(self, cells):
+        """libs/CRP.py:777-820"""
+        std = np.random.choice(self.param_proposal_sd,
+            size=(2, self.muts_total))
+        a = (0 - self.rg_params_split) / std
+        b = (1 - self.rg_params_split) / std
+
+        i, j, S = cells[0], cells[-1], cells[1:-1]
+        cl_i = self.assignment[i]
+        cl_j = self.assignment[j]
+        cnt = self._rg_split_counts(cells)
+        prob_i = np.cumsum(self._get_log_A(
+            self.parameters[cl_i], self.rg_params_split[0], None,
+            a[0], b[0], std[0], True, counts=cnt[0]))[-1]
+        prob_j = np.cumsum(self._get_log_A(
+            self.parameters[cl_j], self.rg_params_split[1], None,
+            a[1], b[1], std[1], True, counts=cnt[1]))[-1]
+
+        if S.size == 0:
+            return prob_i + prob_j + 0.0
+        ll = self._rg_get_ll(S, (self.parameters[cl_i], self.parameters[cl_j]))
+        target = np.where(self.assignment[S] == cl_i, 0, 1)
+        prob_assign = self._rg_native_scan(1, ll, target)
+        return prob_i + prob_j + prob_assign
+
+
+class CRP_errors_learning(CRP):
+    """libs/CRP_learning_errors.py:17-111"""
+
+    def __init__(self, data, DP_alpha=1, param_beta=[1, 1],
+                FP_mean=0.001, FP_sd=0.0005, FN_mean=0.25, FN_sd=0.05):
+        super().__init__(data, DP_alpha, param_beta, FN_mean, FP_mean)
+        self.FP_prior = truncnorm(
+            (0 - FP_mean) / FP_sd, (1 - FP_mean) / FP_sd, FP_mean, FP_sd)
+        self.FP_sd = np.array([FP_sd * 0.5, FP_sd, FP_sd * 1.5])
+        self.FN_prior = truncnorm(
+            (0 - FN_mean) / FN_sd, (1 - FN_mean) / FN_sd, FN_mean, FN_sd)
+        self.FN_sd = np.array([FN_sd * 0.5, FN_sd, FN_sd * 1.5])
+
+    def __str__(self):
+        return ('\nDPMM with:\n'
+            f'\t{self.cells_total} cells\n\t{self.muts_total} mutations\n'
+            '\tlearning errors\n'
+            '\n\tPriors:\n'
+            f'\tparams.:\tBeta({self.p},{self.q})\n'
+            f'\tCRP a_0:\tGamma({self.DP_a_gamma[0]:.2f},'
+            f'{self.DP_a_gamma[1]})\n'
+            f'\tFP:\t\ttrunc norm({self.FP_prior.args[2]},'
+            f'{self.FP_prior.args[3]})\n'
+            f'\tFN:\t\ttrunc norm({self.FN_prior.args[2]},'
+            f'{self.FN_prior.args[3]})\n')
+
+    def get_lprior_full(self):
+        """libs/CRP_learning_errors.py:47-49"""
+        return super().get_lprior_full() \
+            + self.FP_prior.logpdf(self.FP) + self.FN_prior.logpdf(self.FN)
+
+    def update_error_rates(self):
+        """libs/CRP_learning_errors.py:52-55"""
+        self.FP, FP_count = self.MH_error_rates('FP')
+        self.FN, FN_count = self.MH_error_rates('FN')
+        return FP_count, FN_count
+
+    def get_ll_full_error(self, FP, FN):
+        """libs/CRP_learning_errors.py:58-63"""
+        return float(self._ll_total([FP], [FN])[0])
+
+    def MH_error_rates(self, error_type):
+        """libs/CRP_learning_errors.py:66-111; the new/old likelihood pair is
+        ONE launch over the resident per-cluster counts."""
+        if error_type == 'FP':
+            old, prior, sds = self.FP, self.FP_prior, self.FP_sd
+        else:
+            old, prior, sds = self.FN, self.FN_prior, self.FN_sd
+
+        std = np.random.choice(sds)
+        a = (0 - old) / std
+        b = (1 - old) / std
+        try:
+            new = truncnorm.rvs(a, b, loc=old, scale=std)
+        except FloatingPointError:
+            new = truncnorm.rvs(a, np.inf, loc=old, scale=std)
+
+        fwd = truncnorm.logpdf(new, a, b, loc=old, scale=std)
+        rev = truncnorm.logpdf(old, (0 - new) / std, (1 - new) / std,
+            loc=new, scale=std)
+
+        if error_type == 'FP':
+            new_ll, old_ll = self._ll_total([new, old], [self.FN, self.FN])
+        else:
+            new_ll, old_ll = self._ll_total([self.FP, self.FP], [new, old])
+
+        A = new_ll + prior.logpdf(new) - old_ll - prior.logpdf(old) \
+            + rev - fwd
+        if np.log(np.random.random()) < A:
+            return new, [1, 0]
+        return old, [0, 1]

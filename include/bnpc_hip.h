@@ -1,0 +1,208 @@
+/*
+ * bnpc_hip.h - C-ABI of libbnpc_hip.so: the MI355X (gfx950) implementation of
+ * BnpC's Bernoulli error-model log-likelihood hot path.
+ *
+ * The reference (cbg-ethz/BnpC) is pure Python and has no FFI of its own; the
+ * drop-in boundary is the duck-typed class surface of libs/CRP.py and
+ * libs/CRP_learning_errors.py.  This header is the
+ * C-ABI that sits UNDER that surface; bnpc_amd/_lib.py binds it with ctypes
+ * and bnpc_amd/model.py mirrors the reference classes on top of it.  Each
+ * entry point cites the reference expression(s) it replaces
+ * (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message
+ *     is available from bnpc_last_error() (thread local).  HIP errors never
+ *     abort the process.
+ *   - all host buffers are caller-allocated, C-contiguous and only borrowed
+ *     for the duration of the call; the context owns all device memory.
+ *   - one context per process/chain; calls on one context must not overlap.
+ *   - floating point: tables, accumulators and outputs are float64; theta is
+ *     float32 and (1 - theta) is evaluated in float32, as in the reference.
+ *
+ * Device data layout
+ *   row planes   rows[N][W] of {ones, zeros} 64-bit words, W = ceil(M/64)
+ *   slot views   masks[block][m] of {ones, zeros} 64-bit LANE MASKS over a
+ *                block of 64 cells ("slots"): bit s of masks[b][m].ones says
+ *                cell slot 64*b+s has x = 1 at mutation m.  View 0 is the
+ *                identity view (all N cells in order); views 1.. are gathered
+ *                cell lists (restricted-Gibbs moves).
+ */
+#ifndef BNPC_HIP_H
+#define BNPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bnpc_ctx bnpc_ctx;
+
+#define BNPC_MAX_VIEWS 4
+#define BNPC_MAX_TRIALS 4
+
+/* ---- library / device ---------------------------------------------------- */
+const char *bnpc_last_error(void);
+int bnpc_abi_version(void);
+int bnpc_device_count(int *count);
+/* name[len] receives the gfx arch name, *cus the CU count */
+int bnpc_device_info(int device, char *name, int len, int *cus);
+
+/* ---- context: data of one chain ------------------------------------------
+ * Replaces the float64 N x M `self.data` (NaN = missing) of libs/CRP.py:30-31
+ * by two bit planes resident in HBM.  data_nan holds 0 | 1 | NaN. */
+int bnpc_create(int device, int64_t N, int64_t M, const double *data_nan,
+                bnpc_ctx **out);
+/* same, from int8 codes 0 | 1 | 3 (the reference's on-disk code,
+ * libs/dpmmIO.py:27-98 maps 3 -> NaN, 2 -> 1) */
+int bnpc_create_codes(int device, int64_t N, int64_t M, const int8_t *codes,
+                      bnpc_ctx **out);
+int bnpc_destroy(bnpc_ctx *ctx);
+int bnpc_shape(const bnpc_ctx *ctx, int64_t *N, int64_t *M);
+
+/* per-cell counts of observed 1s and 0s (row sums of the planes).  With them
+ * libs/CRP.py:230-234 (get_lpost_single_new_cluster) is n1*c1 + n0*c0. */
+int bnpc_cell_counts(bnpc_ctx *ctx, int32_t *n1, int32_t *n0);
+
+/* ---- slot views ----------------------------------------------------------
+ * Gather the rows of `cells` (n indices into 0..N-1, any order, repeats
+ * allowed) and transpose them into 64-slot lane-mask blocks.  Replaces the
+ * fancy-index gathers `self.data[cells]` of libs/CRP.py:360, 557-560, 636-637,
+ * 726-728.  view in 1..BNPC_MAX_VIEWS-1 (view 0 = all cells, built at create). */
+int bnpc_view_set(bnpc_ctx *ctx, int view, const int64_t *cells, int64_t n);
+int bnpc_view_size(const bnpc_ctx *ctx, int view, int64_t *n);
+
+/* ---- log-likelihood of every slot of a view under K parameter vectors ----
+ * out[s*K + k] = sum over mutations m, IN INDEX ORDER, skipping missing
+ *   entries, of log(theta[k,m]*P(x|1) + (1-theta[k,m])*P(x|0))
+ * = CRP._calc_ll(x, theta)            libs/CRP.py:197-204 (axis=1 form)
+ *   CRP._Bernoulli_FN / _Bernoulli_FP libs/CRP.py:207-212
+ * One launch replaces the N calls of CRP.get_lpost_single per Gibbs sweep
+ * (libs/CRP.py:223-227, 270) and the pair of calls of CRP._rg_get_ll
+ * (libs/CRP.py:635-638).  theta is K x M float32 row-major.  The per-element
+ * logs are evaluated once per (k, m) on the device (2*K*M logs instead of
+ * N*K*M).  out has row stride ldo >= K doubles (0 means K; columns K..ldo
+ * are left for clusters opened later in the sweep).  out may be NULL
+ * (compute only; used for timing - theta must then stay alive until
+ * bnpc_sync / bnpc_timer_stop). */
+int bnpc_ll_theta(bnpc_ctx *ctx, int view, const float *theta, int64_t K,
+                  double FP, double FN, double *out, int64_t ldo);
+
+/* Same sums from caller-built element tables: L1[k,m] is the value an
+ * observed 1 contributes, L0[k,m] an observed 0 (both K x M float64).  With
+ * tables built by the caller's NumPy this reproduces the reference's sums bit
+ * for bit (same elements, same order); used for CRP._rg_init_split
+ * (libs/CRP.py:547-561), whose `ll_j > ll_i` comparison is the one discrete
+ * decision on the path, and for get_lpost_single_new_cluster. */
+int bnpc_ll_tables(bnpc_ctx *ctx, int view, const double *L1, const double *L0,
+                   int64_t K, double *out, int64_t ldo);
+
+/* ---- column counts --------------------------------------------------------
+ * For G segments of cells (CSR: cells[seg_offsets[g] .. seg_offsets[g+1])),
+ * n1[g*M + m] / n0[g*M + m] = number of cells of the segment with an observed
+ * 1 / 0 at mutation m.  Exact integers.  They turn the per-mutation sums over
+ * a cell subset of CRP._get_log_A (libs/CRP.py:359-368), the Beta shapes of
+ * CRP._init_cl_params_new (libs/CRP.py:183-188) and the flat sums of
+ * CRP._get_ll_ratio (libs/CRP.py:716-733) into O(M) table work. */
+int bnpc_colcounts(bnpc_ctx *ctx, const int64_t *cells,
+                   const int64_t *seg_offsets, int64_t G,
+                   int32_t *n1, int32_t *n0);
+
+/* Per-cluster column counts for the K cluster ids `ids` (segment g = cells
+ * with assignment == ids[g]).  The counts also stay resident on the device
+ * for bnpc_ll_total.  n1/n0 may be NULL (device-resident only). */
+int bnpc_colcounts_by_label(bnpc_ctx *ctx, const int64_t *assignment,
+                            const int64_t *ids, int64_t K,
+                            int32_t *n1, int32_t *n0);
+
+/* Total log-likelihood of the data under the resident per-cluster counts,
+ *   out[e] = sum_k sum_m n1[k,m]*log(theta*(1-FN_e) + (1-theta)*FP_e)
+ *                      + n0[k,m]*log(theta*FN_e + (1-theta)*(1-FP_e))
+ * for E <= BNPC_MAX_TRIALS trial error pairs in one launch.  Replaces
+ * CRP.get_ll_full (libs/CRP.py:237-238) and
+ * CRP_errors_learning.get_ll_full_error (libs/CRP_learning_errors.py:58-63).
+ * theta is K x M float32 (row g = parameters of ids[g]). */
+int bnpc_ll_total(bnpc_ctx *ctx, const float *theta, int64_t K,
+                  const double *FP, const double *FN, int E, double *out);
+
+/* ---- timing on the context's stream (HIP events) -------------------------- */
+int bnpc_timer_start(bnpc_ctx *ctx);
+int bnpc_timer_stop(bnpc_ctx *ctx, float *ms);
+int bnpc_sync(bnpc_ctx *ctx);
+
+/* ---- native sequential sweeps (host side, exact legacy-MT19937 replica) ---
+ * NumPy's legacy global stream (np.random.seed / get_state) is MT19937; the
+ * state is exchanged with np.random.get_state() / set_state() so that Python
+ * and C draw from ONE stream in the reference's order.
+ */
+typedef struct bnpc_mt19937 {
+    uint32_t key[624];
+    int32_t pos;
+} bnpc_mt19937;
+
+/* np.random.random_sample(): ((a >> 5) * 2^26 + (b >> 6)) / 2^53 */
+double bnpc_mt_random_sample(bnpc_mt19937 *rng);
+/* np.random.permutation(n): arange + Fisher-Yates from the top with the
+ * masked-rejection legacy random_interval on 32-bit draws */
+int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out);
+
+/* The sequential per-cell loop of CRP.update_assignments_Gibbs
+ * (libs/CRP.py:260-288, with _normalize_log_probs :88-100 and
+ * np.random.choice(p=...) :276-277) over a precomputed log-likelihood matrix.
+ *
+ * Columns of `ll` are clusters ("col"); a column keeps its cluster id for the
+ * whole sweep.  `order[0..n_active)` lists the live columns in the insertion
+ * order of the reference's cells_per_cluster dict (a cluster that loses its
+ * last cell is deleted; a cluster opened later is appended).
+ *
+ * The function processes perm[pos..N) and returns 0 when
+ *   - the sweep is complete: st->pos == st->n_cells, st->new_cell == -1, or
+ *   - the cell perm[st->pos - 1] drew a NEW cluster: st->new_cell == that
+ *     cell.  The cell has already been removed from its old cluster.  The
+ *     caller opens the cluster in Python (lowest free id, Beta draws on the
+ *     same stream - libs/CRP.py:291-299, 183-188), writes its log-likelihood
+ *     column into ll[:, n_cols], registers it (col_id, col_size = 1,
+ *     col_of_id, order[n_active++], n_cols++, assignment[cell]) and calls
+ *     again.
+ */
+typedef struct bnpc_gibbs_state {
+    int64_t n_cells;    /* N */
+    int64_t ld;         /* allocated columns of ll (row stride) */
+    int64_t n_cols;     /* columns in use */
+    int64_t n_active;   /* live clusters = entries of order[] */
+    int64_t pos;        /* next position of perm to process */
+    int64_t new_cell;   /* out: cell that drew a new cluster, else -1 */
+} bnpc_gibbs_state;
+
+int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
+                     const int64_t *perm,      /* N visiting order */
+                     const double *ll,         /* N x ld, row = cell id */
+                     const double *post_new,   /* N new-cluster log posterior */
+                     const double *crp_prior,  /* N+2 log prior by size */
+                     int64_t *assignment,      /* N cluster ids, in/out */
+                     int64_t *col_of_id,       /* N column of a live id / -1 */
+                     int64_t *col_id,          /* ld cluster id of a column */
+                     int64_t *col_size,        /* ld cells in that cluster */
+                     int64_t *order,           /* ld live columns, dict order */
+                     double *scratch);         /* 2 * (ld + 1) doubles */
+
+/* The sequential 2-way loops of the restricted Gibbs scans over an S x 2
+ * log-likelihood matrix (row s = non-anchor cell s, column 0/1 = launch
+ * cluster i/j):
+ *   mode 0  CRP._rg_scan_assign (libs/CRP.py:616-629): permutation(S), then
+ *           per cell one 2-way draw (one uniform each);
+ *   mode 1  the scoring loop of CRP._rg_get_split_prob (libs/CRP.py:808-818):
+ *           index order, no RNG, cells are forced to `target`.
+ * rg_assignment (S, values 0/1) is updated in place; *log_prob receives the
+ * sum in index order of the chosen log-probabilities (always for mode 1, for
+ * mode 0 only meaningful to callers that need it).  Uses
+ * CRP._normalize_log (libs/CRP.py:103-116) and CRP.log_CRP_prior (:83-85). */
+int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S, const double *ll,
+                 double DP_a, int64_t *rg_assignment, const int64_t *target,
+                 double *log_prob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNPC_HIP_H */

@@ -1,0 +1,107 @@
+"""A NumPy stand-in for bnpc_amd._lib.Context, for CPU-only tests of the HOST
+logic of the product (model surface, RNG order, native sequential sweeps).
+
+Test infrastructure: it computes the four device primitives with the oracle's
+arithmetic.  The product never imports this; GPU parity proper is in
+tests/test_gpu_parity.py (-m gpu)."""
+import numpy as np
+
+from oracle import crp_numpy as O
+
+
+class FakeContext:
+    def __init__(self, data=None, codes=None, device=0):
+        self.data = np.asarray(data, dtype=np.float64)
+        self.N, self.M = self.data.shape
+        self.views = {0: np.arange(self.N)}
+        self.lab = None
+        self.calls = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    def close(self):
+        pass
+
+    def cell_counts(self):
+        return (np.nansum(self.data == 1, axis=1).astype(np.int32),
+            np.nansum(self.data == 0, axis=1).astype(np.int32))
+
+    def view_set(self, view, cells):
+        self._count('view_set')
+        self.views[view] = np.asarray(cells, dtype=np.int64).copy()
+        return self.views[view].size
+
+    def view_size(self, view):
+        return self.views[view].size
+
+    def _sum_tables(self, view, L1, L0):
+        x = self.data[self.views[view]]
+        out = np.empty((x.shape[0], L1.shape[0]))
+        for k in range(L1.shape[0]):
+            el = np.where(x == 1, L1[k], np.where(x == 0, L0[k], np.nan))
+            out[:, k] = O.seqsum(el, axis=1) if x.shape[0] else 0
+        return out
+
+    def ll_theta(self, view, theta, FP, FN, out=None, fetch=True):
+        self._count('ll_theta')
+        theta = np.asarray(theta, dtype=np.float32)
+        if theta.ndim == 1:
+            theta = theta[None, :]
+        t64 = theta.astype(np.float64)
+        om64 = (1 - theta).astype(np.float64)
+        L1 = np.log(t64 * (1 - FN) + om64 * FP)
+        L0 = np.log(t64 * FN + om64 * (1 - FP))
+        res = self._sum_tables(view, L1, L0)
+        if out is not None:
+            out[:, :res.shape[1]] = res
+            return out
+        return res
+
+    def ll_tables(self, view, L1, L0, out=None):
+        self._count('ll_tables')
+        L1 = np.atleast_2d(np.asarray(L1, dtype=np.float64))
+        L0 = np.atleast_2d(np.asarray(L0, dtype=np.float64))
+        return self._sum_tables(view, L1, L0)
+
+    def colcounts(self, segments):
+        self._count('colcounts')
+        G = len(segments)
+        n1 = np.zeros((G, self.M), dtype=np.int32)
+        n0 = np.zeros((G, self.M), dtype=np.int32)
+        for g, seg in enumerate(segments):
+            sub = self.data[np.asarray(seg, dtype=np.int64)]
+            n1[g] = (sub == 1).sum(axis=0)
+            n0[g] = (sub == 0).sum(axis=0)
+        return n1, n0
+
+    def colcounts_by_label(self, assignment, ids, fetch=True):
+        self._count('colcounts_by_label')
+        assignment = np.asarray(assignment)
+        segs = [np.flatnonzero(assignment == i) for i in ids]
+        n1, n0 = self.colcounts(segs)
+        self.lab = (n1, n0)
+        return n1, n0
+
+    def ll_total(self, theta, FP, FN):
+        self._count('ll_total')
+        theta = np.asarray(theta, dtype=np.float32)
+        n1, n0 = self.lab
+        assert theta.shape == n1.shape
+        t64 = theta.astype(np.float64)
+        om64 = (1 - theta).astype(np.float64)
+        out = []
+        for fp, fn in zip(np.atleast_1d(FP), np.atleast_1d(FN)):
+            L1 = np.log(t64 * (1 - fn) + om64 * fp)
+            L0 = np.log(t64 * fn + om64 * (1 - fp))
+            out.append((n1 * L1 + n0 * L0).sum())
+        return np.array(out)
+
+    def sync(self):
+        pass
+
+
+def attach(model):
+    """Give a bnpc_amd.model instance a FakeContext instead of a GPU."""
+    model._ctx = FakeContext(data=model.data)
+    return model

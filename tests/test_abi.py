@@ -1,0 +1,57 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol that
+include/bnpc_hip.h declares; the ctypes table covers the header."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from bnpc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    with open(os.path.join(ROOT, 'include', 'bnpc_hip.h')) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bnpc_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_entry_points():
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for must in ('bnpc_create', 'bnpc_ll_theta', 'bnpc_ll_tables',
+            'bnpc_colcounts', 'bnpc_ll_total', 'bnpc_gibbs_sweep'):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), \
+        'run `python -m bnpc_amd.build` first (hipcc, no GPU needed)'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), f'{name} declared but not exported'
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+    lib = _lib.load()
+    assert lib.bnpc_abi_version() == 1
+    assert lib.bnpc_last_error() is not None
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_bad_arguments_return_errors_not_crashes():
+    lib = _lib.load()
+    n = ctypes.c_int64(0)
+    assert lib.bnpc_view_size(None, 0, ctypes.byref(n)) != 0
+    assert b'NULL' in lib.bnpc_last_error()
+    with pytest.raises(RuntimeError, match='libbnpc_hip'):
+        _lib.check(lib.bnpc_sync(None), 'sync')

@@ -1,0 +1,261 @@
+"""CPU-only tests of the product's HOST side: the model surface of
+bnpc_amd.model and the native sequential sweeps of libbnpc_hip.so, driven with
+a NumPy stand-in for the device primitives (tests/fake_device.py), against the
+CPU oracle on the same seeds: identical assignment trajectories, traces to
+1e-9."""
+import contextlib
+import copy
+import ctypes as C
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import crp_numpy as O
+from bnpc_amd import _lib, model as P
+from bnpc_amd.mcmc import MCMC
+from fake_device import FakeContext, attach
+
+
+def synth(seed, N, M, C_, miss, FP_true=0.001, FN_true=0.1):
+    rng = np.random.RandomState(seed)
+    geno = (rng.random_sample((C_, M)) < 0.3)
+    z = rng.randint(0, C_, N)
+    X = geno[z]
+    u = rng.random_sample((N, M))
+    obs = np.where(X == 1, u >= FN_true, u < FP_true).astype(np.float64)
+    obs[rng.random_sample((N, M)) < miss] = np.nan
+    return obs
+
+
+def make(mod, kind, data, pb=(.25, .25)):
+    if kind == 'fixed':
+        return mod.CRP(data, DP_alpha=[-1, -1], param_beta=list(pb),
+            FN_error=0.1, FP_error=0.001)
+    return mod.CRP_errors_learning(data, DP_alpha=[-1, -1],
+        param_beta=list(pb), FP_mean=0.01, FP_sd=0.01, FN_mean=0.2,
+        FN_sd=0.1)
+
+
+def run_chain(model, steps, seed, sm_prob=.33, sm_steps=3, eup=0.):
+    mcmc = MCMC(model, sm_prob=sm_prob, dpa_prob=.25, error_prob=eup,
+        sm_ratios=[.75, .25], sm_steps=sm_steps)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mcmc.run((steps, int(steps * .33)), seed, 1, 0, '', True)
+    return mcmc.get_results()[0]
+
+
+@pytest.fixture(autouse=True)
+def fake_device(monkeypatch):
+    monkeypatch.setattr(_lib, 'Context', FakeContext)
+
+
+# --------------------------------------------------------------- MT replica
+def test_mt19937_replica_matches_numpy(golden_dir):
+    lib = _lib.load()
+    g = np.load(os.path.join(golden_dir, 'rng.npz'))
+    for seed in (1, 42, 1608637542):
+        np.random.seed(seed)
+        st, extra = _lib.rng_export()
+        got = [lib.bnpc_mt_random_sample(C.byref(st)) for _ in range(5)]
+        assert np.array_equal(got, g[f's{seed}_random'])
+        perm = np.empty(37, dtype=np.int64)
+        lib.bnpc_mt_permutation(C.byref(st), 37, _lib.ptr(perm, C.c_int64))
+        assert np.array_equal(perm, g[f's{seed}_perm'])
+        # hand the stream back to numpy: it continues where C stopped
+        _lib.rng_import(st, extra)
+        assert np.array_equal(np.random.randint(0, 1000, size=11),
+            g[f's{seed}_randint'])
+
+
+def test_mt19937_long_run_and_big_permutation():
+    lib = _lib.load()
+    np.random.seed(2024)
+    st, extra = _lib.rng_export()
+    ref = np.random.random(3000)           # crosses several 624-word refills
+    got = np.array([lib.bnpc_mt_random_sample(C.byref(st))
+        for _ in range(3000)])
+    assert np.array_equal(ref, got)
+    for n in (1, 2, 3, 1000, 5000, 70000):
+        np.random.seed(n)
+        st, extra = _lib.rng_export()
+        ref = np.random.permutation(n)
+        out = np.empty(n, dtype=np.int64)
+        lib.bnpc_mt_permutation(C.byref(st), n, _lib.ptr(out, C.c_int64))
+        assert np.array_equal(ref, out)
+        _lib.rng_import(st, extra)
+        ref_next = np.random.get_state()[1].copy()
+        np.random.seed(n)
+        np.random.permutation(n)
+        assert np.array_equal(np.random.get_state()[1], ref_next)
+
+
+# ----------------------------------------------------------- single moves
+@pytest.mark.parametrize('kind', ['fixed', 'learn'])
+def test_gibbs_sweeps_match_oracle(kind):
+    data = synth(1, 150, 70, 4, 0.15)
+    o = make(O, kind, data)
+    p = make(P, kind, data)
+    for m in (o, p):
+        np.random.seed(11)
+        m.init()
+    assert np.array_equal(o.assignment, p.assignment)
+    assert np.array_equal(o.parameters, p.parameters)
+    for sweep in range(4):
+        for m in (o, p):
+            np.random.seed(100 + sweep)
+            m.update_assignments_Gibbs()
+            tail = np.random.random(3)
+            m._tail = tail
+        assert np.array_equal(o.assignment, p.assignment), sweep
+        assert list(o.cells_per_cluster.items()) == \
+            list(p.cells_per_cluster.items())
+        assert np.array_equal(o._tail, p._tail)       # same RNG consumption
+        ids = list(o.cells_per_cluster)
+        assert np.array_equal(o.parameters[ids], p.parameters[ids])
+        np.testing.assert_allclose(p.get_ll_full(), o.get_ll_full(),
+            rtol=1e-12)
+
+
+def test_update_parameters_and_errors_match_oracle():
+    data = synth(2, 120, 60, 3, 0.2)
+    o = make(O, 'learn', data)
+    p = make(P, 'learn', data)
+    for m in (o, p):
+        np.random.seed(5)
+        m.init()
+        m.update_assignments_Gibbs()
+    for rnd in range(3):
+        outs = []
+        for m in (o, p):
+            np.random.seed(50 + rnd)
+            r1 = m.update_parameters()
+            r2 = m.update_error_rates()
+            outs.append((r1, r2, m.FP, m.FN, np.random.random()))
+        assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+        np.testing.assert_allclose(outs[1][2:], outs[0][2:], rtol=1e-12)
+        ids = list(o.cells_per_cluster)
+        assert np.array_equal(o.parameters[ids], p.parameters[ids])
+        np.testing.assert_allclose(p.get_lprior_full(), o.get_lprior_full(),
+            rtol=1e-11)
+        np.testing.assert_allclose(
+            p.get_ll_full_error(0.02, 0.3), o.get_ll_full_error(0.02, 0.3),
+            rtol=1e-12)
+
+
+@pytest.mark.parametrize('pb', [(.25, .25), (1, 1)])
+@pytest.mark.parametrize('start', ['together', 'fragmented', 'gibbs'])
+def test_split_merge_moves_match_oracle(pb, start):
+    data = synth(3, 90, 50, 3, 0.1)
+    o = make(O, 'fixed', data, pb)
+    p = make(P, 'fixed', data, pb)
+    for m in (o, p):
+        np.random.seed(8)
+        if start == 'together':         # splits get accepted
+            m.init(mode='together')
+        elif start == 'fragmented':     # merges get accepted
+            m.init(assign=list(np.random.RandomState(1).randint(0, 12, 90)))
+        else:
+            m.init()
+            m.update_assignments_Gibbs()
+        m.update_parameters()
+    n_acc = 0
+    for rnd in range(40):
+        outs = []
+        for m in (o, p):
+            np.random.seed(1000 + rnd)
+            res = m.update_assignments_split_merge([.6, .4], 2)
+            outs.append((res, np.random.random()))
+        assert outs[0][0] == outs[1][0], rnd
+        assert outs[0][1] == outs[1][1], rnd
+        assert np.array_equal(o.assignment, p.assignment), rnd
+        assert list(o.cells_per_cluster.items()) == \
+            list(p.cells_per_cluster.items())
+        ids = list(o.cells_per_cluster)
+        assert np.array_equal(o.parameters[ids], p.parameters[ids])
+        n_acc += outs[0][0][0][0]
+        if rnd % 5 == 4:
+            for m in (o, p):
+                np.random.seed(rnd)
+                m.update_parameters()
+    if start != 'gibbs':
+        assert n_acc > 0      # accepted moves were exercised
+
+
+def test_rg_init_split_is_bit_identical_to_oracle():
+    """The discrete `ll_j > ll_i` decision, on data with many exact ties."""
+    rng = np.random.RandomState(0)
+    data = (rng.random_sample((80, 24)) < 0.5).astype(float)
+    data[rng.random_sample(data.shape) < 0.3] = np.nan
+    o = make(O, 'fixed', data)
+    p = make(P, 'fixed', data)
+    for m in (o, p):
+        m.init(mode='together')
+    cells = np.arange(80)
+    for trial in range(10):
+        rng.shuffle(cells)
+        for m in (o, p):
+            np.random.seed(trial)
+            m._rg_S = cells[1:-1].copy()
+            if m is p:
+                m._dev().view_set(P.VIEW_MOVE, m._rg_S)
+            m._rg_init_split(cells.copy())
+        assert np.array_equal(o.rg_assignment, p.rg_assignment)
+        assert np.array_equal(o.rg_params_split, p.rg_params_split)
+
+
+# -------------------------------------------------------------- whole chains
+@pytest.mark.parametrize('kind,eup', [('fixed', 0.), ('learn', .25)])
+def test_chain_matches_oracle(kind, eup):
+    data = synth(4, 80, 40, 3, 0.1)
+    ro = run_chain(make(O, kind, data), 60, 7, sm_prob=.4, sm_steps=2, eup=eup)
+    rp = run_chain(make(P, kind, data), 60, 7, sm_prob=.4, sm_steps=2, eup=eup)
+    assert np.array_equal(ro['assignments'], rp['assignments'])
+    for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
+        np.testing.assert_allclose(rp[key], ro[key], rtol=1e-9, err_msg=key)
+    assert np.array_equal(ro['params'], rp['params'])
+
+
+def test_other_init_modes_match_oracle():
+    data = synth(6, 40, 30, 3, 0.1)
+    for mode, assign in (('separate', False), ('together', False),
+            ('random', [0, 1] * 20), ('random', [3] * 39 + [7])):
+        o = make(O, 'fixed', data)
+        p = make(P, 'fixed', data)
+        for m in (o, p):
+            np.random.seed(3)
+            m.init(mode=mode, assign=assign)
+        assert np.array_equal(o.assignment, p.assignment)
+        assert o.cells_per_cluster == p.cells_per_cluster
+        ids = list(o.cells_per_cluster)
+        assert np.array_equal(o.parameters[ids], p.parameters[ids])
+        np.testing.assert_allclose(p.get_ll_full(), o.get_ll_full(),
+            rtol=1e-12)
+    with pytest.raises(TypeError):
+        make(P, 'fixed', data).init(mode='nope')
+
+
+def test_pickle_and_deepcopy_drop_the_device_context():
+    data = synth(5, 30, 20, 2, 0.1)
+    p = make(P, 'learn', data)
+    np.random.seed(1)
+    p.init()
+    ll = p.get_ll_full()
+    assert p._ctx is not None
+    q = pickle.loads(pickle.dumps(p))
+    r = copy.deepcopy(p)
+    for clone in (q, r):
+        assert clone._ctx is None and clone._lab is None
+        assert clone.get_ll_full() == ll        # context rebuilt lazily
+        assert clone._ctx is not None
+
+
+def test_module_path_of_the_drop_in_classes():
+    import libs.CRP
+    import libs.CRP_learning_errors
+    assert libs.CRP.CRP.__module__ == 'libs.CRP'
+    assert libs.CRP_learning_errors.CRP_errors_learning.__module__ == \
+        'libs.CRP_learning_errors'
+    assert issubclass(libs.CRP_learning_errors.CRP_errors_learning, P.CRP)
