@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py - MCMC steps/s of the MI355X hot path on BASELINE.json's metric
+configuration (config 3: synthetic 5,000 cells x 1,000 mutations, 20 % missing,
+learned error rates), one independent chain per GPU.
+
+    python bench.py --gpus 1 --steps 40 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = Chain.do_step + Chain.update_results (libs/MCMC.py:375-388 of the
+reference), the unit of the reference's own "secs. per MCMC step" line
+(libs/dpmmIO.py:310-315).  Warm-up steps include step 1, the sweep from the
+random initial state with K0 ~ 0.63 N clusters; its time is reported
+separately (first_step_s).  The timed K steps run in the converged regime in
+which a chain spends all but its first step.
+
+Rank 0 prints ONE JSON line.  `value` is the whole-job rate: steps of all
+chains / max-over-ranks wall time.  Chains are independent (weak scaling, no
+collective in the data path); torch.distributed (gloo) is used only for the
+barrier and the max-reduction of the timings.
+
+roofline: the cells x clusters x mutations kernel (k_ll) at the workload's
+first-sweep shape, timed live with HIP events on the library's stream.
+cpu_baseline: the CPU oracle (NumPy restatement of the reference, 1 core)
+stepping from the SAME post-warm-up state, on rank 0 at N = 1 only.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_ADDS_PEAK = 39.3e12       # FP64 vector: 78.6 TFLOP/s = 39.3e12 FMA|add/s
+
+CONFIGS = {
+    # name: (N, M, true clusters, missing, learned errors)
+    'c2': (1000, 200, 10, 0.10, False),
+    'c3': (5000, 1000, 10, 0.20, True),
+    'c4': (10000, 2000, 20, 0.20, True),
+}
+
+
+def synth(seed, N, M, C, miss, FP_true=0.001, FN_true=0.1):
+    """SURVEY.md section 8(d) generator."""
+    rng = np.random.RandomState(seed)
+    geno = (rng.random_sample((C, M)) < 0.3)
+    z = rng.randint(0, C, N)
+    X = geno[z]
+    u = rng.random_sample((N, M))
+    obs = np.where(X == 1, u >= FN_true, u < FP_true).astype(np.float64)
+    obs[rng.random_sample((N, M)) < miss] = np.nan
+    return obs
+
+
+def make_model(mod_fixed, mod_learn, data, learned):
+    if learned:
+        # CLI defaults of the reference (run_BnpC.py:67-90)
+        return mod_learn.CRP_errors_learning(data, DP_alpha=[-1, -1],
+            param_beta=[.25, .25], FP_mean=0.01, FP_sd=0.01, FN_mean=0.2,
+            FN_sd=0.1)
+    return mod_fixed.CRP(data, DP_alpha=[-1, -1], param_beta=[.25, .25],
+        FN_error=0.1, FP_error=0.001)
+
+
+MCMC_PARAMS = dict(sm_prob=.33, dpa_prob=.25, sm_ratios=[.75, .25], sm_steps=3)
+
+
+def new_chain(model, learned, total_steps):
+    from bnpc_amd.mcmc import Chain_steps
+    params = dict(MCMC_PARAMS, error_prob=.25 if learned else 0.,
+        param_proposal_sd=np.array([0.1, 0.25, 0.5]))
+    return Chain_steps(model, 1, total_steps, int(total_steps * .33), params,
+        0, False)
+
+
+def step(chain, i, burn_in):
+    chain.do_step()
+    chain.update_results(i, i < burn_in)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--seed', type=int, default=42)
+    ap.add_argument('--cpu-steps', type=int, default=4,
+        help='oracle steps timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--kernel-reps', type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    os.environ['BNPC_DEVICE'] = str(local_rank)
+
+    import torch
+    import torch.distributed as dist
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    def barrier_sync():
+        if distributed:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    from bnpc_amd import _lib
+    import libs.CRP as dev_fixed
+    import libs.CRP_learning_errors as dev_learn
+
+    N, M, C, miss, learned = CONFIGS[args.config]
+    data = synth(0, N, M, C, miss)
+
+    # chain seeds as the reference derives them (libs/MCMC.py:102-104)
+    np.random.seed(args.seed)
+    seeds = np.random.randint(0, 2 ** 32 - 1, world)
+    np.random.seed(seeds[rank])
+
+    model = make_model(dev_fixed, dev_learn, data, learned)
+    model.init()
+    K0 = len(model.cells_per_cluster)
+    total = args.warmup + args.steps
+    chain = new_chain(model, learned, total)
+    burn = int(total * .33)
+
+    # ---- warm-up (untimed): includes the first sweep from K0 clusters ----
+    first_step_s = None
+    for i in range(1, args.warmup + 1):
+        t0 = time.perf_counter()
+        step(chain, i, burn)
+        if i == 1:
+            first_step_s = time.perf_counter() - t0
+    K_warm = len(model.cells_per_cluster)
+
+    # snapshot of the post-warm-up state for the CPU baseline
+    snap = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        snap = dict(assignment=model.assignment.copy(),
+            parameters=model.parameters.copy(),
+            cells_per_cluster=dict(model.cells_per_cluster),
+            DP_a=model.DP_a, FP=model.FP, FN=model.FN,
+            rng=np.random.get_state())
+
+    # ---- timed region: exactly K steps -----------------------------------
+    barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup + 1, total + 1):
+        step(chain, i, burn)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    K_end = len(model.cells_per_cluster)
+    ml_end = float(chain.results['ML'][total])
+
+    # ---- roofline of the dominant kernel, measured live -------------------
+    roofline = None
+    extra = {}
+    if rank == 0:
+        ctx = model._dev()
+        rng = np.random.RandomState(1)
+
+        def time_ll(K):
+            theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+                .astype(np.float32)
+            ctx.ll_theta(0, theta, 0.01, 0.2, fetch=False)
+            ctx.sync()
+            ctx.bench_ll(2)
+            ms = ctx.bench_ll(args.kernel_reps)
+            alg_bytes = N * M / 4 + 4 * K * M + 8 * N * K
+            return ms, alg_bytes
+
+        ms, alg_bytes = time_ll(K0)
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        evals = N * K0 / (ms * 1e-3)
+        roofline = {
+            'kernel': 'k_ll', 'bound': 'hbm',
+            'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None,
+            'shape': {'N': N, 'M': M, 'K': K0},
+            'launch_ms': round(ms, 4),
+            'algorithmic_bytes': int(alg_bytes),
+            # the kernel is FP64-VALU-bound for K >~ 2 (2 exec-masked
+            # v_add_f64 per cell x cluster x mutation)
+            'valu': {
+                'achieved_elem_evals_per_s': evals * M,
+                'peak_elem_evals_per_s': FP64_ADDS_PEAK / 2,
+                'frac': round(evals * M / (FP64_ADDS_PEAK / 2), 4),
+            },
+        }
+        extra['ll_evals_per_s_K0'] = evals
+        for Kc in sorted({10, 64, K_end}):
+            ms_c, b_c = time_ll(Kc)
+            extra[f'll_evals_per_s_K{Kc}'] = N * Kc / (ms_c * 1e-3)
+            extra[f'll_launch_us_K{Kc}'] = round(ms_c * 1e3, 2)
+
+    # ---- CPU baseline: the oracle from the same state, 1 core -------------
+    cpu = None
+    if snap is not None:
+        from oracle import crp_numpy as O
+        om = make_model(O, O, data, learned)
+        om.assignment = snap['assignment'].copy()
+        om.parameters = snap['parameters'].copy()
+        om.cells_per_cluster = dict(snap['cells_per_cluster'])
+        om.DP_a, om.FP, om.FN = snap['DP_a'], snap['FP'], snap['FN']
+        om.init_DP_prior()
+        np.random.set_state(snap['rng'])
+        ochain = new_chain(om, learned, args.cpu_steps)
+        t0 = time.perf_counter()
+        for i in range(1, args.cpu_steps + 1):
+            step(ochain, i, 0)
+        cpu_s = time.perf_counter() - t0
+        # kernel-level: _calc_ll of a few cells against K0 clusters
+        theta = np.clip(np.random.RandomState(1).uniform(size=(K0, M)),
+            1e-5, 1 - 1e-5).astype(np.float32)
+        t0 = time.perf_counter()
+        ncell = 4
+        for r in range(ncell):
+            om._calc_ll(data[[r]], theta)
+        kt = time.perf_counter() - t0
+        import scipy
+        cpu = {
+            'value': round(args.cpu_steps / cpu_s, 4), 'unit': 'steps/s',
+            'cores': 1, 'kind': 'port',
+            'sample': f'{args.cpu_steps} MCMC steps (do_step+update_results) '
+                f'of the NumPy oracle from the GPU chain\'s post-warm-up '
+                f'state (K={K_warm}), {cpu_s:.1f} s',
+            'll_evals_per_s_K0': ncell * K0 / kt,
+            'host_cpus': os.cpu_count(),
+            'numpy': np.__version__, 'scipy': scipy.__version__,
+        }
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        line = {
+            'metric': 'MCMC steps/s, 5k cells x 1k muts (+ cell x cluster '
+                'log-lik evals/s in ll_evals_per_s_K0)',
+            'value': round(value, 3), 'unit': 'steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': f'{args.config}: synthetic {N} cells x {M} muts, '
+                    f'{int(miss * 100)}% missing, '
+                    f'{"learned" if learned else "fixed"} errors, '
+                    '1 chain per GPU, CLI-default moves',
+                'chains': world, 'data_seed': 0, 'mcmc_seed': args.seed,
+                'K0': K0, 'K_after_warmup': K_warm, 'K_end': K_end,
+            },
+            'first_step_s': round(first_step_s, 4),
+            'ML_end': ml_end,
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        line.update(extra)
+        if cpu:
+            line['speedup_vs_cpu_baseline'] = round(value / cpu['value'], 2)
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -53,6 +53,7 @@ SIGNATURES = {
     'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
         _pi32]),
     'bnpc_ll_total': (C.c_int, [_ctx, _pf, _i64, _pd, _pd, C.c_int, _pd]),
+    'bnpc_bench_ll': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
     'bnpc_timer_start': (C.c_int, [_ctx]),
     'bnpc_timer_stop': (C.c_int, [_ctx, C.POINTER(C.c_float)]),
     'bnpc_sync': (C.c_int, [_ctx]),
@@ -260,14 +261,21 @@ class Context:
     def ll_total(self, theta, FP, FN):
         """Total log-likelihood(s) under the resident per-cluster counts."""
         theta = np.ascontiguousarray(theta, dtype=np.float32)
-        FP = np.atleast_1d(np.asarray(FP, dtype=np.float64))
-        FN = np.atleast_1d(np.asarray(FN, dtype=np.float64))
+        FP = np.ascontiguousarray(np.atleast_1d(FP), dtype=np.float64)
+        FN = np.ascontiguousarray(np.atleast_1d(FN), dtype=np.float64)
+        assert FP.shape == FN.shape and FP.ndim == 1
         E = FP.size
         out = np.empty(E, dtype=np.float64)
         check(self._lib.bnpc_ll_total(self._h, ptr(theta, C.c_float),
             theta.shape[0], ptr(FP, C.c_double), ptr(FN, C.c_double), E,
             ptr(out, C.c_double)), 'll_total')
         return out
+
+    def bench_ll(self, reps=10):
+        """Average duration (ms) of the last ll kernel launch, re-issued."""
+        ms = C.c_float(0)
+        check(self._lib.bnpc_bench_ll(self._h, reps, C.byref(ms)), 'bench_ll')
+        return ms.value
 
     def timer_start(self):
         check(self._lib.bnpc_timer_start(self._h), 'timer_start')

@@ -88,6 +88,7 @@ struct bnpc_ctx {
     int64_t N = 0, M = 0;
     int W = 0;          // 64-bit words per row
     int Mpad = 0;       // W * 64
+    int Mt = 0;         // table row count per group: M rounded up to 4
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ulonglong2 *rows = nullptr;           // [N][W]
@@ -101,6 +102,9 @@ struct bnpc_ctx {
     // pinned staging for small D2H
     void *pin = nullptr;
     size_t pin_cap = 0;
+    // configuration of the last k_ll launch (bnpc_bench_ll re-issues it)
+    int last_kw = 0, last_view = -1;
+    int64_t last_K = 0, last_ldo = 0;
 };
 
 static int ensure(DevBuf &b, size_t bytes)
@@ -172,20 +176,20 @@ __global__ __launch_bounds__(256) void k_gather_transpose(
 // ---------------------------------------------------------------------------
 template <int KW>
 __global__ __launch_bounds__(256) void k_tables_theta(
-    const float *__restrict__ theta, int K, int M, double FP, double FN,
-    double *__restrict__ T)
+    const float *__restrict__ theta, int K, int M, int Mt, double FP,
+    double FN, double *__restrict__ T)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int g = blockIdx.y;
-    if (m >= M) return;
+    if (m >= Mt) return;
     const double pFN1 = 1.0 - FN;   // (1-FN)**1 * FN**0
     const double pFP0 = 1.0 - FP;   // (1-FP)**1 * FP**0
-    double *t = T + ((size_t)g * M + m) * (2 * KW);
+    double *t = T + ((size_t)g * Mt + m) * (2 * KW);
 #pragma unroll
     for (int j = 0; j < KW; j++) {
         const int k = g * KW + j;
         double l1 = 0.0, l0 = 0.0;
-        if (k < K) {
+        if (k < K && m < M) {
             const float th = theta[(size_t)k * M + m];
             const double th64 = (double)th;
             const double om64 = (double)(1.0f - th);
@@ -201,17 +205,18 @@ __global__ __launch_bounds__(256) void k_tables_theta(
 template <int KW>
 __global__ __launch_bounds__(256) void k_tables_relayout(
     const double *__restrict__ L1, const double *__restrict__ L0, int K, int M,
-    double *__restrict__ T)
+    int Mt, double *__restrict__ T)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int g = blockIdx.y;
-    if (m >= M) return;
-    double *t = T + ((size_t)g * M + m) * (2 * KW);
+    if (m >= Mt) return;
+    double *t = T + ((size_t)g * Mt + m) * (2 * KW);
 #pragma unroll
     for (int j = 0; j < KW; j++) {
         const int k = g * KW + j;
-        t[j] = (k < K) ? L1[(size_t)k * M + m] : 0.0;
-        t[KW + j] = (k < K) ? L0[(size_t)k * M + m] : 0.0;
+        const bool live = (k < K) && (m < M);
+        t[j] = live ? L1[(size_t)k * M + m] : 0.0;
+        t[KW + j] = live ? L0[(size_t)k * M + m] : 0.0;
     }
 }
 
@@ -225,12 +230,24 @@ __global__ __launch_bounds__(256) void k_tables_relayout(
 // masks and table elements are wave-uniform -> scalar loads; the adds are
 // exec-masked v_add_f64 with an SGPR-pair addend; m runs sequentially.
 // ---------------------------------------------------------------------------
+// Software pipeline: a stage is U consecutive mutations (U mask pairs and
+// U*2*KW table doubles, all in SGPRs); the scalar loads of stage b+1 are in
+// flight while the exec-masked adds of stage b issue.  The table stride Mt is
+// M rounded up to 4 with zero padding and the mask rows are padded to 64
+// mutations with empty masks, so no tail handling is needed; the prefetch of
+// the stage after the last one reads the slack the allocations keep.
+template <int KW>
+struct LLStage {
+    static constexpr int U = (KW >= 8) ? 1 : (KW >= 2 ? 2 : 4);
+};
+
 template <int KW>
 __global__ __launch_bounds__(256) void k_ll(
-    const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
+    const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
     double *__restrict__ out)
 {
+    constexpr int U = LLStage<KW>::U;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const long long blk = (long long)blockIdx.x * 4 + wave;
@@ -238,22 +255,48 @@ __global__ __launch_bounds__(256) void k_ll(
     if (blk >= nblk) return;     // whole wave leaves together
 
     const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
-    const double *__restrict__ t = T + (size_t)g * M * (2 * KW);
+    const double *__restrict__ t = T + (size_t)g * Mt * (2 * KW);
 
     double acc[KW];
 #pragma unroll
     for (int j = 0; j < KW; j++) acc[j] = 0.0;
 
-    for (int m = 0; m < M; m++) {
-        const ulonglong2 p = mk[m];
-        const double *__restrict__ tm = t + (size_t)m * (2 * KW);
-        if (__builtin_amdgcn_inverse_ballot_w64(p.x)) {
+    ulonglong2 cm[U];
+    double ct[U][2 * KW];
 #pragma unroll
-            for (int j = 0; j < KW; j++) acc[j] += tm[j];
+    for (int u = 0; u < U; u++) {
+        cm[u] = mk[u];
+#pragma unroll
+        for (int j = 0; j < 2 * KW; j++) ct[u][j] = t[u * 2 * KW + j];
+    }
+    const int nb = Mt / U;
+    for (int b = 0; b < nb; b++) {
+        ulonglong2 nm[U];
+        double nt[U][2 * KW];
+        const ulonglong2 *__restrict__ mkn = mk + (size_t)(b + 1) * U;
+        const double *__restrict__ tn = t + (size_t)(b + 1) * U * 2 * KW;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            nm[u] = mkn[u];
+#pragma unroll
+            for (int j = 0; j < 2 * KW; j++) nt[u][j] = tn[u * 2 * KW + j];
         }
-        if (__builtin_amdgcn_inverse_ballot_w64(p.y)) {
 #pragma unroll
-            for (int j = 0; j < KW; j++) acc[j] += tm[KW + j];
+        for (int u = 0; u < U; u++) {
+            if (__builtin_amdgcn_inverse_ballot_w64(cm[u].x)) {
+#pragma unroll
+                for (int j = 0; j < KW; j++) acc[j] += ct[u][j];
+            }
+            if (__builtin_amdgcn_inverse_ballot_w64(cm[u].y)) {
+#pragma unroll
+                for (int j = 0; j < KW; j++) acc[j] += ct[u][KW + j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            cm[u] = nm[u];
+#pragma unroll
+            for (int j = 0; j < 2 * KW; j++) ct[u][j] = nt[u][j];
         }
     }
 
@@ -380,7 +423,8 @@ static int build_view(bnpc_ctx *c, int view, const long long *d_cells,
     v.n = n;
     v.nblk = (n + 63) / 64;
     if (n == 0) return 0;
-    if (ensure(v.masks, (size_t)v.nblk * c->Mpad * sizeof(ulonglong2)))
+    // + slack: k_ll prefetches one stage past the last block
+    if (ensure(v.masks, ((size_t)v.nblk * c->Mpad + 8) * sizeof(ulonglong2)))
         return 1;
     dim3 grid((unsigned)v.nblk, (unsigned)((c->W + 3) / 4));
     hipLaunchKernelGGL(k_gather_transpose, grid, dim3(256), 0, c->stream,
@@ -405,6 +449,7 @@ static int create_impl(int device, int64_t N, int64_t M, GetCode code,
     c->M = M;
     c->W = (int)((M + 63) / 64);
     c->Mpad = c->W * 64;
+    c->Mt = (int)((M + 3) / 4 * 4);
 
     // pack on the host: 2 bits per entry
     std::vector<ulonglong2> rows((size_t)N * c->W);
@@ -569,21 +614,23 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
 {
     const int64_t G = (K + KW - 1) / KW;
     ARGCHK(G <= 65535, "too many cluster groups for one launch");
-    if (ensure(c->tabs, (size_t)G * c->M * 2 * KW * sizeof(double))) return 1;
-    dim3 tgrid((unsigned)((c->M + 255) / 256), (unsigned)G);
+    // + slack: k_ll prefetches one stage past the last group
+    if (ensure(c->tabs, ((size_t)G * c->Mt + 8) * 2 * KW * sizeof(double)))
+        return 1;
+    dim3 tgrid((unsigned)((c->Mt + 255) / 256), (unsigned)G);
     if (from_theta)
         hipLaunchKernelGGL(k_tables_theta<KW>, tgrid, dim3(256), 0, c->stream,
-                           (const float *)c->theta.p, (int)K, (int)c->M, FP,
-                           FN, (double *)c->tabs.p);
+                           (const float *)c->theta.p, (int)K, (int)c->M,
+                           c->Mt, FP, FN, (double *)c->tabs.p);
     else
         hipLaunchKernelGGL(k_tables_relayout<KW>, tgrid, dim3(256), 0,
                            c->stream, (const double *)c->tab_in.p,
                            (const double *)c->tab_in.p + (size_t)K * c->M,
-                           (int)K, (int)c->M, (double *)c->tabs.p);
+                           (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
     HIPCHK(hipGetLastError());
     dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)G);
     hipLaunchKernelGGL(k_ll<KW>, grid, dim3(256), 0, c->stream,
-                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
+                       (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,
                        (long long)v.n, (long long)v.nblk,
                        (const double *)c->tabs.p, (int)K, (long long)ldo,
                        d_out);
@@ -614,6 +661,10 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     default: rc = launch_ll<1>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
     }
     if (rc) return rc;
+    c->last_kw = kw;
+    c->last_view = view;
+    c->last_K = K;
+    c->last_ldo = ldo;
     if (out) {
         HIPCHK(hipMemcpyAsync(out, c->out.p, out_bytes, hipMemcpyDeviceToHost,
                               c->stream));
@@ -808,6 +859,43 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
         for (int b = 0; b < TOTAL_BLOCKS; b++) s += p[b * 4 + e];
         out[e] = s;
     }
+    return 0;
+}
+
+template <int KW>
+static void relaunch_ll(bnpc_ctx *c, const View &v)
+{
+    const int64_t G = (c->last_K + KW - 1) / KW;
+    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)G);
+    hipLaunchKernelGGL(k_ll<KW>, grid, dim3(256), 0, c->stream,
+                       (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,
+                       (long long)v.n, (long long)v.nblk,
+                       (const double *)c->tabs.p, (int)c->last_K,
+                       (long long)c->last_ldo, (double *)c->out.p);
+}
+
+extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
+{
+    ARGCHK(c && ms_per_launch, "NULL argument");
+    ARGCHK(reps >= 1, "reps must be positive");
+    ARGCHK(c->last_kw > 0, "no previous bnpc_ll_theta / bnpc_ll_tables call");
+    HIPCHK(hipSetDevice(c->device));
+    const View &v = c->views[c->last_view];
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) {
+        switch (c->last_kw) {
+        case 8: relaunch_ll<8>(c, v); break;
+        case 4: relaunch_ll<4>(c, v); break;
+        case 2: relaunch_ll<2>(c, v); break;
+        default: relaunch_ll<1>(c, v); break;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_per_launch = ms / reps;
     return 0;
 }
 

@@ -127,6 +127,11 @@ int bnpc_ll_total(bnpc_ctx *ctx, const float *theta, int64_t K,
                   const double *FP, const double *FN, int E, double *out);
 
 /* ---- timing on the context's stream (HIP events) -------------------------- */
+/* Re-issue the cells x clusters x mutations kernel of the last bnpc_ll_theta /
+ * bnpc_ll_tables call `reps` times on the resident tables, bracketed by HIP
+ * events on the context's stream; *ms_per_launch = average kernel duration.
+ * Measurement only (bench.py roofline). */
+int bnpc_bench_ll(bnpc_ctx *ctx, int reps, float *ms_per_launch);
 int bnpc_timer_start(bnpc_ctx *ctx);
 int bnpc_timer_stop(bnpc_ctx *ctx, float *ms);
 int bnpc_sync(bnpc_ctx *ctx);

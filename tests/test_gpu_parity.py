@@ -1,0 +1,389 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI
+(bnpc_amd._lib -> libbnpc_hip.so), against the CPU oracle and the golden
+vectors captured from the reference.
+
+Tolerances (north star: 1e-6 relative on log-likelihoods, identical
+assignment trajectories):
+  * sums over caller-built tables (bnpc_ll_tables): BIT-EXACT vs the oracle
+    (same elements, same m-sequential order);
+  * sums over device-built tables (bnpc_ll_theta, bnpc_ll_total): the device
+    log differs from NumPy's by <= 1 ulp per element -> 1e-12 relative asserted;
+  * column counts: exact integers;
+  * trajectories: identical assignments, traces to 1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import crp_numpy as O
+from bnpc_amd import _lib, model as P
+import test_host_logic as H
+
+pytestmark = pytest.mark.gpu
+
+
+def decode(codes):
+    x = codes.astype(np.float64)
+    x[codes == 3] = np.nan
+    return x
+
+
+def oracle_ll(data, theta, FP, FN):
+    m = O.CRP(data, [-1, -1], [1, 1], FN_error=FN, FP_error=FP)
+    return np.stack([m._calc_ll(data[[r]], theta)
+        for r in range(data.shape[0])])
+
+
+def table_sums(x, L1, L0):
+    out = np.empty((x.shape[0], L1.shape[0]))
+    for k in range(L1.shape[0]):
+        el = np.where(x == 1, L1[k], np.where(x == 0, L0[k], np.nan))
+        out[:, k] = O.seqsum(el, axis=1)
+    return out
+
+
+def host_tables(theta, FP, FN):
+    t64 = theta.astype(np.float64)
+    om64 = (1 - theta).astype(np.float64)
+    return (np.log(t64 * (1 - FN) + om64 * FP),
+        np.log(t64 * FN + om64 * (1 - FP)))
+
+
+def test_device_is_gfx950():
+    assert _lib.device_count() >= 1
+    name, cus = _lib.device_info(0)
+    assert name.startswith('gfx950'), name
+    assert cus >= 200
+
+
+# ----------------------------------------------------------- golden vectors
+def test_ll_theta_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'calc_ll.npz'))
+    for ci in range(int(g['n_cases'])):
+        data = decode(g[f'c{ci}_data'])
+        theta = g[f'c{ci}_theta']
+        FP, FN = g[f'c{ci}_FPFN']
+        ctx = _lib.Context(data=data)
+        got = ctx.ll_theta(0, theta, FP, FN)
+        np.testing.assert_allclose(got, g[f'c{ci}_ll'], rtol=1e-12,
+            atol=1e-12, err_msg=f'case {ci}')
+        # and against the oracle on this stack
+        np.testing.assert_allclose(got, oracle_ll(data, theta, FP, FN),
+            rtol=1e-12, atol=1e-12)
+        # flat total through counts
+        assign = g[f'c{ci}_assign']
+        ids = np.unique(assign)
+        ctx.colcounts_by_label(assign, ids)
+        tot = ctx.ll_total(theta[ids], [FP], [FN])[0]
+        np.testing.assert_allclose(tot, g[f'c{ci}_flat'], rtol=1e-12)
+        ctx.close()
+
+
+def test_ll_tables_is_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'calc_ll.npz'))
+    for ci in range(int(g['n_cases'])):
+        data = decode(g[f'c{ci}_data'])
+        theta = g[f'c{ci}_theta']
+        FP, FN = g[f'c{ci}_FPFN']
+        L1, L0 = host_tables(theta, FP, FN)
+        ctx = _lib.Context(data=data)
+        got = ctx.ll_tables(0, L1, L0)
+        assert np.array_equal(got, table_sums(data, L1, L0)), ci
+        # with NumPy-built tables the device reproduces the oracle's
+        # _calc_ll bit for bit
+        assert np.array_equal(got, oracle_ll(data, theta, FP, FN)), ci
+        ctx.close()
+
+
+@pytest.mark.parametrize('kw', ['1', '2', '4', '8'])
+def test_every_cluster_tiling_gives_identical_bits(kw, monkeypatch):
+    rng = np.random.RandomState(5)
+    data = (rng.random_sample((333, 257)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    theta = np.clip(rng.uniform(size=(37, 257)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    ctx = _lib.Context(data=data)
+    monkeypatch.delenv('BNPC_KW', raising=False)
+    ref = ctx.ll_theta(0, theta, 0.01, 0.2)
+    monkeypatch.setenv('BNPC_KW', kw)
+    assert np.array_equal(ctx.ll_theta(0, theta, 0.01, 0.2), ref)
+    L1, L0 = host_tables(theta, 0.01, 0.2)
+    assert np.array_equal(ctx.ll_tables(0, L1, L0), table_sums(data, L1, L0))
+    ctx.close()
+
+
+# ------------------------------------------------------------- edge cases
+@pytest.mark.parametrize('N,M', [(1, 1), (5, 1), (1, 64), (63, 65),
+    (64, 64), (65, 63), (130, 1003), (257, 130)])
+def test_ragged_shapes(N, M):
+    rng = np.random.RandomState(N * 1000 + M)
+    data = (rng.random_sample((N, M)) < 0.4).astype(float)
+    data[rng.random_sample(data.shape) < 0.25] = np.nan
+    theta = np.clip(rng.uniform(size=(3, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    ctx = _lib.Context(data=data)
+    L1, L0 = host_tables(theta, 0.02, 0.15)
+    assert np.array_equal(ctx.ll_tables(0, L1, L0), table_sums(data, L1, L0))
+    np.testing.assert_allclose(ctx.ll_theta(0, theta, 0.02, 0.15),
+        table_sums(data, L1, L0), rtol=1e-12, atol=1e-12)
+    n1, n0 = ctx.cell_counts()
+    assert np.array_equal(n1, (data == 1).sum(axis=1))
+    assert np.array_equal(n0, (data == 0).sum(axis=1))
+    c1, c0 = ctx.colcounts([np.arange(N)])
+    assert np.array_equal(c1[0], (data == 1).sum(axis=0))
+    assert np.array_equal(c0[0], (data == 0).sum(axis=0))
+    ctx.close()
+
+
+def test_all_missing_all_ones_all_zeros_and_boundary_theta():
+    M = 70
+    data = np.zeros((6, M))
+    data[0] = np.nan
+    data[1] = 1
+    data[2] = 0
+    data[3, ::2] = 1
+    data[4, :] = np.nan
+    data[4, 69] = 1
+    data[5, :64] = np.nan
+    theta = np.stack([np.full(M, 1e-5), np.full(M, 1 - 1e-5),
+        np.linspace(1e-5, 1 - 1e-5, M)]).astype(np.float32)
+    eps = np.finfo(np.float64).resolution
+    ctx = _lib.Context(data=data)
+    for FP, FN in ((1e-3, 0.1), (eps, eps), (0.4999, 0.4999)):
+        got = ctx.ll_theta(0, theta, FP, FN)
+        np.testing.assert_allclose(got, oracle_ll(data, theta, FP, FN),
+            rtol=1e-12, atol=1e-12)
+        assert np.all(got[0] == 0.0)          # nothing observed -> empty sum
+    ctx.close()
+
+
+def test_invalid_inputs_raise():
+    data = np.zeros((4, 4))
+    ctx = _lib.Context(data=data)
+    theta = np.full((1, 4), 0.5, dtype=np.float32)
+    with pytest.raises(RuntimeError, match='error rates'):
+        ctx.ll_theta(0, theta, 0.0, 0.1)
+    with pytest.raises(RuntimeError, match='out of range'):
+        ctx.view_set(1, [0, 7])
+    with pytest.raises(RuntimeError, match='view'):
+        ctx.view_set(0, [0])
+    with pytest.raises(RuntimeError, match='resident counts'):
+        ctx.ll_total(theta, [0.1], [0.1])
+    bad = np.full((2, 2), 0.5)
+    with pytest.raises(RuntimeError, match='not 0, 1 or missing'):
+        _lib.Context(data=bad)
+    ctx.close()
+
+
+def test_views_gather_any_cell_list():
+    rng = np.random.RandomState(9)
+    data = (rng.random_sample((300, 150)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    theta = np.clip(rng.uniform(size=(2, 150)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    L1, L0 = host_tables(theta, 0.01, 0.1)
+    ctx = _lib.Context(data=data)
+    for cells in (np.array([], dtype=int), np.array([7]), np.arange(64),
+            rng.permutation(300), rng.randint(0, 300, 129),
+            np.array([5] * 70)):
+        ctx.view_set(1, cells)
+        assert ctx.view_size(1) == cells.size
+        got = ctx.ll_tables(1, L1, L0)
+        assert got.shape == (cells.size, 2)
+        assert np.array_equal(got, table_sums(data[cells], L1, L0))
+    # views are independent
+    ctx.view_set(1, np.arange(10))
+    ctx.view_set(2, np.arange(290, 300))
+    assert np.array_equal(ctx.ll_tables(1, L1, L0),
+        table_sums(data[:10], L1, L0))
+    assert np.array_equal(ctx.ll_tables(2, L1, L0),
+        table_sums(data[290:], L1, L0))
+    ctx.close()
+
+
+def test_colcounts_segments_and_labels():
+    rng = np.random.RandomState(10)
+    data = (rng.random_sample((1000, 333)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    ctx = _lib.Context(data=data)
+    segs = [rng.permutation(1000)[:n] for n in (0, 1, 255, 256, 257, 700)]
+    n1, n0 = ctx.colcounts(segs)
+    for g, s in enumerate(segs):
+        assert np.array_equal(n1[g], (data[s] == 1).sum(axis=0))
+        assert np.array_equal(n0[g], (data[s] == 0).sum(axis=0))
+    assign = rng.randint(0, 40, 1000) * 3      # sparse ids
+    ids = rng.permutation(np.unique(assign))   # any order
+    n1, n0 = ctx.colcounts_by_label(assign, ids)
+    for g, i in enumerate(ids):
+        assert np.array_equal(n1[g], (data[assign == i] == 1).sum(axis=0))
+        assert np.array_equal(n0[g], (data[assign == i] == 0).sum(axis=0))
+    with pytest.raises(RuntimeError, match='not in ids'):
+        ctx.colcounts_by_label(assign, ids[:-1])
+    ctx.close()
+
+
+def test_ll_total_trials_match_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'state_functions.npz'))
+    data = decode(g['data'])
+    ctx = _lib.Context(data=data)
+    ids = g['le_clusters']
+    ctx.colcounts_by_label(g['le_assignment'], ids)
+    trials = g['le_trials']
+    got = np.concatenate([
+        ctx.ll_total(g['le_parameters'], trials[:4, 0], trials[:4, 1]),
+        ctx.ll_total(g['le_parameters'], trials[4:, 0], trials[4:, 1])])
+    np.testing.assert_allclose(got, g['le_ll'], rtol=1e-12)
+    # deterministic: same launch twice gives the same bits
+    again = ctx.ll_total(g['le_parameters'], trials[:4, 0], trials[:4, 1])
+    assert np.array_equal(again, got[:4])
+    ctx.close()
+
+
+# --------------------------------------------- model surface on the device
+def test_state_functions_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'state_functions.npz'))
+    data = decode(g['data'])
+    for pi, pb in enumerate(g['param_betas']):
+        pre = f'p{pi}_'
+        m = P.CRP(data, [-1, -1], list(pb), FN_error=0.1, FP_error=1e-3)
+        m.DP_a = float(g[pre + 'DP_a0'])
+        m.init_DP_prior()
+        m.assignment = g[pre + 'assignment1'].copy()
+        cl = g[pre + 'clusters1']
+        m.parameters = np.zeros(data.shape, dtype=np.float32)
+        m.parameters[cl] = g[pre + 'parameters1']
+        m.cells_per_cluster = dict(
+            zip(cl.tolist(), g[pre + 'sizes1'].tolist()))
+        np.testing.assert_allclose(m.get_lpost_single_new_cluster(),
+            g[pre + 'new_cluster'], rtol=1e-12)
+        np.testing.assert_allclose(m.get_ll_full(), g[pre + 'll_full1'],
+            rtol=1e-12)
+        np.testing.assert_allclose(m.get_lprior_full(), g[pre + 'lprior1'],
+            rtol=1e-10)
+        got = np.stack([m.get_lpost_single(c, cl)
+            for c in range(0, data.shape[0], 7)])
+        np.testing.assert_allclose(got, g[pre + 'lpost_single'], rtol=1e-12)
+        for j in range(int(g[pre + 'n_logA'])):
+            cells = g[pre + f'logA{j}_cells']
+            new, old = g[pre + f'logA{j}_new'], g[pre + f'logA{j}_old']
+            std = g[pre + f'logA{j}_std']
+            a, b = (P.TMIN - old) / std, (P.TMAX - old) / std
+            for clip in (0, 1):
+                A = m._get_log_A(new, old, cells, a, b, std, bool(clip))
+                np.testing.assert_allclose(A, g[pre + f'logA{j}_A{clip}'],
+                    rtol=1e-9, atol=1e-9)
+        cells = g[pre + 'rg_cells']
+        m._rg_S = cells[1:-1]
+        m._rg_counts = None
+        m._dev().view_set(P.VIEW_MOVE, m._rg_S)
+        m.rg_assignment = g[pre + 'rg_assignment_init'].astype(np.int64)
+        m.rg_params_split = g[pre + 'rg_params_split'].copy()
+        m.rg_params_merge = g[pre + 'rg_params_merge'].copy()
+        np.testing.assert_allclose(
+            m._rg_get_ll(cells[1:-1], m.rg_params_split), g[pre + 'rg_ll'],
+            rtol=1e-12)
+        np.testing.assert_allclose(m._get_ll_ratio(cells, 'split'),
+            g[pre + 'rg_ll_ratio_split'], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(m._get_ll_ratio(cells, 'merge'),
+            g[pre + 'rg_ll_ratio_merge'], rtol=1e-9, atol=1e-9)
+        m.close()
+
+
+@pytest.mark.parametrize('kind', ['fixed', 'learn'])
+def test_gibbs_sweeps_match_oracle(kind):
+    H.test_gibbs_sweeps_match_oracle(kind)
+
+
+def test_update_parameters_and_errors_match_oracle():
+    H.test_update_parameters_and_errors_match_oracle()
+
+
+@pytest.mark.parametrize('pb', [(.25, .25), (1, 1)])
+@pytest.mark.parametrize('start', ['together', 'fragmented', 'gibbs'])
+def test_split_merge_moves_match_oracle(pb, start):
+    H.test_split_merge_moves_match_oracle(pb, start)
+
+
+def test_rg_init_split_is_bit_identical_to_oracle():
+    H.test_rg_init_split_is_bit_identical_to_oracle()
+
+
+@pytest.mark.parametrize('kind,eup', [('fixed', 0.), ('learn', .25)])
+def test_chain_matches_oracle(kind, eup):
+    H.test_chain_matches_oracle(kind, eup)
+
+
+def test_other_init_modes_match_oracle():
+    H.test_other_init_modes_match_oracle()
+
+
+def test_example_data_trajectory_matches_reference(golden_dir):
+    """example_data/data.csv, seed 42, fixed error rates, 200 steps: the
+    device path walks the REFERENCE's assignment trajectory
+    (sha ec91db5ad46ef182)."""
+    from bnpc_amd.io import load_data
+    t = np.load(os.path.join(golden_dir, 'trajectories.npz'))
+    data = load_data(os.path.join(golden_dir, 'example_data.csv'))
+    res = H.run_chain(H.make(P, 'fixed', data), 200, 42)
+    assert np.array_equal(res['assignments'], t['ex_fixed_assignments'])
+    np.testing.assert_allclose(res['ML'], t['ex_fixed_ML'], rtol=1e-9)
+    np.testing.assert_allclose(res['MAP'], t['ex_fixed_MAP'], rtol=1e-9)
+
+
+def test_config2_chain_matches_oracle():
+    """BASELINE config 2 (1000 x 200, 10 % missing, fixed FP/FN), 12 steps
+    including the first sweep from K0 ~ 630 clusters."""
+    data = H.synth(0, 1000, 200, 10, 0.10)
+    ro = H.run_chain(H.make(O, 'fixed', data), 12, 42)
+    rp = H.run_chain(H.make(P, 'fixed', data), 12, 42)
+    assert np.array_equal(ro['assignments'], rp['assignments'])
+    np.testing.assert_allclose(rp['ML'], ro['ML'], rtol=1e-9)
+
+
+# ------------------------------------------ full BASELINE size, properties
+def test_full_size_properties_5000x1000():
+    """Config 3 shape (5000 x 1000, 20 % missing) with K0 = 3152 clusters:
+    size-independent properties + a sampled comparison with the oracle."""
+    N, M, K = 5000, 1000, 3152
+    data = H.synth(0, N, M, 10, 0.20)
+    rng = np.random.RandomState(1)
+    theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    FP, FN = 0.01, 0.2
+    ctx = _lib.Context(data=data)
+    ll = ctx.ll_theta(0, theta, FP, FN)
+    assert ll.shape == (N, K) and np.all(np.isfinite(ll)) and np.all(ll < 0)
+
+    # (a) sampled oracle comparison
+    rows = rng.choice(N, 24, replace=False)
+    cols = rng.choice(K, 48, replace=False)
+    want = oracle_ll(data[rows], theta[cols], FP, FN)
+    np.testing.assert_allclose(ll[np.ix_(rows, cols)], want, rtol=1e-12)
+
+    # (b) splitting the clusters over two launches changes nothing
+    left = ctx.ll_theta(0, theta[:1000], FP, FN)
+    assert np.array_equal(left, ll[:, :1000])
+
+    # (c) permutation equivariance through a gathered view
+    perm = rng.permutation(N)[:1500]
+    ctx.view_set(1, perm)
+    sub = ctx.ll_theta(1, theta[:64], FP, FN)
+    assert np.array_equal(sub, ll[perm, :64])
+
+    # (d) the flat total equals the sum of the assigned entries
+    assign = rng.randint(0, K, N)
+    ids = np.unique(assign)
+    ctx.colcounts_by_label(assign, ids)
+    tot = ctx.ll_total(theta[ids], [FP], [FN])[0]
+    np.testing.assert_allclose(tot, ll[np.arange(N), assign].sum(),
+        rtol=1e-11)
+
+    # (e) counts: clusters partition the cells; 1s + 0s + missing = N
+    n1, n0 = ctx.colcounts_by_label(assign, ids)
+    a1, a0 = ctx.colcounts([np.arange(N)])
+    assert np.array_equal(n1.sum(axis=0), a1[0])
+    assert np.array_equal(n0.sum(axis=0), a0[0])
+    assert np.array_equal(a1[0] + a0[0] + np.isnan(data).sum(axis=0),
+        np.full(M, N))
+    ctx.close()
