@@ -88,7 +88,7 @@ struct bnpc_ctx {
     int64_t N = 0, M = 0;
     int W = 0;          // 64-bit words per row
     int Mpad = 0;       // W * 64
-    int Mt = 0;         // table row count per group: M rounded up to 4
+    int Mt = 0;         // table row count per group: M rounded up to 8
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ulonglong2 *rows = nullptr;           // [N][W]
@@ -231,27 +231,54 @@ __global__ __launch_bounds__(256) void k_tables_relayout(
 // exec-masked v_add_f64 with an SGPR-pair addend; m runs sequentially.
 // ---------------------------------------------------------------------------
 // Software pipeline: a stage is U consecutive mutations (U mask pairs and
-// U*2*KW table doubles, all in SGPRs); the scalar loads of stage b+1 are in
-// flight while the exec-masked adds of stage b issue.  The table stride Mt is
-// M rounded up to 4 with zero padding and the mask rows are padded to 64
-// mutations with empty masks, so no tail handling is needed; the prefetch of
-// the stage after the last one reads the slack the allocations keep.
+// U*2*KW table doubles, all in SGPRs); the scalar loads of the next stage are
+// in flight while the exec-masked adds of the current one issue.  The table
+// stride Mt is M rounded up to 8 with zero padding and the mask rows are
+// padded to 64 mutations with empty masks, so no tail handling is needed; the
+// prefetch of the stage after the last one reads the slack the allocations
+// keep.
+//
+// Grid: 1-D, one workgroup = 4 waves = 4 consecutive slot blocks x one
+// cluster group.  Workgroups are dealt round-robin over the 8 XCDs (observed,
+// MI355X_MICROARCH.md), each with its own L2: the XCD-aware remap below gives
+// every XCD a CONTIGUOUS range of virtual ids, and virtual ids enumerate the
+// slot blocks of one cluster group before moving to the next group, so the
+// workgroups that stream the same table run on one XCD and share it in that
+// L2 (speed only; any placement is correct).
 template <int KW>
 struct LLStage {
     static constexpr int U = (KW >= 8) ? 1 : (KW >= 2 ? 2 : 4);
 };
 
+__device__ __forceinline__ void ll_tile_coords(unsigned nbx, unsigned G,
+                                               int xcd_remap, long long &bx,
+                                               long long &g)
+{
+    const unsigned nwg = nbx * G;           // < 2^31, checked by the host
+    unsigned v = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned q = nwg >> 3, r = nwg & 7;
+        const unsigned xcd = v & 7, idx = v >> 3;
+        v = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    const unsigned gg = v / nbx;
+    g = gg;
+    bx = v - gg * nbx;
+}
+
 template <int KW>
 __global__ __launch_bounds__(256) void k_ll(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
-    double *__restrict__ out)
+    double *__restrict__ out, int xcd_remap)
 {
     constexpr int U = LLStage<KW>::U;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const long long blk = (long long)blockIdx.x * 4 + wave;
-    const int g = blockIdx.y;
+    long long bx, g;
+    ll_tile_coords((unsigned)((nblk + 3) >> 2), (unsigned)((K + KW - 1) / KW),
+                   xcd_remap, bx, g);
+    const long long blk = bx * 4 + wave;
     if (blk >= nblk) return;     // whole wave leaves together
 
     const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
@@ -306,6 +333,118 @@ __global__ __launch_bounds__(256) void k_ll(
 #pragma unroll
         for (int j = 0; j < KW; j++)
             if (g * KW + j < K) o[j] = acc[j];
+    }
+}
+
+// One mutation for 8 clusters: EXEC <- lane mask of the cells that observed a
+// 1, eight v_add_f64 with SGPR-pair addends; EXEC <- the 0 mask, eight more;
+// EXEC restored to all lanes.  Hand-placed so that the scalar pipe issues 3
+// instructions per 16 vector adds (the compiler's s_and_saveexec / s_or pairs
+// plus its stage copies keep the CU's single scalar unit as busy as the
+// vector units).  The wave is fully active here by construction.
+__device__ __forceinline__ void ll_step8(double (&a)[8],
+                                         const ulonglong2 &m,
+                                         const double (&t)[16])
+{
+    asm volatile(
+        "s_mov_b64 exec, %8\n\t"
+        "v_add_f64 %0, %0, %10\n\t"
+        "v_add_f64 %1, %1, %11\n\t"
+        "v_add_f64 %2, %2, %12\n\t"
+        "v_add_f64 %3, %3, %13\n\t"
+        "v_add_f64 %4, %4, %14\n\t"
+        "v_add_f64 %5, %5, %15\n\t"
+        "v_add_f64 %6, %6, %16\n\t"
+        "v_add_f64 %7, %7, %17\n\t"
+        "s_mov_b64 exec, %9\n\t"
+        "v_add_f64 %0, %0, %18\n\t"
+        "v_add_f64 %1, %1, %19\n\t"
+        "v_add_f64 %2, %2, %20\n\t"
+        "v_add_f64 %3, %3, %21\n\t"
+        "v_add_f64 %4, %4, %22\n\t"
+        "v_add_f64 %5, %5, %23\n\t"
+        "v_add_f64 %6, %6, %24\n\t"
+        "v_add_f64 %7, %7, %25\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]),
+          "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "s"(m.x), "s"(m.y), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]),
+          "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]), "s"(t[8]), "s"(t[9]),
+          "s"(t[10]), "s"(t[11]), "s"(t[12]), "s"(t[13]), "s"(t[14]),
+          "s"(t[15]));
+}
+
+// 8 clusters x CB slot blocks per wave, two ping-pong stages of one mutation
+// each (no stage copies), hand-placed inner block.  With CB = 2 a wave owns
+// 128 cells: the 16 table doubles of a mutation are loaded once and feed 32
+// masked adds, halving the scalar-pipe and scalar-cache work per add.
+// Same sums, same order, same bits as k_ll<8>.
+template <int CB>
+__global__ __launch_bounds__(256) void k_ll8_asm(
+    const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
+    long long nblk, const double *__restrict__ T, int K, long long ldo,
+    double *__restrict__ out, int xcd_remap)
+{
+    constexpr int KW = 8;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    long long bx, g;
+    ll_tile_coords((unsigned)((nblk + 4 * CB - 1) / (4 * CB)),
+                   (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
+    const long long blk0 = (bx * 4 + wave) * CB;
+    if (blk0 >= nblk) return;
+
+    // mask rows of the wave's CB blocks, as offsets from the one `masks` base
+    // (a block past the end re-reads the wave's first block, never stored)
+    size_t mo[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+        mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad;
+    const double *__restrict__ tp = T + (size_t)g * Mt * (2 * KW);
+
+    double acc[CB][KW];
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+#pragma unroll
+        for (int j = 0; j < KW; j++) acc[c][j] = 0.0;
+
+    ulonglong2 ma[CB], mb[CB];
+    double ta[16], tb[16];
+#pragma unroll
+    for (int c = 0; c < CB; c++) ma[c] = masks[mo[c]];
+#pragma unroll
+    for (int j = 0; j < 16; j++) ta[j] = tp[j];
+
+    // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait
+    // for the current stage FIRST, then issue the next stage's loads, then
+    // the masked adds run under those loads.
+    for (int m = 0; m < Mt; m += 2) {           // Mt is a multiple of 8
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // stage A landed
+#pragma unroll
+        for (int c = 0; c < CB; c++) mb[c] = masks[mo[c] + m + 1];
+#pragma unroll
+        for (int j = 0; j < 16; j++) tb[j] = tp[16 + j];
+#pragma unroll
+        for (int c = 0; c < CB; c++) ll_step8(acc[c], ma[c], ta);
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // stage B landed
+#pragma unroll
+        for (int c = 0; c < CB; c++) ma[c] = masks[mo[c] + m + 2];
+#pragma unroll
+        for (int j = 0; j < 16; j++) ta[j] = tp[32 + j];
+#pragma unroll
+        for (int c = 0; c < CB; c++) ll_step8(acc[c], mb[c], tb);
+        tp += 32;
+    }
+
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+        const long long slot = (blk0 + c) * 64 + lane;
+        if (blk0 + c < nblk && slot < n) {
+            double *o = out + (size_t)slot * ldo + (size_t)g * KW;
+#pragma unroll
+            for (int j = 0; j < KW; j++)
+                if (g * KW + j < K) o[j] = acc[c][j];
+        }
     }
 }
 
@@ -449,7 +588,7 @@ static int create_impl(int device, int64_t N, int64_t M, GetCode code,
     c->M = M;
     c->W = (int)((M + 63) / 64);
     c->Mpad = c->W * 64;
-    c->Mt = (int)((M + 3) / 4 * 4);
+    c->Mt = (int)((M + 7) / 8 * 8);
 
     // pack on the host: 2 bits per entry
     std::vector<ulonglong2> rows((size_t)N * c->W);
@@ -608,6 +747,45 @@ static int pick_kw(int64_t nblk, int64_t K)
     return K >= 2 ? (K >= 16 ? 2 : 1) : 1;
 }
 
+static int env_flag(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// the cells x clusters x mutations launch itself (tables are resident)
+template <int KW>
+static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
+                    double *d_out)
+{
+    const int64_t G = (K + KW - 1) / KW;
+    const int64_t nwg = ((v.nblk + 3) / 4) * G;
+    ARGCHK(nwg < (1ll << 31), "launch too large");
+    const int xcd = env_flag("BNPC_XCD_REMAP", 1);
+    const int impl = env_flag("BNPC_LL_ASM", 2);    // 0 C++, 1 asm, 2 asm x2
+    if (KW == 8 && impl == 2 && ((v.nblk + 7) / 8) * G >= 2048)
+        hipLaunchKernelGGL(k_ll8_asm<2>,
+                           dim3((unsigned)(((v.nblk + 7) / 8) * G)), dim3(256),
+                           0, c->stream, (const ulonglong2 *)v.masks.p,
+                           c->Mpad, c->Mt, (long long)v.n, (long long)v.nblk,
+                           (const double *)c->tabs.p, (int)K, (long long)ldo,
+                           d_out, xcd);
+    else if (KW == 8 && impl >= 1)
+        hipLaunchKernelGGL(k_ll8_asm<1>, dim3((unsigned)nwg), dim3(256), 0,
+                           c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
+                           c->Mt, (long long)v.n, (long long)v.nblk,
+                           (const double *)c->tabs.p, (int)K, (long long)ldo,
+                           d_out, xcd);
+    else
+        hipLaunchKernelGGL(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
+                           c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
+                           c->Mt, (long long)v.n, (long long)v.nblk,
+                           (const double *)c->tabs.p, (int)K, (long long)ldo,
+                           d_out, xcd);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 template <int KW>
 static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                      bool from_theta, double FP, double FN, double *d_out)
@@ -628,13 +806,7 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                            (const double *)c->tab_in.p + (size_t)K * c->M,
                            (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
     HIPCHK(hipGetLastError());
-    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)G);
-    hipLaunchKernelGGL(k_ll<KW>, grid, dim3(256), 0, c->stream,
-                       (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,
-                       (long long)v.n, (long long)v.nblk,
-                       (const double *)c->tabs.p, (int)K, (long long)ldo,
-                       d_out);
-    HIPCHK(hipGetLastError());
+    if (issue_ll<KW>(c, v, K, ldo, d_out)) return 1;
     return 0;
 }
 
@@ -862,18 +1034,6 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
     return 0;
 }
 
-template <int KW>
-static void relaunch_ll(bnpc_ctx *c, const View &v)
-{
-    const int64_t G = (c->last_K + KW - 1) / KW;
-    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)G);
-    hipLaunchKernelGGL(k_ll<KW>, grid, dim3(256), 0, c->stream,
-                       (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,
-                       (long long)v.n, (long long)v.nblk,
-                       (const double *)c->tabs.p, (int)c->last_K,
-                       (long long)c->last_ldo, (double *)c->out.p);
-}
-
 extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
 {
     ARGCHK(c && ms_per_launch, "NULL argument");
@@ -883,14 +1043,16 @@ extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
     const View &v = c->views[c->last_view];
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; r++) {
+        int rc;
+        double *o = (double *)c->out.p;
         switch (c->last_kw) {
-        case 8: relaunch_ll<8>(c, v); break;
-        case 4: relaunch_ll<4>(c, v); break;
-        case 2: relaunch_ll<2>(c, v); break;
-        default: relaunch_ll<1>(c, v); break;
+        case 8: rc = issue_ll<8>(c, v, c->last_K, c->last_ldo, o); break;
+        case 4: rc = issue_ll<4>(c, v, c->last_K, c->last_ldo, o); break;
+        case 2: rc = issue_ll<2>(c, v, c->last_K, c->last_ldo, o); break;
+        default: rc = issue_ll<1>(c, v, c->last_K, c->last_ldo, o); break;
         }
+        if (rc) return rc;
     }
-    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0.f;
