@@ -87,6 +87,77 @@ def step(chain, i, burn_in):
     chain.update_results(i, i < burn_in)
 
 
+class Ranks:
+    """One process per GPU (torch.distributed.run contract).  No collective
+    in the data path: gloo carries the barrier and the max of the timings."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.dist = None
+        self.torch = None
+
+    def init(self):
+        import torch
+        self.torch = torch
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29577')
+            dist.init_process_group('gloo', rank=self.rank,
+                world_size=self.world)
+            self.dist = dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
+        return self
+
+    def barrier_sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.torch is not None and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(ranks, step_fn, first, last):
+    """Time steps first..last inclusive: barrier + device sync on both sides,
+    MAX over ranks."""
+    ranks.barrier_sync()
+    t0 = time.perf_counter()
+    for i in range(first, last + 1):
+        step_fn(i)
+    ranks.barrier_sync()
+    return ranks.max_over_ranks(time.perf_counter() - t0)
+
+
+def load_pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or
+    None.  The counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_v2_asm2.json')
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        for name, ctr in pmc.items():
+            if kernel_substr in name:
+                kib = ctr['FETCH_SIZE']['mean'] + ctr['WRITE_SIZE']['mean']
+                return int(kib * 1024), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,25 +170,9 @@ def main():
     ap.add_argument('--kernel-reps', type=int, default=5)
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    os.environ['BNPC_DEVICE'] = str(local_rank)
-
-    import torch
-    import torch.distributed as dist
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-
-    def barrier_sync():
-        if distributed:
-            dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+    ranks = Ranks().init()
+    rank, world = ranks.rank, ranks.world
+    os.environ['BNPC_DEVICE'] = str(ranks.local_rank)
 
     from bnpc_amd import _lib
     import libs.CRP as dev_fixed
@@ -157,16 +212,8 @@ def main():
             rng=np.random.get_state())
 
     # ---- timed region: exactly K steps -----------------------------------
-    barrier_sync()
-    t0 = time.perf_counter()
-    for i in range(args.warmup + 1, total + 1):
-        step(chain, i, burn)
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = timed_steps(ranks, lambda i: step(chain, i, burn),
+        args.warmup + 1, total)
     K_end = len(model.cells_per_cluster)
     ml_end = float(chain.results['ML'][total])
 
@@ -190,10 +237,12 @@ def main():
         ms, alg_bytes = time_ll(K0)
         gbs = alg_bytes / (ms * 1e-3) / 1e9
         evals = N * K0 / (ms * 1e-3)
+        traffic, traffic_src = load_pmc_traffic('k_ll8_asm<2>')
         roofline = {
-            'kernel': 'k_ll', 'bound': 'hbm',
+            'kernel': 'k_ll8_asm<2>', 'bound': 'hbm',
             'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': None,
+            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'traffic_source': traffic_src,
             'shape': {'N': N, 'M': M, 'K': K0},
             'launch_ms': round(ms, 4),
             'algorithmic_bytes': int(alg_bytes),
@@ -274,8 +323,7 @@ def main():
         if cpu:
             line['speedup_vs_cpu_baseline'] = round(value / cpu['value'], 2)
         print(json.dumps(line))
-    if distributed:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,84 @@
+"""N > 1 paths on CPU: (a) the fork pool of the driver (one chain per worker,
+worker i -> GPU i), (b) bench.py's rank harness under gloo, world_size 2."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from bnpc_amd import _lib, model as P
+from bnpc_amd.mcmc import MCMC, Chain_steps
+from fake_device import FakeContext
+import test_host_logic as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pool_chains_equal_in_process_chains(monkeypatch):
+    monkeypatch.setattr(_lib, 'Context', FakeContext)   # inherited by fork
+    monkeypatch.delenv('BNPC_DEVICE', raising=False)
+    monkeypatch.setenv('BNPC_NUM_DEVICES', '2')
+    data = H.synth(7, 50, 30, 3, 0.1)
+    model = H.make(P, 'learn', data)
+    mcmc = MCMC(model, sm_prob=.33, dpa_prob=.25, error_prob=.25,
+        sm_ratios=[.75, .25], sm_steps=2)
+    mcmc.run((20, 6), 42, 3, 0, '', False)
+    res = mcmc.get_results()
+    assert len(res) == 3 and len(mcmc.get_seeds()) == 3
+    # each pooled chain equals the same chain run alone in this process
+    for i, seed in enumerate(mcmc.get_seeds()):
+        np.random.seed(seed)
+        solo = H.make(P, 'learn', data)
+        solo.init()
+        chain = Chain_steps(solo, i + 1, 20, 6, mcmc.params, 0, False)
+        chain.run()
+        assert np.array_equal(chain.results['assignments'],
+            res[i]['assignments'])
+        np.testing.assert_allclose(chain.results['ML'], res[i]['ML'],
+            rtol=1e-12)
+    # chains differ from each other (different seeds)
+    assert not np.array_equal(res[0]['assignments'], res[1]['assignments'])
+
+
+def test_worker_exception_is_reported(monkeypatch):
+    class Broken(FakeContext):
+        def ll_theta(self, *a, **k):
+            raise RuntimeError('device lost')
+    monkeypatch.setattr(_lib, 'Context', Broken)
+    data = H.synth(7, 30, 20, 2, 0.1)
+    mcmc = MCMC(H.make(P, 'fixed', data), sm_prob=0., dpa_prob=0.,
+        error_prob=0., sm_ratios=[.75, .25], sm_steps=2)
+    with pytest.raises(RuntimeError, match='chain worker failed'):
+        mcmc.run((12, 3), 1, 2, 0, '', False)
+
+
+def _rank_main(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank),
+        WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+        MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import bench
+    ranks = bench.Ranks().init()
+    delay = 0.01 * (rank + 1)           # rank 1 is the slow one
+    el = bench.timed_steps(ranks, lambda i: time.sleep(delay), 1, 5)
+    out.put((rank, el))
+    ranks.close()
+
+
+def test_bench_rank_harness_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 400
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out))
+        for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # both ranks report the MAX over ranks: the slow rank's 5 x 20 ms
+    assert abs(got[0] - got[1]) < 1e-9
+    assert 0.09 < got[0] < 0.5
