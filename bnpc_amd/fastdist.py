@@ -1,0 +1,128 @@
+"""Wrapper-free calls into SciPy's truncated-normal and Beta distributions.
+
+The MH proposal of the reference (libs/CRP.py:328-357, 371-376) calls
+``truncnorm.rvs``, ``truncnorm.logpdf`` (x2) and ``beta.logpdf`` (x2) once per
+cluster per step.  On M ~ 1000 elements most of their time is SciPy's generic
+argument machinery (broadcasting, argsreduce, place), not arithmetic.  The
+functions below evaluate the SAME SciPy kernels (``truncnorm._ppf``,
+``truncnorm._logpdf``, ``beta._logpdf``) directly, with the public wrappers'
+standardisation and support handling restated, so the values are bit-identical
+to the public API - which `selfcheck()` verifies once per process on vectors
+that cover the left / right / central branches; if anything differs (another
+SciPy version) the public API is used instead.  Arrays of any shape are
+accepted, which lets the caller evaluate all clusters of a step at once.
+"""
+import numpy as np
+from scipy.stats import beta as _beta, truncnorm as _truncnorm
+
+_state = {'checked': False, 'fast': False}
+
+
+# -- direct forms ------------------------------------------------------------
+def _tn_ppf_direct(q, a, b, loc, scale):
+    return _truncnorm._ppf(q, a, b) * scale + loc
+
+
+def _tn_logpdf_direct(x, a, b, loc, scale):
+    xs = np.asarray((x - loc) / scale, dtype=np.float64)
+    out = _truncnorm._logpdf(xs, a, b) - np.log(scale)
+    outside = ~((a <= xs) & (xs <= b))
+    if outside.any():
+        out = np.array(out, dtype=np.float64)
+        out[outside] = -np.inf
+    return out
+
+
+def _beta_logpdf_direct(x, p, q):
+    xs = np.asarray(x, dtype=np.float64)
+    out = _beta._logpdf(xs, p, q)
+    outside = ~((0 < xs) & (xs < 1))
+    if outside.any():
+        out = np.array(out, dtype=np.float64)
+        out[outside] = -np.inf
+    return out
+
+
+# -- public forms ------------------------------------------------------------
+def _tn_ppf_public(q, a, b, loc, scale):
+    return _truncnorm.ppf(q, a, b, loc=loc, scale=scale)
+
+
+def _tn_logpdf_public(x, a, b, loc, scale):
+    return _truncnorm.logpdf(x, a, b, loc=loc, scale=scale)
+
+
+def _beta_logpdf_public(x, p, q):
+    return _beta.logpdf(x, p, q)
+
+
+def selfcheck():
+    """Bit-compare the direct forms with SciPy's public API."""
+    if _state['checked']:
+        return _state['fast']
+    _state['checked'] = True
+    try:
+        rng = np.random.RandomState(12345)
+        M = 257
+        old = np.clip(rng.uniform(size=M), 1e-5, 1 - 1e-5).astype(np.float32)
+        old[:8] = np.float32(1e-5)          # a == 0: right branch of ppf
+        old[8:16] = np.float32(1 - 1e-5)    # b == 0: left branch of the mass
+        old[16:24] = np.float32(0.5)
+        std = rng.choice(np.array([0.1, 0.25, 0.5]), size=M)
+        a = (1e-5 - old) / std
+        b = ((1 - 1e-5) - old) / std
+        U = rng.uniform(size=M)
+        state = np.random.get_state()
+        np.random.seed(99)
+        ref_rvs = _truncnorm.rvs(a, b, loc=old, scale=std, size=M)
+        np.random.seed(99)
+        got_rvs = _tn_ppf_direct(np.random.uniform(size=M), a, b, old, std)
+        np.random.set_state(state)
+        ok = np.array_equal(ref_rvs, got_rvs)
+        new = got_rvs.astype(np.float32)
+        new[30:34] = np.float32(0.0)        # outside the support -> -inf
+        for x, lo, sc_ in ((new, old, std), (old, new, std)):
+            aa = (1e-5 - lo) / sc_
+            bb = ((1 - 1e-5) - lo) / sc_
+            with np.errstate(all='ignore'):
+                ok &= np.array_equal(_tn_logpdf_public(x, aa, bb, lo, sc_),
+                    _tn_logpdf_direct(x, aa, bb, lo, sc_))
+        a0 = (0 - old) / std
+        b0 = (1 - old) / std
+        ok &= np.array_equal(_tn_logpdf_public(new, a0, b0, old, std),
+            _tn_logpdf_direct(new, a0, b0, old, std))
+        ok &= np.array_equal(_tn_ppf_public(U, a, b, old, std),
+            _tn_ppf_direct(U, a, b, old, std))
+        xs = new.copy()
+        xs[30:34] = np.float32(0.3)
+        for p, q in ((.25, .25), (.75, 2.0), (3.0, .5)):
+            ok &= np.array_equal(_beta_logpdf_public(xs, p, q),
+                _beta_logpdf_direct(xs, p, q))
+            ok &= np.array_equal(
+                _beta_logpdf_public(xs.reshape(1, -1), p, q),
+                _beta_logpdf_direct(xs.reshape(1, -1), p, q))
+        _state['fast'] = bool(ok)
+    except Exception:
+        _state['fast'] = False
+    return _state['fast']
+
+
+def tn_rvs_from_uniform(U, a, b, loc, scale):
+    """truncnorm.rvs(a, b, loc, scale, size) given its uniforms U
+    (= random_state.uniform(size=size), scipy/stats/_distn_infrastructure.py
+    rv_continuous._rvs): ppf(U) * scale + loc."""
+    if selfcheck():
+        return _tn_ppf_direct(U, a, b, loc, scale)
+    return _truncnorm._ppf(U, a, b) * scale + loc
+
+
+def tn_logpdf(x, a, b, loc, scale):
+    if selfcheck():
+        return _tn_logpdf_direct(x, a, b, loc, scale)
+    return _tn_logpdf_public(x, a, b, loc, scale)
+
+
+def beta_logpdf(x, p, q):
+    if selfcheck():
+        return _beta_logpdf_direct(x, p, q)
+    return _beta_logpdf_public(x, p, q)

@@ -35,7 +35,7 @@ from scipy.special import gamma as _gamma_fn, gammaln
 from scipy.stats import beta as _beta_dist, truncnorm
 from scipy.stats import gamma as _gamma_dist
 
-from bnpc_amd import _lib
+from bnpc_amd import _lib, fastdist
 
 # the reference traps these and uses FloatingPointError as control flow
 # (libs/CRP.py:10)
@@ -325,8 +325,8 @@ class CRP:
             + np.cumsum(self.CRP_prior[sizes])[-1]
         if not self.beta_prior_uniform:
             ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
-            lprior += np.cumsum(
-                self.param_prior.logpdf(self.parameters[ids]).ravel())[-1]
+            lprior += np.cumsum(fastdist.beta_logpdf(
+                self.parameters[ids], self.p, self.q).ravel())[-1]
         return lprior
 
     # ---------------------------------------------------------------- Gibbs
@@ -420,49 +420,67 @@ class CRP:
     # ------------------------------------------------- cluster parameters
     def update_parameters(self, step_no=None):
         """libs/CRP.py:302-311; the per-cluster sums over cells come from one
-        column-count launch that is reused by get_ll_full / the error update."""
+        column-count launch that is reused by get_ll_full / the error update,
+        and the K proposals are evaluated as one (K, M) array expression (the
+        draws stay in the reference's per-cluster order)."""
         lab = self._label_counts()
-        declined = np.zeros(len(self.cells_per_cluster), dtype=int)
-        for n, cl in enumerate(self.cells_per_cluster):
-            self.parameters[cl], _, declined[n] = self.MH_cluster_params(
-                self.parameters[cl], None,
-                counts=(lab['n1'][n], lab['n0'][n]))
+        ids = lab['ids']
+        new, _, declined = self._mh_batch(self.parameters[ids],
+            (lab['n1'], lab['n0']), False)
+        self.parameters[ids] = new
         return declined.sum(), (self.muts_total - declined).sum()
+
+    def _mh_batch(self, old, counts, trans_prob):
+        """MH_cluster_params (libs/CRP.py:314-344) for G clusters at once.
+
+        old: (G, M) float32; counts: (n1, n0) each (G, M).  RNG order per
+        cluster, as in the reference: choice(sd, M) -> truncnorm.rvs (its M
+        uniforms) -> random(M); the arithmetic in between does not draw, so
+        it is hoisted out of the loop and batched."""
+        G, M = old.shape
+        std = np.empty((G, M))
+        U = np.empty((G, M))
+        lu = np.empty((G, M))
+        for g in range(G):
+            std[g] = np.random.choice(self.param_proposal_sd, size=M)
+            U[g] = np.random.uniform(size=M)
+            lu[g] = np.random.random(M)
+        a = (TMIN - old) / std
+        b = (TMAX - old) / std
+        new = fastdist.tn_rvs_from_uniform(U, a, b, old, std) \
+            .astype(np.float32)
+
+        A = self._get_log_A(new, old, None, a, b, std, trans_prob,
+            counts=counts)
+        decline = np.log(lu) >= A
+        new[decline] = old[decline]
+        if trans_prob:
+            A[decline] = np.log(-1 * np.expm1(A[decline]))
+            prob = np.cumsum(A, axis=1)[:, -1]
+        else:
+            prob = np.full(G, np.nan)
+        return new, prob, decline.sum(axis=1)
 
     def MH_cluster_params(self, old_params, cells, trans_prob=False,
                 counts=None):
         """libs/CRP.py:314-344 (draw order: choice(sd) -> truncnorm.rvs ->
         random(M))."""
-        M = self.muts_total
         if counts is None:
             counts = self._counts_of(cells)
-        std = np.random.choice(self.param_proposal_sd, size=M)
-        a = (TMIN - old_params) / std
-        b = (TMAX - old_params) / std
-        new_params = truncnorm.rvs(
-            a, b, loc=old_params, scale=std, size=M).astype(np.float32)
-
-        A = self._get_log_A(new_params, old_params, cells, a, b, std,
-            trans_prob, counts=counts)
-        u = np.log(np.random.random(M))
-        decline = u >= A
-        new_params[decline] = old_params[decline]
-
-        if trans_prob:
-            A[decline] = np.log(-1 * np.expm1(A[decline]))
-            return new_params, np.cumsum(A)[-1], decline.sum()
-        return new_params, np.nan, decline.sum()
+        new, prob, declined = self._mh_batch(
+            np.asarray(old_params)[None, :],
+            (counts[0][None, :], counts[1][None, :]), trans_prob)
+        return new[0], prob[0], declined[0]
 
     def _get_log_A(self, new_params, old_params, cells, a, b, std, clip=False,
                 counts=None):
-        """libs/CRP.py:347-383"""
+        """libs/CRP.py:347-383 (any leading batch dimension)"""
         if counts is None:
             counts = self._counts_of(cells)
-        fwd = truncnorm.logpdf(new_params, a, b, loc=old_params, scale=std)
+        fwd = fastdist.tn_logpdf(new_params, a, b, old_params, std)
         a_rev = (TMIN - new_params) / std
         b_rev = (TMAX - new_params) / std
-        rev = truncnorm.logpdf(old_params, a_rev, b_rev, loc=new_params,
-            scale=std)
+        rev = fastdist.tn_logpdf(old_params, a_rev, b_rev, new_params, std)
 
         new_ll = self._subset_ll(new_params, counts)
         old_ll = self._subset_ll(old_params, counts)
@@ -470,8 +488,8 @@ class CRP:
         if self.beta_prior_uniform:
             new_prior = old_prior = 0
         else:
-            new_prior = self.param_prior.logpdf(new_params)
-            old_prior = self.param_prior.logpdf(old_params)
+            new_prior = fastdist.beta_logpdf(new_params, self.p, self.q)
+            old_prior = fastdist.beta_logpdf(old_params, self.p, self.q)
 
         A = new_ll + new_prior - old_ll - old_prior + rev - fwd
         if clip:
@@ -653,12 +671,11 @@ class CRP:
             return prob
 
     def _rg_scan_params(self, cells, trans_prob=False):
-        """libs/CRP.py:590-606"""
-        cnt = self._rg_split_counts(cells)
-        prob = np.zeros(2)
-        for cl in range(2):
-            self.rg_params_split[cl], prob[cl], _ = self.MH_cluster_params(
-                self.rg_params_split[cl], None, trans_prob, counts=cnt[cl])
+        """libs/CRP.py:590-606 (both launch clusters in one batch)"""
+        ci, cj = self._rg_split_counts(cells)
+        counts = (np.stack([ci[0], cj[0]]), np.stack([ci[1], cj[1]]))
+        self.rg_params_split, prob, _ = self._mh_batch(
+            self.rg_params_split, counts, trans_prob)
         if trans_prob:
             return prob.sum()
 
@@ -755,9 +772,10 @@ class CRP:
             ratio += gammaln(n_i)
         if not self.beta_prior_uniform:
             cl = self.assignment[cells[0]]
-            ratio += np.cumsum(self.param_prior.logpdf(
-                    self.rg_params_split).ravel())[-1] \
-                - np.cumsum(self.param_prior.logpdf(self.parameters[cl]))[-1]
+            ratio += np.cumsum(fastdist.beta_logpdf(
+                    self.rg_params_split, self.p, self.q).ravel())[-1] \
+                - np.cumsum(fastdist.beta_logpdf(
+                    self.parameters[cl], self.p, self.q))[-1]
         return ratio
 
     def _get_ll_ratio(self, cells, move):
@@ -782,10 +800,10 @@ class CRP:
             ratio -= gammaln(n_j)
         if not self.beta_prior_uniform:
             cls = self.assignment[[cells[0], cells[-1]]]
-            ratio += np.cumsum(
-                    self.param_prior.logpdf(self.rg_params_merge))[-1] \
-                - np.cumsum(self.param_prior.logpdf(
-                    self.parameters[cls]).ravel())[-1]
+            ratio += np.cumsum(fastdist.beta_logpdf(
+                    self.rg_params_merge, self.p, self.q))[-1] \
+                - np.cumsum(fastdist.beta_logpdf(
+                    self.parameters[cls], self.p, self.q).ravel())[-1]
         return ratio
 
     def _get_ltrans_prob_size_ratio_split(self, ltrans_prob_size, cluster_size):
