@@ -387,3 +387,41 @@ def test_full_size_properties_5000x1000():
     assert np.array_equal(a1[0] + a0[0] + np.isnan(data).sum(axis=0),
         np.full(M, N))
     ctx.close()
+
+
+# ------------------------------------------------------------------- the CLI
+def test_cli_end_to_end_in_process(golden_dir, tmp_path):
+    """`run_BnpC.py example_data/data.csv -FP .001 -FN .1 -s 200 --seed 42`
+    (chain in the main process): the reference's trajectory, its outputs."""
+    import run_BnpC
+    t = np.load(os.path.join(golden_dir, 'trajectories.npz'))
+    args = run_BnpC.parse_args([os.path.join(golden_dir, 'example_data.csv'),
+        '-FP', '0.001', '-FN', '0.1', '-n', '1', '-s', '200', '--seed', '42',
+        '-np', '-e', 'ML', 'MAP', '-o', str(tmp_path), '-v', '0', '--debug'])
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        results = run_BnpC.main(args)
+    assert np.array_equal(results[0]['assignments'], t['ex_fixed_assignments'])
+    for name in ('assignment.txt', 'errors.txt', 'args.txt'):
+        assert os.path.getsize(os.path.join(str(tmp_path), name)) > 0
+    from bnpc_amd.io import load_txt
+    assign = load_txt(os.path.join(str(tmp_path), 'assignment.txt'))
+    assert len(assign) == 100 and len(set(assign)) == 5
+
+
+def test_cli_two_chains_in_pool_workers(golden_dir, tmp_path):
+    """-n 2: each chain in its own forked worker with its own device context
+    (the parent never touches the GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'run_BnpC.py'),
+        os.path.join(golden_dir, 'example_data.csv'), '-n', '2', '-s', '40',
+        '--seed', '7', '-np', '-e', 'MAP', '-sc', '-o', str(tmp_path)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+        cwd=root)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'secs. per MCMC step' in res.stdout
+    with open(os.path.join(str(tmp_path), 'assignment.txt')) as f:
+        assert len(f.read().strip().splitlines()) == 3
