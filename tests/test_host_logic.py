@@ -259,3 +259,64 @@ def test_module_path_of_the_drop_in_classes():
     assert libs.CRP_learning_errors.CRP_errors_learning.__module__ == \
         'libs.CRP_learning_errors'
     assert issubclass(libs.CRP_learning_errors.CRP_errors_learning, P.CRP)
+
+
+def test_gibbs_opens_many_clusters_in_one_sweep():
+    """> 16 new clusters in one sweep: the ll matrix and the column tables
+    grow mid-sweep; ids of clusters that died earlier in the sweep are
+    re-used (libs/CRP.py:297-299)."""
+    rng = np.random.RandomState(3)
+    profiles = (rng.random_sample((40, 60)) < 0.5).astype(float)
+    data = np.repeat(profiles, 3, axis=0)
+    data[rng.random_sample(data.shape) < 0.05] = np.nan
+    models = []
+    for mod in (O, P):
+        m = mod.CRP(data, DP_alpha=[200, 1], param_beta=[.25, .25],
+            FN_error=0.01, FP_error=0.01)
+        np.random.seed(4)
+        m.init(mode='together')
+        k_before = len(m.cells_per_cluster)
+        np.random.seed(5)
+        m.update_assignments_Gibbs()
+        m._tail = np.random.random(2)
+        models.append(m)
+    o, p = models
+    assert k_before == 1 and len(o.cells_per_cluster) > 20
+    assert np.array_equal(o.assignment, p.assignment)
+    assert list(o.cells_per_cluster.items()) == \
+        list(p.cells_per_cluster.items())
+    assert np.array_equal(o._tail, p._tail)
+    ids = list(o.cells_per_cluster)
+    assert np.array_equal(o.parameters[ids], p.parameters[ids])
+    # a second sweep from the fragmented state (clusters die and ids recycle)
+    for m in (o, p):
+        np.random.seed(6)
+        m.update_assignments_Gibbs()
+    assert np.array_equal(o.assignment, p.assignment)
+    assert list(o.cells_per_cluster.items()) == \
+        list(p.cells_per_cluster.items())
+
+
+def test_native_sweep_rejects_corrupt_state():
+    lib = _lib.load()
+    N, ld = 4, 3
+    st = _lib.GibbsState(N, ld, 1, 1, 0, -1)
+    rng, _ = _lib.rng_export()
+    i64, f64 = C.c_int64, C.c_double
+    perm = np.arange(N, dtype=np.int64)
+    ll = np.zeros((N, ld))
+    post_new = np.zeros(N)
+    prior = np.zeros(N + 2)
+    assignment = np.full(N, 2, dtype=np.int64)      # id 2 has no column
+    col_of_id = np.full(N, -1, dtype=np.int64)
+    col_of_id[0] = 0
+    col_id = np.zeros(ld, dtype=np.int64)
+    col_size = np.array([4, 0, 0], dtype=np.int64)
+    order = np.zeros(ld, dtype=np.int64)
+    scratch = np.zeros(2 * (ld + 1))
+    rc = lib.bnpc_gibbs_sweep(C.byref(st), C.byref(rng), _lib.ptr(perm, i64),
+        _lib.ptr(ll, f64), _lib.ptr(post_new, f64), _lib.ptr(prior, f64),
+        _lib.ptr(assignment, i64), _lib.ptr(col_of_id, i64),
+        _lib.ptr(col_id, i64), _lib.ptr(col_size, i64), _lib.ptr(order, i64),
+        _lib.ptr(scratch, f64))
+    assert rc != 0 and b'unknown cluster' in lib.bnpc_last_error()
