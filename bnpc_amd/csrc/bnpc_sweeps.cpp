@@ -113,6 +113,7 @@ extern "C" int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out)
 // Gibbs sweep
 // ---------------------------------------------------------------------------
 static const double LOG_EPS = -34.538776394910684;   // np.log(1e-15)
+static const double EXP_LOG_EPS = exp(LOG_EPS);       // the probability floor
 
 extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                                 const int64_t *perm, const double *ll,
@@ -172,19 +173,26 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         post[A] = post_new[cell];
         if (post[A] > post[top]) top = A;
 
-        // _normalize_log_probs (CRP.py:88-100)
+        // _normalize_log_probs (CRP.py:88-100).  exp() is skipped where its
+        // result is known exactly: exp(d) == 0.0 for d < -746 (below the
+        // smallest subnormal), and every entry clipped at log(1e-15)
+        // contributes the same constant exp(LOG_EPS) - so a sweep over
+        // thousands of far-away clusters costs two flops per entry, with
+        // the same sums as evaluating every exponential.
         const double ptop = post[top];
         double tail = 0.0;
-        for (int64_t a = 0; a <= A; a++)
-            if (a != top) tail += exp(post[a] - ptop);
+        for (int64_t a = 0; a <= A; a++) {
+            if (a == top) continue;
+            const double d = post[a] - ptop;
+            if (d > -746.0) tail += exp(d);
+        }
         const double lnorm = log1p(tail);
         // choice(p=): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, right)
         double run = 0.0;
         for (int64_t a = 0; a <= A; a++) {
-            double v = post[a] - ptop - lnorm;
-            if (v < LOG_EPS) v = LOG_EPS;
-            if (v > 0.0) v = 0.0;
-            run += exp(v);
+            const double v = post[a] - ptop - lnorm;
+            if (v <= LOG_EPS) run += EXP_LOG_EPS;
+            else run += exp(v > 0.0 ? 0.0 : v);
             cdf[a] = run;
         }
         const double total = cdf[A];

@@ -337,6 +337,10 @@ class CRP:
         lib = _lib.load()
         ctx = self._dev()
         N = self.cells_total
+        timing = os.environ.get('BNPC_TIMING')
+        if timing:
+            import time
+            t_start = time.perf_counter()
         post_new = np.ascontiguousarray(self.get_lpost_single_new_cluster())
         perm = _lib.as_i64(np.random.permutation(N))
 
@@ -346,6 +350,8 @@ class CRP:
         ld = K + 16
         ll = np.empty((N, ld), dtype=np.float64)
         ctx.ll_theta(VIEW_ALL, self.parameters[ids], self.FP, self.FN, out=ll)
+        if timing:
+            t_ll = time.perf_counter()
 
         assignment = _lib.as_i64(self.assignment)
         col_of_id = np.full(N, -1, dtype=np.int64)
@@ -398,6 +404,11 @@ class CRP:
             st.n_cols += 1
             assignment[cell] = new_id
         _lib.rng_import(rng, extra)
+        if timing:
+            t_end = time.perf_counter()
+            print(f'[bnpc] gibbs N={N} K={K}->{st.n_active}: ll matrix+D2H '
+                f'{t_ll - t_start:.3f}s, sweep {t_end - t_ll:.3f}s '
+                f'({st.n_cols - K} clusters opened)', flush=True)
 
         self.assignment = assignment
         live = order[:st.n_active]
