@@ -95,7 +95,7 @@ struct bnpc_ctx {
     std::vector<int32_t> cell_n1, cell_n0;
     View views[BNPC_MAX_VIEWS];
     // scratch
-    DevBuf theta, tabs, tab_in, out, cells, chunks, cnt, partial;
+    DevBuf theta, tabs, tab_in, out, cells, chunks, cnt, partial, part;
     // resident per-cluster counts of the last bnpc_colcounts_by_label
     DevBuf lab_cnt;
     int64_t lab_K = 0;
@@ -103,7 +103,7 @@ struct bnpc_ctx {
     void *pin = nullptr;
     size_t pin_cap = 0;
     // configuration of the last k_ll launch (bnpc_bench_ll re-issues it)
-    int last_kw = 0, last_view = -1;
+    int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
 };
 
@@ -266,23 +266,33 @@ __device__ __forceinline__ void ll_tile_coords(unsigned nbx, unsigned G,
     bx = v - gg * nbx;
 }
 
+// MS > 1 splits the mutations of a (slot block, cluster group) over MS waves
+// (small launches are otherwise one long dependent chain of scalar loads per
+// wave): wave ms sums mutations [ms*m_chunk, (ms+1)*m_chunk) into
+// part[ms][slot][k]; k_ll_combine adds the MS partial sums in index order.
 template <int KW>
 __global__ __launch_bounds__(256) void k_ll(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
-    double *__restrict__ out, int xcd_remap)
+    double *__restrict__ out, int xcd_remap, int MS, int m_chunk)
 {
     constexpr int U = LLStage<KW>::U;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     long long bx, g;
-    ll_tile_coords((unsigned)((nblk + 3) >> 2), (unsigned)((K + KW - 1) / KW),
-                   xcd_remap, bx, g);
+    ll_tile_coords((unsigned)((nblk + 3) >> 2) * (unsigned)MS,
+                   (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
+    const int ms = (int)(bx % MS);
+    bx /= MS;
     const long long blk = bx * 4 + wave;
     if (blk >= nblk) return;     // whole wave leaves together
+    const int m_begin = ms * m_chunk;
+    const int m_end = (m_begin + m_chunk < Mt) ? m_begin + m_chunk : Mt;
 
-    const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
-    const double *__restrict__ t = T + (size_t)g * Mt * (2 * KW);
+    const ulonglong2 *__restrict__ mk =
+        masks + (size_t)blk * Mpad + m_begin;
+    const double *__restrict__ t =
+        T + ((size_t)g * Mt + m_begin) * (2 * KW);
 
     double acc[KW];
 #pragma unroll
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void k_ll(
 #pragma unroll
         for (int j = 0; j < 2 * KW; j++) ct[u][j] = t[u * 2 * KW + j];
     }
-    const int nb = Mt / U;
+    const int nb = (m_end - m_begin) / U;
     for (int b = 0; b < nb; b++) {
         ulonglong2 nm[U];
         double nt[U][2 * KW];
@@ -329,11 +339,27 @@ __global__ __launch_bounds__(256) void k_ll(
 
     const long long slot = blk * 64 + lane;
     if (slot < n) {
-        double *o = out + (size_t)slot * ldo + (size_t)g * KW;
+        // partial sums: part[ms][slot][K]; final sums: out[slot][ldo]
+        double *o = (MS > 1)
+            ? out + ((size_t)ms * n + slot) * K + (size_t)g * KW
+            : out + (size_t)slot * ldo + (size_t)g * KW;
 #pragma unroll
         for (int j = 0; j < KW; j++)
             if (g * KW + j < K) o[j] = acc[j];
     }
+}
+
+__global__ __launch_bounds__(256) void k_ll_combine(
+    const double *__restrict__ part, long long n, int K, int MS,
+    long long ldo, double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * K) return;
+    const long long slot = i / K;
+    const int k = (int)(i - slot * K);
+    double s = part[i];
+    for (int ms = 1; ms < MS; ms++) s += part[(size_t)ms * n * K + i];
+    out[(size_t)slot * ldo + k] = s;
 }
 
 // One mutation for 8 clusters: EXEC <- lane mask of the cells that observed a
@@ -674,7 +700,8 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
-                      &c->chunks, &c->cnt, &c->partial, &c->lab_cnt};
+                      &c->chunks, &c->cnt, &c->partial, &c->part,
+                      &c->lab_cnt};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (View &v : c->views)
@@ -735,16 +762,41 @@ extern "C" int bnpc_view_size(const bnpc_ctx *c, int view, int64_t *n)
     return 0;
 }
 
-// choose clusters-per-wave so that the launch fills the chip
-static int pick_kw(int64_t nblk, int64_t K)
+// clusters per wave: least padded work, weighted by the scalar-pipe overhead
+// that a wider tile amortises
+static int pick_kw(int64_t K)
 {
-    const int64_t wgs = (nblk + 3) / 4;
     const int kws[] = {8, 4, 2, 1};
+    int best = 1;
+    double best_cost = 1e300;
     for (int kw : kws) {
-        if (kw > 1 && K < kw) continue;
-        if (wgs * ((K + kw - 1) / kw) >= 1024) return kw;
+        const double cost = (double)((K + kw - 1) / kw * kw) * (1.0 + 1.0 / kw);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = kw;
+        }
     }
-    return K >= 2 ? (K >= 16 ? 2 : 1) : 1;
+    return best;
+}
+
+// mutation split of a small launch: enough waves to fill the chip, chunks of
+// at least 16 mutations, a multiple of 8 (stage sizes divide 8)
+static void pick_msplit(int64_t waves, int Mt, bool allowed, int *MS,
+                        int *m_chunk)
+{
+    *MS = 1;
+    *m_chunk = Mt;
+    if (!allowed || waves >= 4096) return;
+    int64_t want = (4096 + waves - 1) / waves;
+    if (want > 64) want = 64;
+    int chunk = (int)((Mt + want - 1) / want);
+    chunk = (chunk + 7) / 8 * 8;
+    if (chunk < 16) chunk = 16;
+    const int ms = (Mt + chunk - 1) / chunk;
+    if (ms >= 2) {
+        *MS = ms;
+        *m_chunk = chunk;
+    }
 }
 
 static int env_flag(const char *name, int dflt)
@@ -756,39 +808,56 @@ static int env_flag(const char *name, int dflt)
 // the cells x clusters x mutations launch itself (tables are resident)
 template <int KW>
 static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
-                    double *d_out)
+                    double *d_out, int MS, int m_chunk)
 {
     const int64_t G = (K + KW - 1) / KW;
-    const int64_t nwg = ((v.nblk + 3) / 4) * G;
+    const int64_t nwg = ((v.nblk + 3) / 4) * G * MS;
     ARGCHK(nwg < (1ll << 31), "launch too large");
     const int xcd = env_flag("BNPC_XCD_REMAP", 1);
     const int impl = env_flag("BNPC_LL_ASM", 2);    // 0 C++, 1 asm, 2 asm x2
-    if (KW == 8 && impl == 2 && ((v.nblk + 7) / 8) * G >= 2048)
+    if (KW == 8 && MS == 1 && impl == 2 && ((v.nblk + 7) / 8) * G >= 2048)
         hipLaunchKernelGGL(k_ll8_asm<2>,
                            dim3((unsigned)(((v.nblk + 7) / 8) * G)), dim3(256),
                            0, c->stream, (const ulonglong2 *)v.masks.p,
                            c->Mpad, c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
                            d_out, xcd);
-    else if (KW == 8 && impl >= 1)
+    else if (KW == 8 && MS == 1 && impl >= 1)
         hipLaunchKernelGGL(k_ll8_asm<1>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
                            d_out, xcd);
-    else
+    else {
+        double *dst = d_out;
+        if (MS > 1) {
+            if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double)))
+                return 1;
+            dst = (double *)c->part.p;
+        }
         hipLaunchKernelGGL(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
-                           d_out, xcd);
+                           dst, xcd, MS, m_chunk);
+        if (MS > 1) {
+            HIPCHK(hipGetLastError());
+            const long long total = (long long)v.n * K;
+            hipLaunchKernelGGL(k_ll_combine,
+                               dim3((unsigned)((total + 255) / 256)),
+                               dim3(256), 0, c->stream,
+                               (const double *)c->part.p, (long long)v.n,
+                               (int)K, MS, (long long)ldo, d_out);
+        }
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 template <int KW>
 static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
-                     bool from_theta, double FP, double FN, double *d_out)
+                     bool from_theta, double FP, double FN, double *d_out,
+                     int MS, int m_chunk)
 {
     const int64_t G = (K + KW - 1) / KW;
     ARGCHK(G <= 65535, "too many cluster groups for one launch");
@@ -806,7 +875,7 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                            (const double *)c->tab_in.p + (size_t)K * c->M,
                            (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
     HIPCHK(hipGetLastError());
-    if (issue_ll<KW>(c, v, K, ldo, d_out)) return 1;
+    if (issue_ll<KW>(c, v, K, ldo, d_out, MS, m_chunk)) return 1;
     return 0;
 }
 
@@ -819,20 +888,28 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     ARGCHK(ldo >= K, "ldo smaller than K");
     const size_t out_bytes = (size_t)v.n * ldo * sizeof(double);
     if (ensure(c->out, out_bytes)) return 1;
-    int kw = pick_kw(v.nblk, K);
+    int kw = pick_kw(K);
     const char *force = getenv("BNPC_KW");
     if (force) {
         int f = atoi(force);
         if (f == 1 || f == 2 || f == 4 || f == 8) kw = f;
     }
+    // Sums over caller-built tables keep the strict mutation order (they are
+    // the bit-exact path); device-built tables may split the mutations.
+    int MS, m_chunk;
+    pick_msplit(v.nblk * ((K + kw - 1) / kw), c->Mt,
+                from_theta && env_flag("BNPC_MSPLIT", 1), &MS, &m_chunk);
+    double *d_out = (double *)c->out.p;
     int rc;
     switch (kw) {
-    case 8: rc = launch_ll<8>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
-    case 4: rc = launch_ll<4>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
-    case 2: rc = launch_ll<2>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
-    default: rc = launch_ll<1>(c, v, K, ldo, from_theta, FP, FN, (double *)c->out.p); break;
+    case 8: rc = launch_ll<8>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
+    case 4: rc = launch_ll<4>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
+    case 2: rc = launch_ll<2>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
+    default: rc = launch_ll<1>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
     }
     if (rc) return rc;
+    c->last_ms = MS;
+    c->last_mchunk = m_chunk;
     c->last_kw = kw;
     c->last_view = view;
     c->last_K = K;
@@ -1046,10 +1123,10 @@ extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
         int rc;
         double *o = (double *)c->out.p;
         switch (c->last_kw) {
-        case 8: rc = issue_ll<8>(c, v, c->last_K, c->last_ldo, o); break;
-        case 4: rc = issue_ll<4>(c, v, c->last_K, c->last_ldo, o); break;
-        case 2: rc = issue_ll<2>(c, v, c->last_K, c->last_ldo, o); break;
-        default: rc = issue_ll<1>(c, v, c->last_K, c->last_ldo, o); break;
+        case 8: rc = issue_ll<8>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;
+        case 4: rc = issue_ll<4>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;
+        case 2: rc = issue_ll<2>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;
+        default: rc = issue_ll<1>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;
         }
         if (rc) return rc;
     }
