@@ -61,6 +61,8 @@ SIGNATURES = {
     'bnpc_mt_permutation': (C.c_int, [C.POINTER(MT19937), _i64, _pi64]),
     'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
+    'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,
+        C.POINTER(C.c_int8), _pi64, _pi64]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
 }

@@ -32,6 +32,59 @@ def _is_code(token):
         return False
 
 
+def _sniff_layout(head):
+    """(separator, header_row, index_col) from the first lines of the file."""
+    sep = _sniff_separator(head[0])
+    header_row = any(not _is_code(tok) for tok in head[0].split(sep)
+        if tok not in ('', ' '))
+    body_probe = head[1:] if header_row else head
+    index_col = any(not _is_code(ln.split(sep)[0]) for ln in body_probe
+        if ln.split(sep)[0] not in ('', ' '))
+    return sep, header_row, index_col
+
+
+def load_codes_native(in_file, transpose=True):
+    """The same matrix as `load_data`, as int8 codes 0 | 1 | 3 (missing),
+    cells x mutations, scanned by libbnpc_hip.so's byte scanner
+    (bnpc_parse_matrix).  No names."""
+    import ctypes as C
+    from bnpc_amd import _lib
+    head = []
+    with open(in_file, 'r') as f:
+        for _ in range(5):
+            ln = f.readline()
+            if ln.strip():
+                head.append(ln.strip())
+    if not head:
+        raise ValueError(f'Could not read data from file: {in_file}')
+    sep, header_row, index_col = _sniff_layout(head)
+    lib = _lib.load()
+    rows, cols = C.c_int64(0), C.c_int64(0)
+    path = os.fsencode(in_file)
+    bsep = sep.encode()
+    _lib.check(lib.bnpc_parse_matrix(path, bsep, int(header_row),
+        int(index_col), None, C.byref(rows), C.byref(cols)), 'parse_matrix')
+    codes = np.empty((rows.value, cols.value), dtype=np.int8)
+    _lib.check(lib.bnpc_parse_matrix(path, bsep, int(header_row),
+        int(index_col), _lib.ptr(codes, C.c_int8), C.byref(rows),
+        C.byref(cols)), 'parse_matrix')
+    if transpose:
+        codes = np.ascontiguousarray(codes.T)
+    return codes
+
+
+def codes_to_data(codes):
+    """int8 codes 0 | 1 | 3 -> the reference's float64 matrix with NaN."""
+    data = codes.astype(np.float64)
+    data[codes == 3] = np.nan
+    return data
+
+
+def data_to_codes(data):
+    codes = np.where(np.isnan(data), 3, data).astype(np.int8)
+    return codes
+
+
 def load_data(in_file, transpose=True, get_names=False):
     """Read a 0|1|2|3 matrix; returns cells x mutations float64 with NaN.
 
@@ -46,14 +99,8 @@ def load_data(in_file, transpose=True, get_names=False):
     if not lines:
         raise ValueError(f'Could not read data from file: {in_file}')
 
-    sep = _sniff_separator(lines[0].strip())
-    head = [ln.strip() for ln in lines[:5]]
-
-    header_row = any(not _is_code(tok) for tok in head[0].split(sep)
-        if tok not in ('', ' '))
-    body_probe = head[1:] if header_row else head
-    index_col = any(not _is_code(ln.split(sep)[0]) for ln in body_probe
-        if ln.split(sep)[0] not in ('', ' '))
+    sep, header_row, index_col = _sniff_layout(
+        [ln.strip() for ln in lines[:5]])
 
     col_names = None
     if header_row:

@@ -207,6 +207,16 @@ int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S, const double *ll,
                  double DP_a, int64_t *rg_assignment, const int64_t *target,
                  double *log_prob);
 
+/* ---- data ingest ---------------------------
+ * Body scanner for the reference's text matrix format (libs/dpmmIO.py:27-98):
+ * fields 0|1|2|3 (2 -> 1; 3 or empty -> missing) separated by `sep`.  Skips
+ * `skip_rows` header lines and, if skip_index, the first field of each line.
+ * Call once with out == NULL to get rows/cols, then with an int8 buffer of
+ * rows*cols (file orientation; codes 0, 1, 3).  Host only, no GPU. */
+int bnpc_parse_matrix(const char *path, char sep, int skip_rows,
+                      int skip_index, int8_t *out, int64_t *rows,
+                      int64_t *cols);
+
 #ifdef __cplusplus
 }
 #endif

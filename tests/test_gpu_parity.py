@@ -349,6 +349,29 @@ def test_config2_chain_matches_oracle():
     np.testing.assert_allclose(rp['ML'], ro['ML'], rtol=1e-9)
 
 
+def test_config3_full_size_trajectory_matches_oracle_fixture(golden_dir):
+    """BASELINE config 3 at FULL size (5000 x 1000, 20 % missing, learned
+    errors, CLI-default moves), 9 steps including the first sweep from
+    K0 = 3152 clusters: the device chain walks the trajectory the CPU oracle
+    produced (tests/golden/make_c3_trajectory.py, ~3 CPU-minutes)."""
+    import bench
+    import libs.CRP_learning_errors as dev
+    from bnpc_amd.mcmc import MCMC
+    import contextlib
+    import io
+    t = np.load(os.path.join(golden_dir, 'c3_trajectory.npz'))
+    N, M, C, miss, learned = bench.CONFIGS['c3']
+    data = bench.synth(0, N, M, C, miss)
+    model = bench.make_model(None, dev, data, learned)
+    mcmc = MCMC(model, error_prob=.25, **bench.MCMC_PARAMS)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mcmc.run((9, 3), 42, 1, 0, '', True)
+    res = mcmc.get_results()[0]
+    assert np.array_equal(res['assignments'], t['assignments'])
+    for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
+        np.testing.assert_allclose(res[key], t[key], rtol=1e-9, err_msg=key)
+
+
 # ------------------------------------------ full BASELINE size, properties
 def test_full_size_properties_5000x1000():
     """Config 3 shape (5000 x 1000, 20 % missing) with K0 = 3152 clusters:

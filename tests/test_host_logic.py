@@ -244,10 +244,16 @@ def test_pickle_and_deepcopy_drop_the_device_context():
     p.init()
     ll = p.get_ll_full()
     assert p._ctx is not None
-    q = pickle.loads(pickle.dumps(p))
+    blob = pickle.dumps(p)
+    assert len(blob) < p.data.nbytes // 2 + p.parameters.nbytes + 20000
+    q = pickle.loads(blob)
     r = copy.deepcopy(p)
     for clone in (q, r):
         assert clone._ctx is None and clone._lab is None
+        assert clone.data.dtype == np.float64
+        assert np.array_equal(np.isnan(clone.data), np.isnan(p.data))
+        assert np.array_equal(np.nan_to_num(clone.data, nan=9),
+            np.nan_to_num(p.data, nan=9))
         assert clone.get_ll_full() == ll        # context rebuilt lazily
         assert clone._ctx is not None
 
