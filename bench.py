@@ -165,7 +165,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--seed', type=int, default=42)
-    ap.add_argument('--cpu-steps', type=int, default=4,
+    ap.add_argument('--cpu-steps', type=int, default=12,
         help='oracle steps timed for cpu_baseline (0 = skip)')
     ap.add_argument('--kernel-reps', type=int, default=5)
     args = ap.parse_args()

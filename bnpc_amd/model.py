@@ -267,22 +267,10 @@ class CRP:
             0, self.log_CRP_prior(sizes, self.cells_total, self.DP_a))
 
     # ------------------------------------------------- likelihood surface
-    def _Bernoulli_FN(self, x):
-        return (1 - self.FN) ** x * self.FN ** (1 - x)
-
-    def _Bernoulli_FP(self, x):
-        return (1 - self.FP) ** (1 - x) * self.FP ** x
-
-    def _calc_ll(self, x, theta, flat=False):
-        """Host form of libs/CRP.py:197-204 for callers that hand in raw
-        rows; the sampler itself never takes this route."""
-        mixed = theta * self._Bernoulli_FN(x) \
-            + (1 - theta) * self._Bernoulli_FP(x)
-        ll = np.nan_to_num(np.log(mixed), nan=0.0)
-        if flat:
-            return np.cumsum(ll.ravel())[-1] if ll.size else 0.0
-        return np.cumsum(ll, axis=1)[:, -1]
-
+    # The reference's private helpers _calc_ll / _Bernoulli_FN / _Bernoulli_FP
+    # (libs/CRP.py:197-212) take raw data ROWS; here every caller hands cell
+    # INDICES to the device primitives instead, so there is deliberately no
+    # host-side likelihood routine in this class.
     def get_lpost_single(self, cell_id, cl_ids):
         """libs/CRP.py:223-227 (one cell; the sweep evaluates all at once)."""
         ctx = self._dev()

@@ -177,8 +177,13 @@ def main(args):
     from bnpc_amd import postproc
     from libs.MCMC import MCMC
 
-    data, names = bio.load_data(args.input, transpose=args.transpose,
-        get_names=True)
+    if os.path.getsize(args.input) > (4 << 20):
+        # large matrices: native byte scanner (no row / column names)
+        data = bio.codes_to_data(
+            bio.load_codes_native(args.input, transpose=args.transpose))
+    else:
+        data, _ = bio.load_data(args.input, transpose=args.transpose,
+            get_names=True)
     assert data.size > 0, f'Could not read data from file: {args.input}'
 
     # fixed error rates only if BOTH are given (run_BnpC.py:249-262)
