@@ -108,8 +108,12 @@ class Ranks:
             dist.init_process_group('gloo', rank=self.rank,
                 world_size=self.world)
             self.dist = dist
+        self.device = 0
         if torch.cuda.is_available():
-            torch.cuda.set_device(self.local_rank)
+            # one rank per GPU; if there are more ranks than GPUs (a 2-rank
+            # smoke run on a 1-GPU box) ranks share devices round-robin
+            self.device = self.local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(self.device)
         return self
 
     def barrier_sync(self):
@@ -172,7 +176,7 @@ def main():
 
     ranks = Ranks().init()
     rank, world = ranks.rank, ranks.world
-    os.environ['BNPC_DEVICE'] = str(ranks.local_rank)
+    os.environ['BNPC_DEVICE'] = str(ranks.device)
 
     from bnpc_amd import _lib
     import libs.CRP as dev_fixed
