@@ -63,6 +63,7 @@ SIGNATURES = {
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
     'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,
         C.POINTER(C.c_int8), _pi64, _pi64]),
+    'bnpc_codist': (C.c_int, [C.c_int, _pi32, _i64, _i64, _pi32]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
 }
@@ -136,6 +137,19 @@ def rng_import(st, extra):
     """Write an MT19937 struct back into the global legacy np.random state."""
     key = np.frombuffer(st.key, dtype=np.uint32).copy()
     np.random.set_state(('MT19937', key, int(st.pos), extra[0], extra[1]))
+
+
+def codist(assignments, device=None):
+    """Condensed int32 counts of samples in which two cells differ in label
+    (bnpc_codist); assignments: samples x cells integer array."""
+    a = np.ascontiguousarray(assignments, dtype=np.int32)
+    S, N = a.shape
+    out = np.empty(N * (N - 1) // 2, dtype=np.int32)
+    if device is None:
+        device = int(os.environ.get('BNPC_DEVICE', '0'))
+    check(load().bnpc_codist(device, ptr(a, C.c_int32), S, N,
+        ptr(out, C.c_int32)), 'codist')
+    return out
 
 
 class Context:

@@ -1,9 +1,13 @@
-"""The little post-processing the driver and the CLI need.
+"""Post-processing the driver and the CLI need.
 
 Restated from /root/reference/libs/utils.py: the lugsail batch-means PSRF
-(:427-467, used by the -ls termination mode and the run summary) and the ML /
-MAP point estimates (:248-282).  The posterior (MPEAR) estimator, metrics and
-tree helpers are out of scope.
+(:427-467, used by the -ls termination mode and the run summary), the ML / MAP
+point estimates (:248-282) and the posterior estimator (:90-244: mean
+co-clustering distance, MPEAR-selected Ward clustering, averaged cluster
+genotypes).  The O(samples x cells^2) co-clustering distance - the next
+data-parallel kernel after the likelihood path (SURVEY.md section 8(f) rank
+4) - runs on the GPU (bnpc_codist); the rest is O(cells^2) SciPy on the host.
+Metrics (V-measure, ARI, Hamming) and tree helpers are out of scope.
 """
 import numpy as np
 
@@ -65,3 +69,114 @@ def point_estimate(result, est, data):
 def best_chain(results, est):
     scores = [np.max(r[est][r['burn_in']:]) for r in results]
     return results[int(np.argmax(scores))]
+
+
+# ---------------------------------------------------------------------------
+# posterior estimator (utils.py:90-244)
+# ---------------------------------------------------------------------------
+def get_dist(assignments):
+    """Mean posterior co-clustering distance of all cell pairs, condensed in
+    pdist order (utils.py:90-97); exact integer counts from the GPU."""
+    from bnpc_amd import _lib
+    differ = _lib.codist(assignments)
+    return differ / assignments.shape[0]
+
+
+def calc_MPEAR(pi, labels):
+    """Posterior expected adjusted Rand index of a clustering
+    (Fritsch & Ickstadt 2009, eq. 13; utils.py:133-145)."""
+    from scipy.spatial.distance import pdist
+    from scipy.special import binom
+    same = 1 - pdist(np.stack([labels, labels]).T, 'hamming')
+    I_sum, pi_sum = same.sum(), pi.sum()
+    expected = (I_sum * pi_sum) / binom(labels.size, 2)
+    return ((same * pi).sum() - expected) \
+        / (.5 * (I_sum + pi_sum) - expected)
+
+
+def get_MPEAR(assignments, dist=None):
+    """Ward tree on the mean distance, cut where MPEAR is largest
+    (utils.py:100-130)."""
+    from scipy.cluster.hierarchy import cut_tree, linkage
+    if dist is None:
+        dist = get_dist(assignments)
+    sim = 1 - dist
+    tree = linkage(dist, method='ward')
+    sizable = [int((np.unique(a, return_counts=True)[1] > 2).sum())
+        for a in assignments]
+    avg = np.mean(sizable)
+    candidates = np.arange(max(2, avg * 0.2),
+        min(avg * 2.5, assignments.shape[1]), dtype=int)
+    best, best_score = None, -np.inf
+    for n in candidates:
+        labels = cut_tree(tree, n_clusters=n).flatten()
+        score = calc_MPEAR(sim, labels)
+        if score > best_score:
+            best, best_score = labels, score
+    return best
+
+
+def mean_hierarchy_assignment(assignments, params_full, dist=None):
+    """utils.py:148-192: the MPEAR clustering and, per cluster, the mean of
+    the sampled parameter vectors of the posterior samples in which the
+    cluster's cells sit together (and alone, if such samples exist)."""
+    steps = assignments.shape[0]
+    assign = get_MPEAR(assignments, dist)
+    clusters = np.unique(assign)
+    params = np.zeros((clusters.size, params_full.shape[2]))
+    for row, cluster in enumerate(clusters):
+        member = assign == cluster
+        cells = np.flatnonzero(member)
+        sub = assignments[:, cells]
+        others = assignments[:, np.flatnonzero(~member)]
+        together = (sub == sub[:, :1]).all(axis=1)
+        major = np.array([np.argmax(np.bincount(r)) for r in sub])
+        alone = ~(others == major[:, None]).any(axis=1)
+        if together.any():
+            pick = together & alone
+            if not pick.any():
+                pick = together
+            chosen = np.flatnonzero(pick)
+            for s in chosen:
+                present = np.append(np.unique(others[s]), major[s])
+                rank = np.argwhere(np.sort(present) == major[s])[0][0]
+                params[row] += params_full[s][rank]
+            params[row] /= chosen.size
+        else:
+            for s, sample in enumerate(assignments):
+                all_ids = np.unique(sample)
+                ids, cnt = np.unique(sample[cells], return_counts=True)
+                rows = np.flatnonzero(np.isin(all_ids, ids))
+                params[row] += np.dot(cnt, params_full[s][rows])
+            params[row] /= steps * cells.size
+    return assign, params[assign].T
+
+
+def concat_chain_results(results):
+    """Pool the post-burn-in samples of all chains (utils.py:206-223)."""
+    pooled = {k: np.concatenate([r[k][r['burn_in']:] for r in results])
+        for k in ('assignments', 'DP_alpha', 'ML', 'MAP', 'FN', 'FP')}
+    width = max(r['params'].shape[1] for r in results)
+    pooled['params'] = np.concatenate([np.pad(r['params'],
+        [(0, 0), (0, width - r['params'].shape[1]), (0, 0)])
+        for r in results])
+    pooled['burn_in'] = 0
+    return pooled
+
+
+def posterior_estimate(results, data):
+    """`-e posterior` (the default estimator), chains pooled
+    (utils.py:195-244)."""
+    res = concat_chain_results(results)
+    assign, geno = mean_hierarchy_assignment(res['assignments'],
+        res['params'])
+    called = geno.T.round()
+    FN_geno = (((called == 1) & (data == 0)).sum() + EPSILON) \
+        / (called.sum() + EPSILON)
+    FP_geno = (((called == 0) & (data == 1)).sum() + EPSILON) \
+        / ((1 - called).sum() + EPSILON)
+    return {'a': (np.mean(res['DP_alpha']), np.std(res['DP_alpha'])),
+        'assignment': assign.tolist(), 'genotypes': geno.T,
+        'FN': (np.mean(res['FN']), np.std(res['FN'])),
+        'FP': (np.mean(res['FP']), np.std(res['FP'])),
+        'FN_geno': FN_geno, 'FP_geno': FP_geno}

@@ -217,6 +217,16 @@ int bnpc_parse_matrix(const char *path, char sep, int skip_rows,
                       int skip_index, int8_t *out, int64_t *rows,
                       int64_t *cols);
 
+/* ---- posterior co-clustering distance ------
+ * differ[(i,j)] = number of the S posterior samples in which cells i < j carry
+ * different cluster labels, condensed in scipy pdist order (N*(N-1)/2 int32).
+ * Replaces the per-sample pdist accumulation of utils.get_dist
+ * (libs/utils.py:90-97); the mean distance is differ / S.  assignments is
+ * S x N int32 row-major.  Stand-alone: allocates and frees its own device
+ * memory. */
+int bnpc_codist(int device, const int32_t *assignments, int64_t S, int64_t N,
+                int32_t *differ);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,9 +9,9 @@ Kept verbatim from the reference: every flag, its destination name, type,
 default and choices - including the defaults that differ from their help text
 (-FP_m 0.01, -sms 3) and `-t` being store_false.  Outputs are restated
 minimally (file I/O and reporting are out of scope):
-args.txt, assignment.txt and errors.txt for the ML / MAP point estimates; the
-MPEAR posterior estimator and all plots are not part of this build, `-e
-posterior` reports the MAP sample instead and says so.
+args.txt, assignment.txt and errors.txt for the posterior (MPEAR, chains
+pooled), ML and MAP estimators; plots, genotype tables and metrics are not
+part of this build.
 """
 import argparse
 from datetime import datetime
@@ -141,13 +141,24 @@ def save_outputs(args, results, data, out_dir):
     chains = list(enumerate(results)) if args.single_chains else [('mean', None)]
     rows_a, rows_e = [], []
     for est in ests:
-        use = 'MAP' if est == 'posterior' else est
-        if est == 'posterior' and args.verbosity > 0:
-            print('note: the MPEAR posterior estimator is not part of this '
-                'build; reporting the MAP sample for "-e posterior"')
+        if est == 'posterior':
+            # the reference's per-chain posterior (-sc) indexes its parameter
+            # trace inconsistently (utils.py:228-229); chains are pooled here
+            inf = postproc.posterior_estimate(results, data)
+            rows_a.append(('mean', est,
+                ' '.join(str(i) for i in inf['assignment'])))
+            rows_e.append(('mean', est,
+                f'{inf["FN"][0]:.4f}+-{inf["FN"][1]:.4f}',
+                round(float(inf['FN_geno']), 4),
+                f'{inf["FP"][0]:.8f}+-{inf["FP"][1]:.8f}',
+                round(float(inf['FP_geno']), 8)))
+            if args.verbosity > 0:
+                print(f'posterior: {len(set(inf["assignment"]))} clusters, '
+                    f'FN {inf["FN"][0]:.4f}, FP {inf["FP"][0]:.6f}')
+            continue
         for chain, res in chains:
-            res = res if res is not None else postproc.best_chain(results, use)
-            inf = postproc.point_estimate(res, use, data)
+            res = res if res is not None else postproc.best_chain(results, est)
+            inf = postproc.point_estimate(res, est, data)
             rows_a.append((chain, est,
                 ' '.join(str(i) for i in inf['assignment'])))
             rows_e.append((chain, est, round(float(inf['FN']), 4),

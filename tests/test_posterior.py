@@ -1,0 +1,127 @@
+"""Posterior estimator: oracle and product
+against golden vectors captured from the reference
+(tests/golden/make_posterior_golden.py); the GPU co-clustering kernel against
+the oracle's exact integer counts."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.distance import pdist
+
+from oracle import posterior_numpy as Q
+from bnpc_amd import _lib, postproc
+
+
+def decode(codes):
+    x = codes.astype(np.float64)
+    x[codes == 3] = np.nan
+    return x
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'posterior.npz'))
+    results = []
+    for i in range(2):
+        r = {k: g[f'r{i}_{k}'] for k in ('assignments', 'params', 'DP_alpha',
+            'FN', 'FP', 'ML', 'MAP')}
+        r['burn_in'] = int(g[f'r{i}_burn_in'])
+        results.append(r)
+    return g, results, decode(g['data'])
+
+
+def differ_counts(assignments):
+    out = np.zeros(assignments.shape[1] * (assignments.shape[1] - 1) // 2,
+        dtype=np.int32)
+    for a in assignments:
+        out += pdist(np.stack([a, a]).T, 'hamming').astype(np.int32)
+    return out
+
+
+def test_oracle_matches_reference(G):
+    g, results, data = G
+    a0 = results[0]['assignments'][results[0]['burn_in']:]
+    dist = Q.get_dist(a0)
+    assert np.array_equal(dist, g['dist0'])
+    labels = Q.get_MPEAR(a0)
+    assert np.array_equal(labels, g['mpear0'])
+    assert Q.calc_MPEAR(1 - dist, labels) == float(g['mpear0_score'])
+    lat = Q.latents_posterior(results, data)
+    assert np.array_equal(lat['assignment'], g['mean0_assignment'])
+    assert np.array_equal(lat['genotypes'], g['mean0_genotypes'])
+    np.testing.assert_allclose(lat['a'], g['mean0_a'], rtol=1e-14)
+    np.testing.assert_allclose(lat['FN_geno'], g['mean0_FN_geno'], rtol=1e-14)
+    np.testing.assert_allclose(lat['FP_geno'], g['mean0_FP_geno'], rtol=1e-14)
+
+
+def test_point_estimates_and_psrf_match_reference(G):
+    g, results, data = G
+    for est in ('ML', 'MAP'):
+        inf = postproc.point_estimate(postproc.best_chain(results, est), est,
+            data)
+        assert inf['step'] == int(g[f'{est}_step'])
+        assert np.array_equal(inf['assignment'], g[f'{est}_assignment'])
+        assert np.array_equal(inf['genotypes'].T, g[f'{est}_genotypes'])
+        np.testing.assert_allclose(inf['FN_geno'], g[f'{est}_FN_geno'],
+            rtol=1e-14)
+    psrf = postproc.get_lugsail_batch_means_est(
+        [(r['ML'], r['burn_in']) for r in results])
+    np.testing.assert_allclose(psrf, g['psrf'], rtol=1e-12)
+
+
+def test_product_posterior_host_logic(G, monkeypatch):
+    """The product's estimator with the device kernel replaced by the exact
+    NumPy counts: the reference's clustering and genotypes."""
+    g, results, data = G
+    monkeypatch.setattr(_lib, 'codist',
+        lambda a, device=None: differ_counts(np.asarray(a)))
+    inf = postproc.posterior_estimate(results, data)
+    assert np.array_equal(inf['assignment'], g['mean0_assignment'])
+    assert np.array_equal(inf['genotypes'].T, g['mean0_genotypes'])
+    np.testing.assert_allclose(inf['FN'], g['mean0_FN'], rtol=1e-14)
+    np.testing.assert_allclose(inf['FN_geno'], g['mean0_FN_geno'], rtol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,N,K', [(1, 2, 2), (33, 63, 4), (64, 64, 3),
+    (100, 65, 7), (37, 300, 12), (250, 1000, 10)])
+def test_codist_kernel_is_exact(S, N, K):
+    rng = np.random.RandomState(S * 1000 + N)
+    a = rng.randint(0, K, size=(S, N))
+    a[:, : N // 3] = a[:, :1]            # a block of always-together cells
+    got = _lib.codist(a)
+    assert got.dtype == np.int32
+    assert np.array_equal(got, differ_counts(a))
+    assert np.array_equal(postproc.get_dist(a), Q.get_dist(a))
+
+
+@pytest.mark.gpu
+def test_product_posterior_on_device(G):
+    g, results, data = G
+    inf = postproc.posterior_estimate(results, data)
+    assert np.array_equal(inf['assignment'], g['mean0_assignment'])
+    assert np.array_equal(inf['genotypes'].T, g['mean0_genotypes'])
+
+
+@pytest.mark.gpu
+def test_codist_full_size_properties():
+    """5000 cells x 400 samples (the config-3 cell count): symmetry-free
+    invariants of the condensed counts + a sampled exact comparison."""
+    rng = np.random.RandomState(0)
+    S, N = 400, 5000
+    base = rng.randint(0, 10, N)
+    a = np.tile(base, (S, 1))
+    flip = rng.random_sample((S, N)) < 0.05
+    a[flip] = rng.randint(0, 10, flip.sum())
+    d = _lib.codist(a)
+    assert d.size == N * (N - 1) // 2 and d.min() >= 0 and d.max() <= S
+    # relabelling the clusters of any sample changes nothing
+    b = (a + 3) % 10
+    assert np.array_equal(_lib.codist(b), d)
+    # sampled rows against the direct count
+    for i in rng.choice(N - 1, 5, replace=False):
+        row = (a[:, [i]] != a[:, i + 1:]).sum(axis=0)
+        start = i * (2 * N - i - 1) // 2
+        assert np.array_equal(d[start:start + N - i - 1], row)
+    # a permutation of the samples changes nothing
+    assert np.array_equal(_lib.codist(a[rng.permutation(S)]), d)
