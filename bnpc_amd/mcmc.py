@@ -194,19 +194,29 @@ class MCMC:
 
 
 class Chain:
-    """MCMC.py:200-342"""
+    """One MCMC chain: the move schedule and its trace store.
 
-    TRACES = ('ML', 'MAP', 'DP_alpha', 'FN', 'FP')
+    Follows libs/MCMC.py:200-342.  `results` keeps the reference's layout
+    because everything downstream reads it: float traces ML, MAP, DP_alpha,
+    FN, FP (entry 0 = initial state), `assignments` (samples x cells),
+    after burn-in `params` (samples x clusters x mutations float32, clusters in
+    sorted-id order, zero-padded to the largest cluster count seen), and
+    `burn_in`.
+    """
+
+    SCALAR_TRACES = ('ML', 'MAP', 'DP_alpha', 'FN', 'FP')
+    # rows of MH_counter (cols: accepted, declined)
+    ROW_PARAMS, ROW_SPLIT, ROW_MERGE, ROW_FP, ROW_FN = range(5)
 
     def __init__(self, model, mcmc, no, verbosity=1, fix_assign=False):
         self.model = model
         self.mcmc = mcmc
         self.no = no
+        # the reference keys this on the module path (MCMC.py:206-209)
         self.learning_errors = \
-            model.__class__.__module__ == 'libs.CRP_learning_errors' \
+            type(model).__module__ == 'libs.CRP_learning_errors' \
             or callable(getattr(model, 'update_error_rates', None))
         self.results = {}
-        # rows: parameters, splits, merges, FP, FN; cols: accepted, declined
         self.MH_counter = np.zeros((5, 2))
         self.verbosity = verbosity
         self.fix_assign = fix_assign
@@ -220,98 +230,107 @@ class Chain:
     def run(self, *args):
         pass
 
+    # ------------------------------------------------------------ traces
     def init_results(self, steps):
-        for key in self.TRACES:
+        for key in self.SCALAR_TRACES:
             self.results[key] = np.zeros(steps)
         self.results['assignments'] = np.zeros(
             (steps, self.model.cells_total), dtype=int)
 
+    def _capacity(self):
+        return self.results['ML'].size
+
     def update_results(self, step, burn_in=True):
-        """MCMC.py:242-282"""
-        res = self.results
-        room = res['ML'].size - step
-        if room == 0:
+        """Record the state after `step` (MCMC.py:242-282)."""
+        free_slots = self._capacity() - step
+        if free_slots == 0:         # time-limited runs grow their traces
             try:
                 self._extend_results(burn_in=burn_in)
             except MemoryError:
-                step = step % res['ML'].size
+                step %= self._capacity()
                 self.burn_in = np.nan
+        self._record_state(step)
+        if not burn_in:
+            self._record_parameters(step, free_slots)
 
-        model = self.model
-        ll = model.get_ll_full()
-        res['ML'][step] = ll
-        res['MAP'][step] = ll + model.get_lprior_full()
+    def _record_state(self, step):
+        model, res = self.model, self.results
+        log_lik = model.get_ll_full()
+        res['ML'][step] = log_lik
+        res['MAP'][step] = log_lik + model.get_lprior_full()
         res['DP_alpha'][step] = model.DP_a
         res['FN'][step] = model.FN
         res['FP'][step] = model.FP
         res['assignments'][step] = model.assignment
 
-        if burn_in:
-            return
-        clusters = np.sort(
-            np.fromiter(model.cells_per_cluster.keys(), dtype=int))
+    def _record_parameters(self, step, free_slots):
+        model, res = self.model, self.results
+        live = np.sort(np.fromiter(model.cells_per_cluster.keys(), dtype=int))
         if 'params' not in res:
             res['params'] = np.zeros(
-                (room, clusters.size, model.muts_total), dtype=np.float32)
-        first_kept = res['ML'].size - res['params'].shape[0] + 1
-        grow = clusters.size - res['params'].shape[1]
-        if grow > 0:
-            res['params'] = np.pad(
-                res['params'], [(0, 0), (0, grow), (0, 0)], mode='constant')
-        res['params'][step - first_kept + 1][:clusters.size] = \
-            model.parameters[clusters]
+                (free_slots, live.size, model.muts_total), dtype=np.float32)
+        trace = res['params']
+        if live.size > trace.shape[1]:
+            trace = res['params'] = np.pad(trace,
+                [(0, 0), (0, live.size - trace.shape[1]), (0, 0)],
+                mode='constant')
+        first_kept = self._capacity() - trace.shape[0] + 1
+        trace[step - first_kept + 1][:live.size] = model.parameters[live]
 
     def _extend_results(self, add_size=None, burn_in=True):
         """MCMC.py:285-305"""
         res = self.results
-        if not add_size:
-            add_size = min(200, res['ML'].size)
+        extra = add_size or min(200, self._capacity())
         if not burn_in:
-            res['params'] = np.append(res['params'],
-                np.zeros((add_size, res['params'].shape[1],
-                    self.model.muts_total)), axis=0)
-        pad = np.zeros(add_size)
-        for key in self.TRACES:
-            res[key] = np.append(res[key], pad)
+            res['params'] = np.append(res['params'], np.zeros(
+                (extra, res['params'].shape[1], self.model.muts_total)),
+                axis=0)
+        for key in self.SCALAR_TRACES:
+            res[key] = np.append(res[key], np.zeros(extra))
         res['assignments'] = np.append(res['assignments'],
-            np.zeros((add_size, self.model.cells_total), int), axis=0)
+            np.zeros((extra, self.model.cells_total), int), axis=0)
 
+    # ------------------------------------------------------------ reporting
     def stdout_progress(self):
         from bnpc_amd.io import show_MH_acceptance
-        show_MH_acceptance(self.MH_counter[0], 'parameters', 1)
+        rows = [(self.ROW_PARAMS, 'parameters', 1)]
         if not self.fix_assign:
-            show_MH_acceptance(self.MH_counter[1], 'splits')
-            show_MH_acceptance(self.MH_counter[2], 'merges')
+            rows += [(self.ROW_SPLIT, 'splits', 2), (self.ROW_MERGE, 'merges', 2)]
         if self.learning_errors:
-            show_MH_acceptance(self.MH_counter[3], 'FP')
-            show_MH_acceptance(self.MH_counter[4], 'FN')
+            rows += [(self.ROW_FP, 'FP', 2), (self.ROW_FN, 'FN', 2)]
+        for row, name, tabs in rows:
+            show_MH_acceptance(self.MH_counter[row], name, tabs)
         self.MH_counter = np.zeros((5, 2))
 
+    # ------------------------------------------------------------ one step
     def do_step(self):
-        """MCMC.py:320-342"""
-        model, cfg = self.model, self.mcmc
+        """The move schedule (MCMC.py:320-342).  Every `np.random.random()`
+        below is a draw of the reference's stream, in its order; the error
+        draw only happens for models that learn their error rates."""
+        model, prob = self.model, self.mcmc
         if not self.fix_assign:
-            if np.random.random() < cfg['sm_prob']:
-                counts, move = model.update_assignments_split_merge(
-                    cfg['sm_ratios'], cfg['sm_steps'])
-                self.MH_counter[1 if move == 0 else 2] += counts
+            if np.random.random() < prob['sm_prob']:
+                outcome, move = model.update_assignments_split_merge(
+                    prob['sm_ratios'], prob['sm_steps'])
+                row = self.ROW_SPLIT if move == 0 else self.ROW_MERGE
+                self.MH_counter[row] += outcome
             else:
                 model.update_assignments_Gibbs()
-            if np.random.random() < cfg['dpa_prob']:
+            if np.random.random() < prob['dpa_prob']:
                 model.update_DP_alpha()
 
         declined, accepted = model.update_parameters()
-        self.MH_counter[0][1] += declined
-        self.MH_counter[0][0] += accepted
+        self.MH_counter[self.ROW_PARAMS] += (accepted, declined)
 
-        if self.learning_errors and np.random.random() < cfg['error_prob']:
-            FP_count, FN_count = model.update_error_rates()
-            self.MH_counter[3] += FP_count
-            self.MH_counter[4] += FN_count
+        if self.learning_errors \
+                and np.random.random() < prob['error_prob']:
+            FP_outcome, FN_outcome = model.update_error_rates()
+            self.MH_counter[self.ROW_FP] += FP_outcome
+            self.MH_counter[self.ROW_FN] += FN_outcome
 
 
 class Chain_steps(Chain):
-    """Fixed number of steps.  MCMC.py:349-388"""
+    """A chain that runs a fixed number of steps (MCMC.py:349-388)."""
 
     def __init__(self, model, no, steps, burn_in, mcmc, verbosity=1,
                 fix_assign=False):
@@ -325,30 +344,34 @@ class Chain_steps(Chain):
         self.steps = n + 1
 
     def get_steps(self):
-        return self.results['ML'].size
+        return self._capacity()
 
     def stdout_progress(self, step_no, total):
         print(f'\t{self}\tstep:\t{step_no: >3} / {total - 1}\n'
             '\t\tmean MH accept. ratio:')
         super().stdout_progress()
 
+    def _in_burn_in(self, step):
+        try:
+            return step < self.burn_in
+        except TypeError:
+            return False
+
     def run(self, init_steps=0):
-        # reference quirk kept: fewer than 9 steps divides by zero here
+        # reference quirk kept: with fewer than 9 steps the report interval
+        # is zero and the modulo below raises ZeroDivisionError
         report_every = self.steps // 10
+        last = self.steps + init_steps
         for step in range(1, self.steps):
             if step % report_every == 0 and self.verbosity > 1:
-                self.stdout_progress(step + init_steps, self.steps + init_steps)
+                self.stdout_progress(step + init_steps, last)
             self.do_step()
-            try:
-                burn_in = step < self.burn_in
-            except TypeError:
-                burn_in = False
-            self.update_results(step + init_steps, burn_in)
+            self.update_results(step + init_steps, self._in_burn_in(step))
         self.results['burn_in'] = self.burn_in
 
 
 class Chain_time(Chain):
-    """Run until a wall-clock deadline.  MCMC.py:395-440"""
+    """A chain that runs until a wall-clock deadline (MCMC.py:395-440)."""
 
     def __init__(self, model, no, end_time, burn_in, mcmc, verbosity=1,
                 fix_assign=False):
@@ -374,14 +397,15 @@ class Chain_time(Chain):
             step += 1
             self.do_step()
             try:
-                burn_in = now < self.burn_in
+                warming_up = now < self.burn_in
             except TypeError:
-                burn_in = False
-            self.update_results(step, burn_in)
+                warming_up = False
+            self.update_results(step, warming_up)
 
+        # drop the unused tail of the pre-allocated traces
         unused = int((self.results['MAP'] == 0).sum())
         if unused:
-            for key, values in self.results.items():
-                self.results[key] = values[:-unused]
-        self.results['burn_in'] = self.results['ML'].size \
+            self.results = {key: values[:-unused]
+                for key, values in self.results.items()}
+        self.results['burn_in'] = self._capacity() \
             - self.results['params'].shape[0]

@@ -82,3 +82,24 @@ def test_bench_rank_harness_gloo_world2():
     # both ranks report the MAX over ranks: the slow rank's 5 x 20 ms
     assert abs(got[0] - got[1]) < 1e-9
     assert 0.09 < got[0] < 0.5
+
+
+def test_lugsail_mode_extends_chains_until_psrf_cutoff(monkeypatch):
+    """-ls: chains run max(10, 1/(c^2-1)) steps, then are extended by 200
+    steps through the pool until the lugsail PSRF drops under the cutoff
+    (libs/MCMC.py:85-90, 138-189)."""
+    monkeypatch.setattr(_lib, 'Context', FakeContext)
+    data = H.synth(9, 40, 25, 2, 0.1)
+    mcmc = MCMC(H.make(P, 'fixed', data), sm_prob=.2, dpa_prob=.25,
+        error_prob=0., sm_ratios=[.75, .25], sm_steps=2)
+    mcmc.run((1.2, 0), 3, 2, 0, '', False)
+    res = mcmc.get_results()
+    assert len(res) == 2
+    for r in res:
+        steps = r['ML'].size
+        assert steps >= 11 and (steps - 11) % 200 == 0
+        assert r['PSRF_cutoff'] == 1.2 and r['PSRF'][-1][1] <= 1.2
+        assert r['burn_in'] == (r['PSRF'][-1][0] // 2) + 1
+        assert r['params'].shape[0] == steps - r['burn_in'] or \
+            r['params'].shape[0] <= steps
+        assert np.all(r['ML'] != 0)
