@@ -357,8 +357,19 @@ __global__ __launch_bounds__(256) void k_ll_combine(
     if (i >= n * K) return;
     const long long slot = i / K;
     const int k = (int)(i - slot * K);
+    // partial sums are added in index order (deterministic); the loads are
+    // independent of the adds, 8 in flight
+    const size_t stride = (size_t)n * K;
     double s = part[i];
-    for (int ms = 1; ms < MS; ms++) s += part[(size_t)ms * n * K + i];
+    int ms = 1;
+    for (; ms + 8 <= MS; ms += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(ms + u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; ms < MS; ms++) s += part[(size_t)ms * stride + i];
     out[(size_t)slot * ldo + k] = s;
 }
 
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
 //   = the sums over a cell subset inside CRP._get_log_A (libs/CRP.py:359-368),
 //     CRP._init_cl_params_new (libs/CRP.py:183-188) and the flat sums of
 //     CRP._get_ll_ratio (libs/CRP.py:716-733), as exact integers.
-// thread <-> mutation; block <-> (chunk of <= 256 cells of one segment, 256
+// thread <-> mutation; block <-> (chunk of <= 32 cells of one segment, 256
 // mutations); a row word is shared by the 64 lanes of a wave (broadcast load).
 // ---------------------------------------------------------------------------
 struct Chunk {
@@ -498,7 +509,22 @@ __global__ __launch_bounds__(256) void k_colcounts(
     if (m >= M) return;
     const int w = m >> 6, b = m & 63;
     int c1 = 0, c0 = 0;
-    for (long long i = ch.begin; i < ch.end; i++) {
+    // chunks are short (<= 32 cells) so that a launch has thousands of
+    // workgroups; 4 independent row loads in flight per thread
+    long long i = ch.begin;
+    for (; i + 4 <= ch.end; i += 4) {
+        const long long ca = cells[i], cb = cells[i + 1], cc = cells[i + 2],
+            cd = cells[i + 3];
+        const ulonglong2 ra = rows[(size_t)ca * W + w];
+        const ulonglong2 rb = rows[(size_t)cb * W + w];
+        const ulonglong2 rc = rows[(size_t)cc * W + w];
+        const ulonglong2 rd = rows[(size_t)cd * W + w];
+        c1 += (int)((ra.x >> b) & 1ull) + (int)((rb.x >> b) & 1ull)
+            + (int)((rc.x >> b) & 1ull) + (int)((rd.x >> b) & 1ull);
+        c0 += (int)((ra.y >> b) & 1ull) + (int)((rb.y >> b) & 1ull)
+            + (int)((rc.y >> b) & 1ull) + (int)((rd.y >> b) & 1ull);
+    }
+    for (; i < ch.end; i++) {
         const long long cell = cells[i];
         const ulonglong2 r = rows[(size_t)cell * W + w];
         c1 += (int)((r.x >> b) & 1ull);
@@ -967,7 +993,7 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
     if (ensure(cnt, cnt_bytes)) return 1;
     HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_bytes, c->stream));
     std::vector<Chunk> chunks;
-    const int64_t CH = 256;
+    const int64_t CH = 32;
     for (int64_t g = 0; g < G; g++)
         for (int64_t b = seg_offsets[g]; b < seg_offsets[g + 1]; b += CH)
             chunks.push_back(
