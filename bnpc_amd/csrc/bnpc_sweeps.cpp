@@ -133,8 +133,15 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     double *post = scratch;             // ld + 1
     double *cdf = scratch + ld + 1;     // ld + 1
     st->new_cell = -1;
+    if (st->pos_end > N || st->pos > st->pos_end ||
+        (st->row_base >= 0 && st->row_base > st->pos)) {
+        bnpc_set_error("bad sweep window [%lld, %lld) / row_base %lld",
+                       (long long)st->pos, (long long)st->pos_end,
+                       (long long)st->row_base);
+        return 2;
+    }
 
-    while (st->pos < N) {
+    while (st->pos < st->pos_end) {
         const int64_t cell = perm[st->pos];
         if (cell < 0 || cell >= N) {
             bnpc_set_error("perm[%lld] out of range", (long long)st->pos);
@@ -163,7 +170,8 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 
         // log posterior of joining each live cluster / a new one (:268-274)
         const int64_t A = st->n_active;
-        const double *row = ll + (size_t)cell * ld;
+        const double *row = ll + (size_t)(st->row_base >= 0 ?
+            st->pos - st->row_base : cell) * ld;
         int64_t top = 0;
         for (int64_t a = 0; a < A; a++) {
             const int64_t c = order[a];

@@ -48,6 +48,8 @@ log_EPSILON = np.log(EPSILON)
 
 VIEW_ALL = 0      # identity view: all cells
 VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
+VIEW_ONE = 2      # a single cell (get_lpost_single)
+VIEW_SWEEP = 3    # a permutation-ordered tile of a tiled Gibbs sweep
 
 
 class CRP:
@@ -274,8 +276,8 @@ class CRP:
     def get_lpost_single(self, cell_id, cl_ids):
         """libs/CRP.py:223-227 (one cell; the sweep evaluates all at once)."""
         ctx = self._dev()
-        ctx.view_set(VIEW_MOVE + 1, [cell_id])
-        ll = ctx.ll_theta(VIEW_MOVE + 1, self.parameters[cl_ids], self.FP,
+        ctx.view_set(VIEW_ONE, [cell_id])
+        ll = ctx.ll_theta(VIEW_ONE, self.parameters[cl_ids], self.FP,
             self.FN)[0]
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
         return ll + self.CRP_prior[sizes]
@@ -331,11 +333,18 @@ class CRP:
 
     # ---------------------------------------------------------------- Gibbs
     def update_assignments_Gibbs(self):
-        """libs/CRP.py:254-288: one launch for the N x K log-likelihood
-        matrix, then the native sequential sweep; Python only opens new
-        clusters (rare)."""
-        lib = _lib.load()
-        ctx = self._dev()
+        """libs/CRP.py:254-288: the N x K log-likelihood matrix comes from the
+        device, the sequential per-cell loop runs natively on the replica of
+        NumPy's stream; Python only opens new clusters (rare).
+
+        If the matrix fits the host budget (BNPC_SWEEP_BYTES, default 256 MiB)
+        it is computed in ONE launch for all cells (rows = cell ids).  A
+        larger sweep - the first one, from K0 ~ 0.63 N clusters - is tiled
+        over permutation-ordered chunks of cells: each tile is evaluated only
+        for the clusters still alive when it starts (clusters die quickly
+        during that sweep), so the work and the memory shrink as the sweep
+        proceeds.  Same decisions, same draws, same trajectory either way.
+        """
         N = self.cells_total
         timing = os.environ.get('BNPC_TIMING')
         if timing:
@@ -343,17 +352,54 @@ class CRP:
             t_start = time.perf_counter()
         post_new = np.ascontiguousarray(self.get_lpost_single_new_cluster())
         perm = _lib.as_i64(np.random.permutation(N))
-
+        assignment = _lib.as_i64(self.assignment)
+        crp_prior = np.ascontiguousarray(self.CRP_prior, dtype=np.float64)
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
-        K = ids.size
-        ld = K + 16
-        ll = np.empty((N, ld), dtype=np.float64)
-        ctx.ll_theta(VIEW_ALL, self.parameters[ids], self.FP, self.FN, out=ll)
-        if timing:
-            t_ll = time.perf_counter()
+        K_start = ids.size
 
-        assignment = _lib.as_i64(self.assignment)
+        budget = int(os.environ.get('BNPC_SWEEP_BYTES', 256 << 20))
+        rng, extra = _lib.rng_export()
+        pos, opened, tiles = 0, 0, 0
+        while pos < N:
+            K = ids.size
+            rows_fit = max(64, budget // (8 * (K + 16)))
+            whole = pos == 0 and rows_fit >= N
+            pos_end = N if whole else min(N, pos + rows_fit)
+            rng, extra, ids, sizes, n_new = self._gibbs_window(
+                rng, extra, perm, pos, pos_end, whole, ids, sizes, assignment,
+                post_new, crp_prior)
+            opened += n_new
+            tiles += 1
+            pos = pos_end
+        _lib.rng_import(rng, extra)
+        if timing:
+            print(f'[bnpc] gibbs N={N} K={K_start}->{ids.size}: '
+                f'{time.perf_counter() - t_start:.3f}s in {tiles} tile(s), '
+                f'{opened} clusters opened', flush=True)
+
+        self.assignment = assignment
+        self.cells_per_cluster = {
+            int(i): int(n) for i, n in zip(ids, sizes)}
+
+    def _gibbs_window(self, rng, extra, perm, pos, pos_end, whole, ids, sizes,
+                assignment, post_new, crp_prior):
+        """Positions [pos, pos_end) of the sweep against the clusters `ids`
+        (dict order) with `sizes`.  Returns the stream state and the live
+        clusters (dict order) after the window."""
+        lib = _lib.load()
+        ctx = self._dev()
+        N = self.cells_total
+        K = ids.size
+        if whole:
+            view, n_rows = VIEW_ALL, N
+        else:
+            view, n_rows = VIEW_SWEEP, pos_end - pos
+            ctx.view_set(VIEW_SWEEP, perm[pos:pos_end])
+        ld = K + 16
+        ll = np.empty((n_rows, ld), dtype=np.float64)
+        ctx.ll_theta(view, self.parameters[ids], self.FP, self.FN, out=ll)
+
         col_of_id = np.full(N, -1, dtype=np.int64)
         col_of_id[ids] = np.arange(K)
         col_id = np.full(ld, -1, dtype=np.int64)
@@ -363,11 +409,11 @@ class CRP:
         order = np.zeros(ld, dtype=np.int64)
         order[:K] = np.arange(K)
         scratch = np.empty(2 * (ld + 1), dtype=np.float64)
-        crp_prior = np.ascontiguousarray(self.CRP_prior, dtype=np.float64)
 
-        st = _lib.GibbsState(N, ld, K, K, 0, -1)
-        rng, extra = _lib.rng_export()
+        st = _lib.GibbsState(N, ld, K, K, pos, -1, pos_end,
+            -1 if whole else pos)
         i64, f64 = C.c_int64, C.c_double
+        n_new = 0
         while True:
             _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), C.byref(rng),
                 _lib.ptr(perm, i64), _lib.ptr(ll, f64),
@@ -386,7 +432,7 @@ class CRP:
             if st.n_cols == ld:
                 grow = max(16, ld // 4)
                 ll = np.concatenate(
-                    [ll, np.empty((N, grow), dtype=np.float64)], axis=1)
+                    [ll, np.empty((n_rows, grow), dtype=np.float64)], axis=1)
                 col_id = np.concatenate([col_id, np.full(grow, -1, np.int64)])
                 col_size = np.concatenate([col_size, np.zeros(grow, np.int64)])
                 order = np.concatenate([order, np.zeros(grow, np.int64)])
@@ -394,7 +440,7 @@ class CRP:
                 scratch = np.empty(2 * (ld + 1), dtype=np.float64)
                 st.ld = ld
             col = int(st.n_cols)
-            ll[:, col] = ctx.ll_theta(VIEW_ALL, self.parameters[[new_id]],
+            ll[:, col] = ctx.ll_theta(view, self.parameters[[new_id]],
                 self.FP, self.FN)[:, 0]
             col_id[col] = new_id
             col_size[col] = 1
@@ -403,17 +449,9 @@ class CRP:
             st.n_active += 1
             st.n_cols += 1
             assignment[cell] = new_id
-        _lib.rng_import(rng, extra)
-        if timing:
-            t_end = time.perf_counter()
-            print(f'[bnpc] gibbs N={N} K={K}->{st.n_active}: ll matrix+D2H '
-                f'{t_ll - t_start:.3f}s, sweep {t_end - t_ll:.3f}s '
-                f'({st.n_cols - K} clusters opened)', flush=True)
-
-        self.assignment = assignment
+            n_new += 1
         live = order[:st.n_active]
-        self.cells_per_cluster = {
-            int(col_id[c]): int(col_size[c]) for c in live}
+        return rng, extra, col_id[live].copy(), col_size[live].copy(), n_new
 
     def init_new_cluster(self, cell_id):
         """libs/CRP.py:291-294"""

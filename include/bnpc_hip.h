@@ -161,8 +161,8 @@ int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out);
  * order of the reference's cells_per_cluster dict (a cluster that loses its
  * last cell is deleted; a cluster opened later is appended).
  *
- * The function processes perm[pos..N) and returns 0 when
- *   - the sweep is complete: st->pos == st->n_cells, st->new_cell == -1, or
+ * The function processes perm[pos..pos_end) and returns 0 when
+ *   - the window is complete: st->pos == st->pos_end, st->new_cell == -1, or
  *   - the cell perm[st->pos - 1] drew a NEW cluster: st->new_cell == that
  *     cell.  The cell has already been removed from its old cluster.  The
  *     caller opens the cluster in Python (lowest free id, Beta draws on the
@@ -178,11 +178,15 @@ typedef struct bnpc_gibbs_state {
     int64_t n_active;   /* live clusters = entries of order[] */
     int64_t pos;        /* next position of perm to process */
     int64_t new_cell;   /* out: cell that drew a new cluster, else -1 */
+    int64_t pos_end;    /* process perm[pos..pos_end) (N for a whole sweep) */
+    int64_t row_base;   /* -1: row of ll = cell id (whole matrix resident);
+                           >= 0: row of ll = position in perm - row_base (the
+                           matrix of one permutation-ordered tile of cells) */
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                      const int64_t *perm,      /* N visiting order */
-                     const double *ll,         /* N x ld, row = cell id */
+                     const double *ll,         /* rows x ld, see row_base */
                      const double *post_new,   /* N new-cluster log posterior */
                      const double *crp_prior,  /* N+2 log prior by size */
                      int64_t *assignment,      /* N cluster ids, in/out */

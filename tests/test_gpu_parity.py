@@ -303,6 +303,16 @@ def test_gibbs_sweeps_match_oracle(kind):
     H.test_gibbs_sweeps_match_oracle(kind)
 
 
+def test_tiled_sweep_on_device(monkeypatch):
+    monkeypatch.setenv('BNPC_SWEEP_BYTES', '30000')
+    H.test_gibbs_sweeps_match_oracle('learn')
+    H.test_gibbs_opens_many_clusters_in_one_sweep()
+    data = H.synth(0, 1000, 200, 10, 0.10)
+    ro = H.run_chain(H.make(O, 'fixed', data), 9, 42)
+    rp = H.run_chain(H.make(P, 'fixed', data), 9, 42)
+    assert np.array_equal(ro['assignments'], rp['assignments'])
+
+
 def test_update_parameters_and_errors_match_oracle():
     H.test_update_parameters_and_errors_match_oracle()
 

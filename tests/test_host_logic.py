@@ -93,6 +93,27 @@ def test_mt19937_long_run_and_big_permutation():
 
 
 # ----------------------------------------------------------- single moves
+@pytest.mark.parametrize('budget', [None, '30000'])
+def test_tiled_sweep_equals_whole_matrix_sweep(budget, monkeypatch):
+    """BNPC_SWEEP_BYTES: a sweep whose N x K matrix exceeds the budget is
+    tiled over permutation-ordered cell chunks (each tile only against the
+    clusters alive at its start); decisions and draws do not change."""
+    if budget:
+        monkeypatch.setenv('BNPC_SWEEP_BYTES', budget)
+    else:
+        monkeypatch.delenv('BNPC_SWEEP_BYTES', raising=False)
+    test_gibbs_sweeps_match_oracle('learn')
+    test_gibbs_opens_many_clusters_in_one_sweep()
+    if budget:
+        data = synth(1, 150, 70, 4, 0.15)
+        p = make(P, 'fixed', data)
+        np.random.seed(11)
+        p.init()
+        np.random.seed(1)
+        p.update_assignments_Gibbs()
+        assert p._ctx.calls['view_set'] >= 3      # several tiles were used
+
+
 @pytest.mark.parametrize('kind', ['fixed', 'learn'])
 def test_gibbs_sweeps_match_oracle(kind):
     data = synth(1, 150, 70, 4, 0.15)
@@ -307,7 +328,7 @@ def test_gibbs_opens_many_clusters_in_one_sweep():
 def test_native_sweep_rejects_corrupt_state():
     lib = _lib.load()
     N, ld = 4, 3
-    st = _lib.GibbsState(N, ld, 1, 1, 0, -1)
+    st = _lib.GibbsState(N, ld, 1, 1, 0, -1, N, -1)
     rng, _ = _lib.rng_export()
     i64, f64 = C.c_int64, C.c_double
     perm = np.arange(N, dtype=np.int64)
