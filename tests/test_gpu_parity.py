@@ -466,3 +466,75 @@ def test_cli_two_chains_in_pool_workers(golden_dir, tmp_path):
     assert 'secs. per MCMC step' in res.stdout
     with open(os.path.join(str(tmp_path), 'assignment.txt')) as f:
         assert len(f.read().strip().splitlines()) == 3
+
+
+def test_linearity_and_erasure_properties():
+    """The device sum is linear in the tables, and erasing observations
+    (0/1 -> missing) removes exactly their terms."""
+    rng = np.random.RandomState(21)
+    N, M, K = 700, 333, 5
+    data = (rng.random_sample((N, M)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.1] = np.nan
+    A1, A0 = -rng.random_sample((K, M)) * 5, -rng.random_sample((K, M))
+    B1, B0 = -rng.random_sample((K, M)) * 2, -rng.random_sample((K, M)) * 7
+    ctx = _lib.Context(data=data)
+    a = ctx.ll_tables(0, A1, A0)
+    b = ctx.ll_tables(0, B1, B0)
+    ab = ctx.ll_tables(0, A1 + B1, A0 + B0)
+    np.testing.assert_allclose(ab, a + b, rtol=1e-12)
+    # scaling by a power of two is exact in floating point
+    assert np.array_equal(ctx.ll_tables(0, 4 * A1, 4 * A0), 4 * a)
+    # erase 15 % of the observations
+    erase = (rng.random_sample(data.shape) < 0.15) & ~np.isnan(data)
+    erased = data.copy()
+    erased[erase] = np.nan
+    ctx2 = _lib.Context(data=erased)
+    a2 = ctx2.ll_tables(0, A1, A0)
+    for k in range(K):
+        gone = np.where(erase & (data == 1), A1[k], 0.0) \
+            + np.where(erase & (data == 0), A0[k], 0.0)
+        np.testing.assert_allclose(a[:, k] - a2[:, k], gone.sum(axis=1),
+            rtol=1e-9, atol=1e-9)
+    # erasing everything leaves empty sums
+    ctx3 = _lib.Context(data=np.full((N, M), np.nan))
+    assert not ctx3.ll_tables(0, A1, A0).any()
+    n1, n0 = ctx3.colcounts([np.arange(N)])
+    assert not n1.any() and not n0.any()
+    for c in (ctx, ctx2, ctx3):
+        c.close()
+
+
+def test_full_size_properties_50000x5000():
+    """Config 5 shape (50000 x 5000, 20 % missing): the largest BASELINE
+    size, K = 512 clusters; sampled oracle rows + size-independent
+    properties."""
+    N, M, K = 50000, 5000, 512
+    data = H.synth(0, N, M, 50, 0.20)
+    rng = np.random.RandomState(2)
+    theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    FP, FN = 0.01, 0.2
+    ctx = _lib.Context(data=data)
+    ll = ctx.ll_theta(0, theta, FP, FN)
+    assert ll.shape == (N, K) and np.all(np.isfinite(ll))
+    rows = rng.choice(N, 6, replace=False)
+    cols = rng.choice(K, 16, replace=False)
+    np.testing.assert_allclose(ll[np.ix_(rows, cols)],
+        oracle_ll(data[rows], theta[cols], FP, FN), rtol=1e-12)
+    n1c, n0c = ctx.cell_counts()
+    assert np.array_equal(n1c[rows], (data[rows] == 1).sum(axis=1))
+    # a gathered tile of cells in any order gives the same rows
+    tile = rng.permutation(N)[:3000]
+    ctx.view_set(1, tile)
+    np.testing.assert_allclose(ctx.ll_theta(1, theta[:96], FP, FN),
+        ll[tile, :96], rtol=1e-14)
+    # flat total == sum of the assigned entries; counts partition the cells
+    assign = rng.randint(0, K, N)
+    n1, n0 = ctx.colcounts_by_label(assign, np.arange(K))
+    tot = ctx.ll_total(theta, [FP], [FN])[0]
+    np.testing.assert_allclose(tot, ll[np.arange(N), assign].sum(), rtol=1e-11)
+    a1, a0 = ctx.colcounts([np.arange(N)])
+    assert np.array_equal(n1.sum(axis=0), a1[0])
+    assert np.array_equal(a1[0] + a0[0] + np.isnan(data).sum(axis=0),
+        np.full(M, N))
+    ctx.close()
