@@ -25,8 +25,6 @@ cpu_baseline: the CPU oracle (NumPy restatement of the reference, 1 core)
 stepping from the SAME post-warm-up state, on rank 0 at N = 1 only.
 """
 import argparse
-import contextlib
-import io
 import json
 import os
 import sys
@@ -178,7 +176,6 @@ def main():
     rank, world = ranks.rank, ranks.world
     os.environ['BNPC_DEVICE'] = str(ranks.device)
 
-    from bnpc_amd import _lib
     import libs.CRP as dev_fixed
     import libs.CRP_learning_errors as dev_learn
 

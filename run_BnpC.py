@@ -17,8 +17,6 @@ import argparse
 from datetime import datetime
 import os
 
-import numpy as np
-
 VERSION = '0.2.1'
 
 

@@ -16,7 +16,7 @@ import pytest
 from oracle import crp_numpy as O
 from bnpc_amd import _lib, model as P
 from bnpc_amd.mcmc import MCMC
-from fake_device import FakeContext, attach
+from fake_device import FakeContext
 
 
 def synth(seed, N, M, C_, miss, FP_true=0.001, FN_true=0.1):
