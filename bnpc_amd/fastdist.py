@@ -15,7 +15,16 @@ accepted, which lets the caller evaluate all clusters of a step at once.
 import numpy as np
 from scipy.stats import beta as _beta, truncnorm as _truncnorm
 
-_state = {'checked': False, 'fast': False}
+try:        # SciPy's own building blocks of truncnorm (private module)
+    from scipy.stats import _continuous_distns as _cd
+    import scipy.special as _sc
+    _HAVE_PARTS = all(hasattr(_cd, n) for n in
+        ('_log_gauss_mass', '_log_sum', '_norm_logcdf', '_norm_logpdf')) \
+        and hasattr(_sc, 'ndtri_exp')
+except Exception:           # pragma: no cover
+    _HAVE_PARTS = False
+
+_state = {'checked': False, 'fast': False, 'shared': False}
 
 
 # -- direct forms ------------------------------------------------------------
@@ -37,6 +46,37 @@ def _beta_logpdf_direct(x, p, q):
     xs = np.asarray(x, dtype=np.float64)
     out = _beta._logpdf(xs, p, q)
     outside = ~((0 < xs) & (xs < 1))
+    if outside.any():
+        out = np.array(out, dtype=np.float64)
+        out[outside] = -np.inf
+    return out
+
+
+# -- composed forms: the Gaussian mass of (a, b) is evaluated ONCE and shared
+#    by the proposal's ppf and its forward log-density (scipy's _ppf and
+#    _logpdf each recompute it) --------------------------------------------
+def _tn_mass(a, b):
+    return _cd._log_gauss_mass(a, b)
+
+
+def _tn_ppf_shared(q, a, b, loc, scale, lgm):
+    q, a, b, lgm = np.broadcast_arrays(q, a, b, lgm)
+    left = a < 0
+    out = np.empty_like(q)
+    if left.any():
+        out[left] = _sc.ndtri_exp(_cd._log_sum(_cd._norm_logcdf(a[left]),
+            np.log(q[left]) + lgm[left]))
+    right = ~left
+    if right.any():
+        out[right] = -_sc.ndtri_exp(_cd._log_sum(_cd._norm_logcdf(-b[right]),
+            np.log1p(-q[right]) + lgm[right]))
+    return out * scale + loc
+
+
+def _tn_logpdf_shared(x, a, b, loc, scale, lgm):
+    xs = np.asarray((x - loc) / scale, dtype=np.float64)
+    out = _cd._norm_logpdf(xs) - lgm - np.log(scale)
+    outside = ~((a <= xs) & (xs <= b))
     if outside.any():
         out = np.array(out, dtype=np.float64)
         out[outside] = -np.inf
@@ -102,8 +142,19 @@ def selfcheck():
                 _beta_logpdf_public(xs.reshape(1, -1), p, q),
                 _beta_logpdf_direct(xs.reshape(1, -1), p, q))
         _state['fast'] = bool(ok)
+        if ok and _HAVE_PARTS:
+            with np.errstate(all='ignore'):
+                lgm = _tn_mass(a, b)
+                shared = np.array_equal(
+                    _tn_ppf_shared(U, a, b, old, std, lgm),
+                    _tn_ppf_public(U, a, b, old, std))
+                shared &= np.array_equal(
+                    _tn_logpdf_shared(new, a, b, old, std, lgm),
+                    _tn_logpdf_public(new, a, b, old, std))
+            _state['shared'] = bool(shared)
     except Exception:
         _state['fast'] = False
+        _state['shared'] = False
     return _state['fast']
 
 
@@ -126,3 +177,17 @@ def beta_logpdf(x, p, q):
     if selfcheck():
         return _beta_logpdf_direct(x, p, q)
     return _beta_logpdf_public(x, p, q)
+
+
+def tn_propose(U, a, b, loc, scale):
+    """The proposal draw and its forward log-density in one go:
+    x = truncnorm.rvs(...) from its uniforms U, and a function giving
+    truncnorm.logpdf(y, a, b, loc, scale) for that same (a, b) - the Gaussian
+    mass of the interval is computed once.  Bit-identical to the public API
+    (self-checked); falls back to two independent evaluations otherwise."""
+    if selfcheck() and _state['shared']:
+        lgm = _tn_mass(a, b)
+        x = _tn_ppf_shared(U, a, b, loc, scale, lgm)
+        return x, (lambda y: _tn_logpdf_shared(y, a, b, loc, scale, lgm))
+    x = tn_rvs_from_uniform(U, a, b, loc, scale)
+    return x, (lambda y: tn_logpdf(y, a, b, loc, scale))

@@ -496,11 +496,11 @@ class CRP:
             lu[g] = np.random.random(M)
         a = (TMIN - old) / std
         b = (TMAX - old) / std
-        new = fastdist.tn_rvs_from_uniform(U, a, b, old, std) \
-            .astype(np.float32)
+        draw, fwd_logpdf = fastdist.tn_propose(U, a, b, old, std)
+        new = draw.astype(np.float32)
 
         A = self._get_log_A(new, old, None, a, b, std, trans_prob,
-            counts=counts)
+            counts=counts, fwd=fwd_logpdf(new))
         decline = np.log(lu) >= A
         new[decline] = old[decline]
         if trans_prob:
@@ -522,11 +522,13 @@ class CRP:
         return new[0], prob[0], declined[0]
 
     def _get_log_A(self, new_params, old_params, cells, a, b, std, clip=False,
-                counts=None):
-        """libs/CRP.py:347-383 (any leading batch dimension)"""
+                counts=None, fwd=None):
+        """libs/CRP.py:347-383 (any leading batch dimension); `fwd` may carry
+        the forward proposal log-density if the caller already has it."""
         if counts is None:
             counts = self._counts_of(cells)
-        fwd = fastdist.tn_logpdf(new_params, a, b, old_params, std)
+        if fwd is None:
+            fwd = fastdist.tn_logpdf(new_params, a, b, old_params, std)
         a_rev = (TMIN - new_params) / std
         b_rev = (TMAX - new_params) / std
         rev = fastdist.tn_logpdf(old_params, a_rev, b_rev, new_params, std)
