@@ -14,6 +14,7 @@ accepted, which lets the caller evaluate all clusters of a step at once.
 """
 import numpy as np
 from scipy.stats import beta as _beta, truncnorm as _truncnorm
+from scipy.stats import gamma as _gamma
 
 try:        # SciPy's own building blocks of truncnorm (private module)
     from scipy.stats import _continuous_distns as _cd
@@ -50,6 +51,13 @@ def _beta_logpdf_direct(x, p, q):
         out = np.array(out, dtype=np.float64)
         out[outside] = -np.inf
     return out
+
+
+def _gamma_logpdf_direct(x, a, loc, scale):
+    xs = np.asarray((x - loc) / scale, dtype=np.float64)
+    if not np.all(xs > 0):
+        return _gamma.logpdf(x, a, loc=loc, scale=scale)
+    return _gamma._logpdf(xs, a) - np.log(scale)
 
 
 # -- composed forms: the Gaussian mass of (a, b) is evaluated ONCE and shared
@@ -141,6 +149,15 @@ def selfcheck():
             ok &= np.array_equal(
                 _beta_logpdf_public(xs.reshape(1, -1), p, q),
                 _beta_logpdf_direct(xs.reshape(1, -1), p, q))
+        # scalar arguments (error-rate and concentration priors)
+        for x, lo, sc_ in ((0.013, 0.01, 0.01), (0.19, 0.2, 0.1),
+                (0.0004, 0.001, 0.0005)):
+            aa, bb = (0 - lo) / sc_, (1 - lo) / sc_
+            ok &= bool(_tn_logpdf_public(x, aa, bb, lo, sc_)
+                == _tn_logpdf_direct(x, aa, bb, lo, sc_))
+        for x, aa, lo in ((70.7, 70.71, 1), (3.2, 2.5, 0.5), (31.0, 31.6, 1)):
+            ok &= bool(_gamma.logpdf(x, aa, loc=lo, scale=1)
+                == _gamma_logpdf_direct(x, aa, lo, 1))
         _state['fast'] = bool(ok)
         if ok and _HAVE_PARTS:
             with np.errstate(all='ignore'):
@@ -177,6 +194,12 @@ def beta_logpdf(x, p, q):
     if selfcheck():
         return _beta_logpdf_direct(x, p, q)
     return _beta_logpdf_public(x, p, q)
+
+
+def gamma_logpdf(x, a, loc=0, scale=1):
+    if selfcheck():
+        return _gamma_logpdf_direct(x, a, loc, scale)
+    return _gamma.logpdf(x, a, loc=loc, scale=scale)
 
 
 def tn_propose(U, a, b, loc, scale):

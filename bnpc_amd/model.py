@@ -323,7 +323,10 @@ class CRP:
     def get_lprior_full(self):
         """libs/CRP.py:241-251"""
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
-        lprior = self.DP_a_prior.logpdf(self.DP_a) \
+        # Gamma(*DP_a_gamma): scipy reads the pair as (shape, loc), as in the
+        # reference (libs/CRP.py:55)
+        shape, loc = self.DP_a_gamma[0], self.DP_a_gamma[1]
+        lprior = fastdist.gamma_logpdf(self.DP_a, shape, loc) \
             + np.cumsum(self.CRP_prior[sizes])[-1]
         if not self.beta_prior_uniform:
             ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
@@ -928,7 +931,14 @@ class CRP_errors_learning(CRP):
     def get_lprior_full(self):
         """libs/CRP_learning_errors.py:47-49"""
         return super().get_lprior_full() \
-            + self.FP_prior.logpdf(self.FP) + self.FN_prior.logpdf(self.FN)
+            + self._error_prior_logpdf('FP', self.FP) \
+            + self._error_prior_logpdf('FN', self.FN)
+
+    def _error_prior_logpdf(self, which, x):
+        """FP_prior.logpdf / FN_prior.logpdf without the frozen wrapper."""
+        a, b, mean, sd = (self.FP_prior if which == 'FP'
+            else self.FN_prior).args
+        return fastdist.tn_logpdf(x, a, b, mean, sd)
 
     def update_error_rates(self):
         """libs/CRP_learning_errors.py:52-55"""
@@ -944,9 +954,9 @@ class CRP_errors_learning(CRP):
         """libs/CRP_learning_errors.py:66-111; the new/old likelihood pair is
         ONE launch over the resident per-cluster counts."""
         if error_type == 'FP':
-            old, prior, sds = self.FP, self.FP_prior, self.FP_sd
+            old, sds = self.FP, self.FP_sd
         else:
-            old, prior, sds = self.FN, self.FN_prior, self.FN_sd
+            old, sds = self.FN, self.FN_sd
 
         std = np.random.choice(sds)
         a = (0 - old) / std
@@ -956,17 +966,17 @@ class CRP_errors_learning(CRP):
         except FloatingPointError:
             new = truncnorm.rvs(a, np.inf, loc=old, scale=std)
 
-        fwd = truncnorm.logpdf(new, a, b, loc=old, scale=std)
-        rev = truncnorm.logpdf(old, (0 - new) / std, (1 - new) / std,
-            loc=new, scale=std)
+        fwd = fastdist.tn_logpdf(new, a, b, old, std)
+        rev = fastdist.tn_logpdf(old, (0 - new) / std, (1 - new) / std, new,
+            std)
 
         if error_type == 'FP':
             new_ll, old_ll = self._ll_total([new, old], [self.FN, self.FN])
         else:
             new_ll, old_ll = self._ll_total([self.FP, self.FP], [new, old])
 
-        A = new_ll + prior.logpdf(new) - old_ll - prior.logpdf(old) \
-            + rev - fwd
+        A = new_ll + self._error_prior_logpdf(error_type, new) - old_ll \
+            - self._error_prior_logpdf(error_type, old) + rev - fwd
         if np.log(np.random.random()) < A:
             return new, [1, 0]
         return old, [0, 1]
