@@ -46,6 +46,24 @@ TMIN = 1e-5
 TMAX = 1 - TMIN
 log_EPSILON = np.log(EPSILON)
 
+_THREAD_MIN_ELEMS = 1 << 17     # below this NumPy call overhead dominates
+_POOL = {}
+
+
+def _host_pool():
+    """Thread pool for large elementwise host batches (BNPC_HOST_THREADS,
+    default min(8, cores); 1 disables).  Created per process, after fork."""
+    pid = os.getpid()
+    if _POOL.get('pid') != pid:
+        n = int(os.environ.get('BNPC_HOST_THREADS',
+            min(8, os.cpu_count() or 1)))
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.clear()
+        _POOL.update(pid=pid,
+            pool=ThreadPoolExecutor(max_workers=n) if n > 1 else None)
+    return _POOL['pool']
+
+
 VIEW_ALL = 0      # identity view: all cells
 VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
 VIEW_ONE = 2      # a single cell (get_lpost_single)
@@ -497,21 +515,45 @@ class CRP:
             std[g] = np.random.choice(self.param_proposal_sd, size=M)
             U[g] = np.random.uniform(size=M)
             lu[g] = np.random.random(M)
-        a = (TMIN - old) / std
-        b = (TMAX - old) / std
-        draw, fwd_logpdf = fastdist.tn_propose(U, a, b, old, std)
-        new = draw.astype(np.float32)
-
-        A = self._get_log_A(new, old, None, a, b, std, trans_prob,
-            counts=counts, fwd=fwd_logpdf(new))
-        decline = np.log(lu) >= A
-        new[decline] = old[decline]
+        n1, n0 = counts
+        pool = _host_pool() if G * M >= _THREAD_MIN_ELEMS and G > 1 else None
+        if pool is None:
+            new, A, decline = self._mh_math(old, std, U, lu, n1, n0,
+                trans_prob)
+        else:
+            # large batches (first steps, config 4/5): the per-element SciPy
+            # math of row blocks runs on host threads (ufuncs release the
+            # GIL); elementwise, so the values do not depend on the split
+            edges = np.linspace(0, G, min(G, pool._max_workers) + 1,
+                dtype=int)
+            parts = list(pool.map(
+                lambda lo_hi: self._mh_math(*(x[lo_hi[0]:lo_hi[1]] for x in
+                    (old, std, U, lu, n1, n0)), trans_prob),
+                zip(edges[:-1], edges[1:])))
+            new, A, decline = (np.concatenate([p[i] for p in parts])
+                for i in range(3))
         if trans_prob:
-            A[decline] = np.log(-1 * np.expm1(A[decline]))
             prob = np.cumsum(A, axis=1)[:, -1]
         else:
             prob = np.full(G, np.nan)
         return new, prob, decline.sum(axis=1)
+
+    def _mh_math(self, old, std, U, lu, n1, n0, trans_prob):
+        """Proposal, log acceptance ratio and accept/decline of a block of
+        clusters (no random draws in here)."""
+        with np.errstate(divide='raise', over='ignore', under='ignore',
+                invalid='raise'):       # error state is per thread
+            a = (TMIN - old) / std
+            b = (TMAX - old) / std
+            draw, fwd_logpdf = fastdist.tn_propose(U, a, b, old, std)
+            new = draw.astype(np.float32)
+            A = self._get_log_A(new, old, None, a, b, std, trans_prob,
+                counts=(n1, n0), fwd=fwd_logpdf(new))
+            decline = np.log(lu) >= A
+            new[decline] = old[decline]
+            if trans_prob:
+                A[decline] = np.log(-1 * np.expm1(A[decline]))
+        return new, A, decline
 
     def MH_cluster_params(self, old_params, cells, trans_prob=False,
                 counts=None):

@@ -348,3 +348,31 @@ def test_native_sweep_rejects_corrupt_state():
         _lib.ptr(col_id, i64), _lib.ptr(col_size, i64), _lib.ptr(order, i64),
         _lib.ptr(scratch, f64))
     assert rc != 0 and b'unknown cluster' in lib.bnpc_last_error()
+
+
+def test_threaded_host_batches_are_bit_identical(monkeypatch):
+    """Large (clusters x mutations) proposal batches are evaluated on host
+    threads; elementwise math, so the split must not change a bit."""
+    data = synth(8, 300, 120, 3, 0.1)
+    outs = []
+    for threads, min_elems in (('1', 1 << 30), ('4', 1)):
+        monkeypatch.setenv('BNPC_HOST_THREADS', threads)
+        monkeypatch.setattr(P, '_THREAD_MIN_ELEMS', min_elems)
+        P._POOL.clear()
+        p = make(P, 'fixed', data)
+        np.random.seed(2)
+        p.init()                        # ~190 clusters
+        np.random.seed(3)
+        res = p.update_parameters()
+        ids = list(p.cells_per_cluster)
+        outs.append((res, p.parameters[ids].copy(), np.random.random()))
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+    o = make(O, 'fixed', data)
+    np.random.seed(2)
+    o.init()
+    np.random.seed(3)
+    assert o.update_parameters() == outs[1][0]
+    assert np.array_equal(o.parameters[ids], outs[1][1])
+    P._POOL.clear()
