@@ -49,6 +49,8 @@ SIGNATURES = {
     'bnpc_view_size': (C.c_int, [_ctx, C.c_int, _pi64]),
     'bnpc_ll_theta': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
         C.c_double, _pd, _i64]),
+    'bnpc_ll_theta_pinned': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
+        C.c_double, _i64, C.POINTER(_pd)]),
     'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
     'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
     'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
@@ -230,6 +232,21 @@ class Context:
         check(self._lib.bnpc_ll_theta(self._h, view, ptr(theta, C.c_float), K,
             float(FP), float(FN), po, ld), 'll_theta')
         return out
+
+    def ll_theta_pinned(self, view, theta, FP, FN, ld):
+        """(slots x ld) float64 NumPy VIEW of the context's pinned host
+        buffer holding the log-likelihoods in columns [0, K); valid until the
+        next pinned call on this context."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        K = theta.shape[0]
+        n = self.view_size(view)
+        host = _pd()
+        check(self._lib.bnpc_ll_theta_pinned(self._h, view,
+            ptr(theta, C.c_float), K, float(FP), float(FN), ld,
+            C.byref(host)), 'll_theta_pinned')
+        if n == 0:
+            return np.empty((0, ld))
+        return np.ctypeslib.as_array(host, shape=(n, ld))
 
     def ll_tables(self, view, L1, L0, out=None):
         L1 = np.ascontiguousarray(L1, dtype=np.float64)

@@ -99,9 +99,10 @@ struct bnpc_ctx {
     // resident per-cluster counts of the last bnpc_colcounts_by_label
     DevBuf lab_cnt;
     int64_t lab_K = 0;
-    // pinned staging for small D2H
+    // pinned host buffers: the sweep's ll matrix / small reductions
     void *pin = nullptr;
     size_t pin_cap = 0;
+    void *pin_small = nullptr;
     // configuration of the last k_ll launch (bnpc_bench_ll re-issues it)
     int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
@@ -734,6 +735,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
         if (v.masks.p) (void)hipFree(v.masks.p);
     if (c->rows) (void)hipFree(c->rows);
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_small) (void)hipHostFree(c->pin_small);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -966,6 +968,31 @@ extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
     return ll_common(c, view, K, ldo, true, FP, FN, out);
 }
 
+// Same as bnpc_ll_theta, but the result lands in a context-owned PINNED host
+// buffer (DMA straight from the device, no bounce through pageable staging)
+// that the caller reads - and may write - in place.
+extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
+                                    int64_t K, double FP, double FN,
+                                    int64_t ldo, double **host)
+{
+    ARGCHK(c && host, "NULL argument");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(K > 0 && theta, "theta is NULL");
+    if (ldo == 0) ldo = K;
+    ARGCHK(ldo >= K, "ldo smaller than K");
+    *host = nullptr;
+    int rc = bnpc_ll_theta(c, view, theta, K, FP, FN, nullptr, ldo);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
+    if (bytes == 0) return 0;
+    if (ensure_pin(c, bytes)) return 1;
+    HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *host = (double *)c->pin;
+    return 0;
+}
+
 extern "C" int bnpc_ll_tables(bnpc_ctx *c, int view, const double *L1,
                               const double *L0, int64_t K, double *out,
                               int64_t ldo)
@@ -1109,7 +1136,9 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
     const size_t bytes = (size_t)K * c->M * sizeof(float);
     if (ensure(c->theta, bytes)) return 1;
     if (ensure(c->partial, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
-    if (ensure_pin(c, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
+    if (!c->pin_small)
+        HIPCHK(hipHostMalloc(&c->pin_small, TOTAL_BLOCKS * 4 * sizeof(double),
+                             hipHostMallocDefault));
     HIPCHK(hipMemcpyAsync(c->theta.p, theta, bytes, hipMemcpyHostToDevice,
                           c->stream));
     double fp[4] = {0.5, 0.5, 0.5, 0.5}, fn[4] = {0.5, 0.5, 0.5, 0.5};
@@ -1124,11 +1153,11 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
                        (long long)(K * c->M), E, fp[0], fn[0], fp[1], fn[1],
                        fp[2], fn[2], fp[3], fn[3], (double *)c->partial.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->pin, c->partial.p,
+    HIPCHK(hipMemcpyAsync(c->pin_small, c->partial.p,
                           TOTAL_BLOCKS * 4 * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const double *p = (const double *)c->pin;
+    const double *p = (const double *)c->pin_small;
     for (int e = 0; e < E; e++) {
         double s = 0.0;
         for (int b = 0; b < TOTAL_BLOCKS; b++) s += p[b * 4 + e];

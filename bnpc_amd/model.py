@@ -418,8 +418,9 @@ class CRP:
             view, n_rows = VIEW_SWEEP, pos_end - pos
             ctx.view_set(VIEW_SWEEP, perm[pos:pos_end])
         ld = K + 16
-        ll = np.empty((n_rows, ld), dtype=np.float64)
-        ctx.ll_theta(view, self.parameters[ids], self.FP, self.FN, out=ll)
+        # pinned host buffer of the context: read (and extended) in place
+        ll = ctx.ll_theta_pinned(view, self.parameters[ids], self.FP, self.FN,
+            ld)
 
         col_of_id = np.full(N, -1, dtype=np.int64)
         col_of_id[ids] = np.arange(K)

@@ -89,6 +89,14 @@ int bnpc_view_size(const bnpc_ctx *ctx, int view, int64_t *n);
 int bnpc_ll_theta(bnpc_ctx *ctx, int view, const float *theta, int64_t K,
                   double FP, double FN, double *out, int64_t ldo);
 
+/* bnpc_ll_theta into a context-owned PINNED host buffer: *host points at
+ * slots x ldo doubles (DMA target, no pageable bounce) that stay valid until
+ * the next *_pinned call on this context; the caller may
+ * write into it (columns K..ldo are free for clusters opened mid-sweep). */
+int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
+                         int64_t K, double FP, double FN, int64_t ldo,
+                         double **host);
+
 /* Same sums from caller-built element tables: L1[k,m] is the value an
  * observed 1 contributes, L0[k,m] an observed 0 (both K x M float64).  With
  * tables built by the caller's NumPy this reproduces the reference's sums bit

@@ -58,6 +58,11 @@ class FakeContext:
             return out
         return res
 
+    def ll_theta_pinned(self, view, theta, FP, FN, ld):
+        n = self.views[view].size
+        out = np.empty((n, ld))
+        return self.ll_theta(view, theta, FP, FN, out=out)
+
     def ll_tables(self, view, L1, L0, out=None):
         self._count('ll_tables')
         L1 = np.atleast_2d(np.asarray(L1, dtype=np.float64))

@@ -538,3 +538,23 @@ def test_full_size_properties_50000x5000():
     assert np.array_equal(a1[0] + a0[0] + np.isnan(data).sum(axis=0),
         np.full(M, N))
     ctx.close()
+
+
+def test_pinned_result_buffer():
+    rng = np.random.RandomState(4)
+    data = (rng.random_sample((500, 90)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    theta = np.clip(rng.uniform(size=(6, 90)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    ctx = _lib.Context(data=data)
+    want = ctx.ll_theta(0, theta, 0.01, 0.2)
+    view = ctx.ll_theta_pinned(0, theta, 0.01, 0.2, 6 + 16)
+    assert view.shape == (500, 22)
+    assert np.array_equal(view[:, :6], want)
+    view[:, 6] = 1.5                      # writable in place (new columns)
+    assert np.all(view[:, 6] == 1.5)
+    # the flat total uses its own staging: the pinned matrix stays intact
+    ctx.colcounts_by_label(rng.randint(0, 6, 500), np.arange(6))
+    ctx.ll_total(theta, [0.01], [0.2])
+    assert np.array_equal(view[:, :6], want)
+    ctx.close()
