@@ -173,35 +173,59 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const double *row = ll + (size_t)(st->row_base >= 0 ?
             st->pos - st->row_base : cell) * ld;
         int64_t top = 0;
+        double second = -INFINITY;          // largest entry that is not `top`
         for (int64_t a = 0; a < A; a++) {
             const int64_t c = order[a];
-            post[a] = row[c] + crp_prior[col_size[c]];
-            if (post[a] > post[top]) top = a;
+            const double v = row[c] + crp_prior[col_size[c]];
+            post[a] = v;
+            if (v > post[top]) {
+                second = post[top];
+                top = a;
+            } else if (a != top && v > second) {
+                second = v;
+            }
         }
         post[A] = post_new[cell];
-        if (post[A] > post[top]) top = A;
-
-        // _normalize_log_probs (CRP.py:88-100).  exp() is skipped where its
-        // result is known exactly: exp(d) == 0.0 for d < -746 (below the
-        // smallest subnormal), and every entry clipped at log(1e-15)
-        // contributes the same constant exp(LOG_EPS) - so a sweep over
-        // thousands of far-away clusters costs two flops per entry, with
-        // the same sums as evaluating every exponential.
-        const double ptop = post[top];
-        double tail = 0.0;
-        for (int64_t a = 0; a <= A; a++) {
-            if (a == top) continue;
-            const double d = post[a] - ptop;
-            if (d > -746.0) tail += exp(d);
+        if (post[A] > post[top]) {
+            second = post[top];
+            top = A;
+        } else if (A != top && post[A] > second) {
+            second = post[A];
         }
-        const double lnorm = log1p(tail);
-        // choice(p=): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, right)
+        if (A == 0) second = -INFINITY;
+
+        // _normalize_log_probs (CRP.py:88-100) + choice(p=): cdf = cumsum(p);
+        // cdf /= cdf[-1]; searchsorted(u, right).
+        const double ptop = post[top];
         double run = 0.0;
-        for (int64_t a = 0; a <= A; a++) {
-            const double v = post[a] - ptop - lnorm;
-            if (v <= LOG_EPS) run += EXP_LOG_EPS;
-            else run += exp(v > 0.0 ? 0.0 : v);
-            cdf[a] = run;
+        if (second - ptop < -39.0 - log((double)(A + 1))) {
+            // One cluster dominates: the tail sum of exponentials is below
+            // 2^-55, so log1p(tail) == tail < half an ulp of 1: the winner's
+            // probability is exp(-tail) == 1.0 exactly and every other entry
+            // sits below the floor log(1e-15) and is clipped to it.  No
+            // exponential has to be evaluated (the usual case once the
+            // clusters have separated), with bit-identical probabilities.
+            for (int64_t a = 0; a <= A; a++) {
+                run += (a == top) ? 1.0 : EXP_LOG_EPS;
+                cdf[a] = run;
+            }
+        } else {
+            // exp() is still skipped where its result is known exactly:
+            // exp(d) == 0.0 for d < -746 (below the smallest subnormal), and
+            // every entry clipped at log(1e-15) contributes exp(LOG_EPS).
+            double tail = 0.0;
+            for (int64_t a = 0; a <= A; a++) {
+                if (a == top) continue;
+                const double d = post[a] - ptop;
+                if (d > -746.0) tail += exp(d);
+            }
+            const double lnorm = log1p(tail);
+            for (int64_t a = 0; a <= A; a++) {
+                const double v = post[a] - ptop - lnorm;
+                if (v <= LOG_EPS) run += EXP_LOG_EPS;
+                else run += exp(v > 0.0 ? 0.0 : v);
+                cdf[a] = run;
+            }
         }
         const double total = cdf[A];
         const double u = mt_double(rng);
