@@ -103,3 +103,41 @@ def test_lugsail_mode_extends_chains_until_psrf_cutoff(monkeypatch):
         assert r['params'].shape[0] == steps - r['burn_in'] or \
             r['params'].shape[0] <= steps
         assert np.all(r['ML'] != 0)
+
+
+def test_runtime_mode_and_fixed_assignment(monkeypatch, tmp_path):
+    """-r (wall-clock termination, Chain_time, MCMC.py:395-440) and -fa
+    (a fixed assignment that is used and never updated, MCMC.py:96, 321)."""
+    from datetime import datetime, timedelta
+    from oracle import crp_numpy as O
+    monkeypatch.setattr(_lib, 'Context', FakeContext)
+    data = H.synth(10, 40, 25, 3, 0.1)
+
+    # runtime mode: traces are trimmed to the steps actually run
+    mcmc = MCMC(H.make(P, 'fixed', data), sm_prob=.2, dpa_prob=.25,
+        error_prob=0., sm_ratios=[.75, .25], sm_steps=2)
+    t0 = datetime.now()
+    run_var = (t0 + timedelta(seconds=1.5), t0 + timedelta(seconds=0.5))
+    mcmc.run(run_var, 5, 1, 0, '', True)
+    res = mcmc.get_results()[0]
+    n = res['ML'].size
+    assert 3 < n < 100000 and np.all(res['MAP'] != 0)
+    assert res['assignments'].shape == (n, 40)
+    assert res['burn_in'] == n - res['params'].shape[0] and res['burn_in'] > 0
+
+    # fixed assignment: product and oracle walk the same parameter trajectory
+    truth = list(np.random.RandomState(1).randint(0, 3, 40))
+    f = tmp_path / 'assign.txt'
+    f.write_text(' '.join(str(i) for i in truth))
+    outs = []
+    for mod in (O, P):
+        mcmc = MCMC(H.make(mod, 'learn', data), sm_prob=.33, dpa_prob=.25,
+            error_prob=.25, sm_ratios=[.75, .25], sm_steps=2)
+        mcmc.run((30, 10), 9, 1, 0, str(f), True)
+        outs.append(mcmc.get_results()[0])
+    o, p = outs
+    want = np.unique(truth, return_inverse=True)[1]
+    assert np.all(p['assignments'] == want) and np.all(o['assignments'] == want)
+    np.testing.assert_allclose(p['ML'], o['ML'], rtol=1e-9)
+    np.testing.assert_allclose(p['FN'], o['FN'], rtol=1e-9)
+    assert np.array_equal(p['params'], o['params'])
