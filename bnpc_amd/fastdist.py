@@ -64,20 +64,49 @@ def _gamma_logpdf_direct(x, a, loc, scale):
 #    by the proposal's ppf and its forward log-density (scipy's _ppf and
 #    _logpdf each recompute it) --------------------------------------------
 def _tn_mass(a, b):
+    """scipy's _log_gauss_mass(a, b).  When every interval straddles zero
+    (a <= 0 < b, its 'central' case: always true for proposals around a value
+    strictly inside the bounds) that is log1p(-ndtr(a) - ndtr(-b)) for all
+    elements - evaluated directly, without the per-case masks and the complex
+    scratch array; anything else goes to SciPy."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    if a.shape == b.shape and (a <= 0).all() and (b > 0).all():
+        return _sc.log1p(-_sc.ndtr(a) - _sc.ndtr(-b))
     return _cd._log_gauss_mass(a, b)
+
+
+def _log_sum(p, q):
+    """scipy's _log_sum(p, q) = logsumexp([p, q], axis=0) for two finite real
+    arrays, with the arithmetic of scipy.special._logsumexp spelled out (max
+    removed from the sum, log1p of the remaining exponential, log of the
+    multiplicity of the max) - the same ufuncs in the same order, without the
+    array-API plumbing.  Non-finite input goes to SciPy."""
+    if not (np.isfinite(p).all() and np.isfinite(q).all()):
+        return _cd._log_sum(p, q)
+    top = np.maximum(p, q)
+    tie = p == q
+    s = np.where(tie, 0.0, np.exp(np.minimum(p, q) - top))
+    m = np.where(tie, 2.0, 1.0)
+    return np.log1p(s) + np.log(m) + top
 
 
 def _tn_ppf_shared(q, a, b, loc, scale, lgm):
     q, a, b, lgm = np.broadcast_arrays(q, a, b, lgm)
     left = a < 0
     out = np.empty_like(q)
-    if left.any():
-        out[left] = _sc.ndtri_exp(_cd._log_sum(_cd._norm_logcdf(a[left]),
-            np.log(q[left]) + lgm[left]))
-    right = ~left
-    if right.any():
-        out[right] = -_sc.ndtri_exp(_cd._log_sum(_cd._norm_logcdf(-b[right]),
-            np.log1p(-q[right]) + lgm[right]))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        if left.all():
+            out = _sc.ndtri_exp(_log_sum(_cd._norm_logcdf(a),
+                np.log(q) + lgm))
+        else:
+            if left.any():
+                out[left] = _sc.ndtri_exp(_log_sum(
+                    _cd._norm_logcdf(a[left]), np.log(q[left]) + lgm[left]))
+            right = ~left
+            out[right] = -_sc.ndtri_exp(_log_sum(
+                _cd._norm_logcdf(-b[right]),
+                np.log1p(-q[right]) + lgm[right]))
     return out * scale + loc
 
 
