@@ -215,6 +215,8 @@ def tn_rvs_from_uniform(U, a, b, loc, scale):
 
 def tn_logpdf(x, a, b, loc, scale):
     if selfcheck():
+        if _state['shared'] and np.ndim(a) > 0:
+            return _tn_logpdf_shared(x, a, b, loc, scale, _tn_mass(a, b))
         return _tn_logpdf_direct(x, a, b, loc, scale)
     return _tn_logpdf_public(x, a, b, loc, scale)
 
