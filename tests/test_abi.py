@@ -55,3 +55,20 @@ def test_bad_arguments_return_errors_not_crashes():
     assert b'NULL' in lib.bnpc_last_error()
     with pytest.raises(RuntimeError, match='libbnpc_hip'):
         _lib.check(lib.bnpc_sync(None), 'sync')
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/bnpc_hip.h is a C header: it must compile with a C compiler."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'use_header.c'
+    src.write_text('#include "bnpc_hip.h"\n'
+        'int main(void) { bnpc_ctx *c = 0; bnpc_gibbs_state s; bnpc_mt19937 r;'
+        ' (void)c; (void)s; (void)r; return bnpc_abi_version ? 0 : 1; }\n')
+    res = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic',
+        '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
+        capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
