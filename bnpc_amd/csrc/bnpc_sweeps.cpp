@@ -143,6 +143,21 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 
     while (st->pos < st->pos_end) {
         const int64_t cell = perm[st->pos];
+        // rows are visited in permutation order: pull the row (and the
+        // per-cell scalars) of a cell a few positions ahead into the cache
+        if (st->pos + 6 < st->pos_end) {
+            const int64_t ahead = perm[st->pos + 6];
+            if (ahead >= 0 && ahead < N) {
+                const char *r = (const char *)(ll + (size_t)(
+                    st->row_base >= 0 ? st->pos + 6 - st->row_base : ahead)
+                    * ld);
+                const size_t bytes = (size_t)st->n_cols * sizeof(double);
+                for (size_t off = 0; off < bytes && off < 512; off += 64)
+                    __builtin_prefetch(r + off, 0, 1);
+                __builtin_prefetch(&assignment[ahead], 1, 1);
+                __builtin_prefetch(&post_new[ahead], 0, 1);
+            }
+        }
         if (cell < 0 || cell >= N) {
             bnpc_set_error("perm[%lld] out of range", (long long)st->pos);
             return 2;
