@@ -3,7 +3,7 @@
 configuration (config 3: synthetic 5,000 cells x 1,000 mutations, 20 % missing,
 learned error rates), one independent chain per GPU.
 
-    python bench.py --gpus 1 --steps 40 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -163,8 +163,8 @@ def load_pmc_traffic(kernel_substr):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--cpu-steps', type=int, default=12,
@@ -213,6 +213,8 @@ def main():
             rng=np.random.get_state())
 
     # ---- timed region: exactly K steps -----------------------------------
+    import gc
+    gc.collect()
     elapsed = timed_steps(ranks, lambda i: step(chain, i, burn),
         args.warmup + 1, total)
     K_end = len(model.cells_per_cluster)
