@@ -46,8 +46,19 @@ TMIN = 1e-5
 TMAX = 1 - TMIN
 log_EPSILON = np.log(EPSILON)
 
-_THREAD_MIN_ELEMS = 1 << 17     # below this NumPy call overhead dominates
+_THREAD_MIN_ELEMS = 1 << 14     # below this NumPy call overhead dominates
 _POOL = {}
+
+
+def _host_parts(elems, rows):
+    """Row blocks to evaluate an elementwise host batch in.  Measured on the
+    GPU box's host (tools/host_threads_ab.py): ~8k elements per thread is the
+    break-even, more than 4 threads only pay for >= 128k elements (the GIL is
+    held between ufunc calls)."""
+    if elems < _THREAD_MIN_ELEMS or rows < 2:
+        return 1
+    parts = 8 if elems >= (1 << 17) else min(4, max(1, elems // 8192))
+    return min(parts, rows)
 
 
 def _host_pool():
@@ -517,16 +528,18 @@ class CRP:
             U[g] = np.random.uniform(size=M)
             lu[g] = np.random.random(M)
         n1, n0 = counts
-        pool = _host_pool() if G * M >= _THREAD_MIN_ELEMS and G > 1 else None
-        if pool is None:
+        pool, n_parts = None, _host_parts(G * M, G)
+        if n_parts > 1:
+            pool = _host_pool()
+            n_parts = min(n_parts, pool._max_workers) if pool else 1
+        if pool is None or n_parts < 2:
             new, A, decline = self._mh_math(old, std, U, lu, n1, n0,
                 trans_prob)
         else:
             # large batches (first steps, config 4/5): the per-element SciPy
             # math of row blocks runs on host threads (ufuncs release the
             # GIL); elementwise, so the values do not depend on the split
-            edges = np.linspace(0, G, min(G, pool._max_workers) + 1,
-                dtype=int)
+            edges = np.linspace(0, G, n_parts + 1, dtype=int)
             parts = list(pool.map(
                 lambda lo_hi: self._mh_math(*(x[lo_hi[0]:lo_hi[1]] for x in
                     (old, std, U, lu, n1, n0)), trans_prob),

@@ -355,7 +355,7 @@ def test_threaded_host_batches_are_bit_identical(monkeypatch):
     threads; elementwise math, so the split must not change a bit."""
     data = synth(8, 300, 120, 3, 0.1)
     outs = []
-    for threads, min_elems in (('1', 1 << 30), ('4', 1)):
+    for threads, min_elems in (('1', 1 << 30), ('4', 1 << 13)):
         monkeypatch.setenv('BNPC_HOST_THREADS', threads)
         monkeypatch.setattr(P, '_THREAD_MIN_ELEMS', min_elems)
         P._POOL.clear()
