@@ -62,6 +62,8 @@ SIGNATURES = {
     'bnpc_sync': (C.c_int, [_ctx]),
     'bnpc_mt_random_sample': (C.c_double, [C.POINTER(MT19937)]),
     'bnpc_mt_permutation': (C.c_int, [C.POINTER(MT19937), _i64, _pi64]),
+    'bnpc_mt_mh_draws': (C.c_int, [C.POINTER(MT19937), _i64, _i64, _i64,
+        _pi32, _pd, _pd]),
     'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
     'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,
@@ -153,6 +155,64 @@ def codist(assignments, device=None):
     check(load().bnpc_codist(device, ptr(a, C.c_int32), S, N,
         ptr(out, C.c_int32)), 'codist')
     return out
+
+
+_live = {}
+
+
+def rng_live():
+    """Pointer to the MT19937 state of NumPy's global legacy RandomState, for
+    in-place draws from C (no get_state / set_state round trip), or None if
+    this NumPy does not expose it as expected (then callers exchange a copy).
+    Checked once per process against np.random.get_state()."""
+    pid = os.getpid()
+    if _live.get('pid') != pid:
+        _live.clear()
+        _live['pid'] = pid
+        _live['ptr'] = None
+        try:
+            bg = np.random.mtrand._rand._bit_generator
+            if type(bg).__name__ == 'MT19937':
+                p = C.cast(bg.ctypes.state_address, C.POINTER(MT19937))
+                kind, key, pos = np.random.get_state()[:3]
+                if kind == 'MT19937' and p.contents.pos == pos and \
+                        np.array_equal(np.frombuffer(p.contents.key,
+                            dtype=np.uint32), key):
+                    _live['ptr'] = p
+                    _live['bg'] = bg        # keep the owner alive
+        except Exception:
+            _live['ptr'] = None
+    return _live['ptr']
+
+
+class NumpyStream:
+    """`with NumpyStream() as rng:` yields a ctypes reference to the global
+    legacy stream for native draws: NumPy's own state in place when possible,
+    else a copy that is written back on exit."""
+
+    def __enter__(self):
+        self._ptr = rng_live()
+        if self._ptr is not None:
+            return self._ptr
+        self._copy, self._extra = rng_export()
+        return C.pointer(self._copy)
+
+    def __exit__(self, *exc):
+        if self._ptr is None:
+            rng_import(self._copy, self._extra)
+        return False
+
+
+def mh_draws(G, M, n_sd):
+    """(sd_idx int32 (G, M), U (G, M), u (G, M)): the per-cluster draws of
+    MH_cluster_params from the global stream, natively."""
+    sd_idx = np.empty((G, M), dtype=np.int32)
+    U = np.empty((G, M))
+    u = np.empty((G, M))
+    with NumpyStream() as rng:
+        check(load().bnpc_mt_mh_draws(rng, G, M, n_sd, ptr(sd_idx, C.c_int32),
+            ptr(U, C.c_double), ptr(u, C.c_double)), 'mh_draws')
+    return sd_idx, U, u
 
 
 class Context:

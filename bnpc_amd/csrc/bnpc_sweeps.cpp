@@ -109,6 +109,31 @@ extern "C" int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out)
     return 0;
 }
 
+// The three draws of MH_cluster_params (libs/CRP.py:328-335) for G clusters,
+// in the reference's per-cluster order:
+//   np.random.choice(sd, size=M)   = legacy randint(0, n_sd, M): masked
+//                                    rejection on 32-bit draws
+//   truncnorm.rvs(size=M)          : its M uniforms (random_state.uniform)
+//   np.random.random(M)
+extern "C" int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M,
+                                int64_t n_sd, int32_t *sd_idx, double *U,
+                                double *u)
+{
+    if (!rng || !sd_idx || !U || !u || n_sd < 1) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    for (int64_t g = 0; g < G; g++) {
+        int32_t *si = sd_idx + g * M;
+        double *Ug = U + g * M, *ug = u + g * M;
+        for (int64_t m = 0; m < M; m++)
+            si[m] = (int32_t)mt_interval(rng, (uint64_t)(n_sd - 1));
+        for (int64_t m = 0; m < M; m++) Ug[m] = 0.0 + 1.0 * mt_double(rng);
+        for (int64_t m = 0; m < M; m++) ug[m] = mt_double(rng);
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Gibbs sweep
 // ---------------------------------------------------------------------------

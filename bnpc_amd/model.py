@@ -391,20 +391,18 @@ class CRP:
         K_start = ids.size
 
         budget = int(os.environ.get('BNPC_SWEEP_BYTES', 256 << 20))
-        rng, extra = _lib.rng_export()
         pos, opened, tiles = 0, 0, 0
         while pos < N:
             K = ids.size
             rows_fit = max(64, budget // (8 * (K + 16)))
             whole = pos == 0 and rows_fit >= N
             pos_end = N if whole else min(N, pos + rows_fit)
-            rng, extra, ids, sizes, n_new = self._gibbs_window(
-                rng, extra, perm, pos, pos_end, whole, ids, sizes, assignment,
-                post_new, crp_prior)
+            ids, sizes, n_new = self._gibbs_window(
+                perm, pos, pos_end, whole, ids, sizes, assignment, post_new,
+                crp_prior)
             opened += n_new
             tiles += 1
             pos = pos_end
-        _lib.rng_import(rng, extra)
         if timing:
             print(f'[bnpc] gibbs N={N} K={K_start}->{ids.size}: '
                 f'{time.perf_counter() - t_start:.3f}s in {tiles} tile(s), '
@@ -414,11 +412,11 @@ class CRP:
         self.cells_per_cluster = {
             int(i): int(n) for i, n in zip(ids, sizes)}
 
-    def _gibbs_window(self, rng, extra, perm, pos, pos_end, whole, ids, sizes,
-                assignment, post_new, crp_prior):
+    def _gibbs_window(self, perm, pos, pos_end, whole, ids, sizes, assignment,
+                post_new, crp_prior):
         """Positions [pos, pos_end) of the sweep against the clusters `ids`
-        (dict order) with `sizes`.  Returns the stream state and the live
-        clusters (dict order) after the window."""
+        (dict order) with `sizes`.  Returns the live clusters (dict order)
+        after the window."""
         lib = _lib.load()
         ctx = self._dev()
         N = self.cells_total
@@ -448,20 +446,21 @@ class CRP:
         i64, f64 = C.c_int64, C.c_double
         n_new = 0
         while True:
-            _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), C.byref(rng),
-                _lib.ptr(perm, i64), _lib.ptr(ll, f64),
-                _lib.ptr(post_new, f64), _lib.ptr(crp_prior, f64),
-                _lib.ptr(assignment, i64), _lib.ptr(col_of_id, i64),
-                _lib.ptr(col_id, i64), _lib.ptr(col_size, i64),
-                _lib.ptr(order, i64), _lib.ptr(scratch, f64)), 'gibbs_sweep')
+            with _lib.NumpyStream() as rng:
+                _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), rng,
+                    _lib.ptr(perm, i64), _lib.ptr(ll, f64),
+                    _lib.ptr(post_new, f64), _lib.ptr(crp_prior, f64),
+                    _lib.ptr(assignment, i64), _lib.ptr(col_of_id, i64),
+                    _lib.ptr(col_id, i64), _lib.ptr(col_size, i64),
+                    _lib.ptr(order, i64), _lib.ptr(scratch, f64)),
+                    'gibbs_sweep')
             if st.new_cell < 0:
                 break
-            # open a new cluster for this cell (libs/CRP.py:281-282, 291-299)
+            # open a new cluster for this cell (libs/CRP.py:281-282, 291-299);
+            # its Beta draws continue the same stream
             cell = int(st.new_cell)
-            _lib.rng_import(rng, extra)
             new_id = int(np.flatnonzero(col_of_id < 0)[0])
             self.parameters[new_id] = self._init_cl_params_new([cell])
-            rng, extra = _lib.rng_export()
             if st.n_cols == ld:
                 grow = max(16, ld // 4)
                 ll = np.concatenate(
@@ -484,7 +483,7 @@ class CRP:
             assignment[cell] = new_id
             n_new += 1
         live = order[:st.n_active]
-        return rng, extra, col_id[live].copy(), col_size[live].copy(), n_new
+        return col_id[live].copy(), col_size[live].copy(), n_new
 
     def init_new_cluster(self, cell_id):
         """libs/CRP.py:291-294"""
@@ -520,13 +519,8 @@ class CRP:
         uniforms) -> random(M); the arithmetic in between does not draw, so
         it is hoisted out of the loop and batched."""
         G, M = old.shape
-        std = np.empty((G, M))
-        U = np.empty((G, M))
-        lu = np.empty((G, M))
-        for g in range(G):
-            std[g] = np.random.choice(self.param_proposal_sd, size=M)
-            U[g] = np.random.uniform(size=M)
-            lu[g] = np.random.random(M)
+        sd_idx, U, lu = _lib.mh_draws(G, M, self.param_proposal_sd.size)
+        std = self.param_proposal_sd[sd_idx]
         n1, n0 = counts
         pool, n_parts = None, _host_parts(G * M, G)
         if n_parts > 1:
@@ -797,11 +791,10 @@ class CRP:
         ll = np.ascontiguousarray(ll, dtype=np.float64)
         i64, f64 = C.c_int64, C.c_double
         if mode == 0:
-            rng, extra = _lib.rng_export()
-            _lib.check(lib.bnpc_rg_scan(C.byref(rng), 0, S, _lib.ptr(ll, f64),
-                float(self.DP_a), _lib.ptr(rg, i64), None, C.byref(out)),
-                'rg_scan')
-            _lib.rng_import(rng, extra)
+            with _lib.NumpyStream() as rng:
+                _lib.check(lib.bnpc_rg_scan(rng, 0, S, _lib.ptr(ll, f64),
+                    float(self.DP_a), _lib.ptr(rg, i64), None, C.byref(out)),
+                    'rg_scan')
         else:
             target = _lib.as_i64(target)
             _lib.check(lib.bnpc_rg_scan(None, 1, S, _lib.ptr(ll, f64),

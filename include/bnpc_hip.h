@@ -145,9 +145,12 @@ int bnpc_timer_stop(bnpc_ctx *ctx, float *ms);
 int bnpc_sync(bnpc_ctx *ctx);
 
 /* ---- native sequential sweeps (host side, exact legacy-MT19937 replica) ---
- * NumPy's legacy global stream (np.random.seed / get_state) is MT19937; the
- * state is exchanged with np.random.get_state() / set_state() so that Python
- * and C draw from ONE stream in the reference's order.
+ * NumPy's legacy global stream (np.random.seed / get_state) is MT19937; C
+ * and Python draw from ONE stream in the reference's order (SURVEY.md
+ * Appendix B).  bnpc_mt19937 has the layout of NumPy's own mt19937_state, so
+ * the binding passes the address of the global RandomState's state
+ * (bit_generator.ctypes.state_address) and the draws happen in place; a copy
+ * exchanged through np.random.get_state() / set_state() works as well.
  */
 typedef struct bnpc_mt19937 {
     uint32_t key[624];
@@ -159,6 +162,12 @@ double bnpc_mt_random_sample(bnpc_mt19937 *rng);
 /* np.random.permutation(n): arange + Fisher-Yates from the top with the
  * masked-rejection legacy random_interval on 32-bit draws */
 int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out);
+
+/* The three draws of CRP.MH_cluster_params (libs/CRP.py:328-335) for G
+ * clusters in the reference's per-cluster order: choice(sd, M) as indices
+ * 0..n_sd-1 (legacy randint), the M uniforms of truncnorm.rvs, random(M). */
+int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
+                     int32_t *sd_idx, double *U, double *u);
 
 /* The sequential per-cell loop of CRP.update_assignments_Gibbs
  * (libs/CRP.py:260-288, with _normalize_log_probs :88-100 and

@@ -242,3 +242,43 @@ def test_sweep_window_and_tile_rows():
         _lib.ptr(zi, i64), _lib.ptr(zi, i64), _lib.ptr(zi, i64),
         _lib.ptr(zi, i64), _lib.ptr(zi, i64), _lib.ptr(z, f64))
     assert rc != 0 and b'window' in lib.bnpc_last_error()
+
+
+def test_native_mh_draws_equal_numpy():
+    sd = np.array([0.1, 0.25, 0.5])
+    for seed, (G, M) in enumerate([(1, 1), (3, 100), (10, 1000), (2, 4097)]):
+        np.random.seed(seed)
+        want = [(np.random.choice(sd, size=M), np.random.uniform(size=M),
+            np.random.random(M)) for _ in range(G)]
+        tail = np.random.random(3)
+        np.random.seed(seed)
+        idx, U, u = _lib.mh_draws(G, M, 3)
+        assert np.array_equal(np.random.random(3), tail)   # same consumption
+        for g in range(G):
+            assert np.array_equal(sd[idx[g]], want[g][0])
+            assert np.array_equal(U[g], want[g][1])
+            assert np.array_equal(u[g], want[g][2])
+
+
+def test_stream_in_place_and_copy_fallback(monkeypatch):
+    """Native draws act on NumPy's own MT19937 state in place; if that
+    address is not available a copy is exchanged - same stream either way."""
+    lib = _lib.load()
+    assert _lib.rng_live() is not None
+    outs = []
+    for live in (True, False):
+        if not live:
+            monkeypatch.setattr(_lib, 'rng_live', lambda: None)
+        np.random.seed(77)
+        a = np.random.random()
+        with _lib.NumpyStream() as rng:
+            b = lib.bnpc_mt_random_sample(rng)
+            perm = np.empty(50, dtype=np.int64)
+            lib.bnpc_mt_permutation(rng, 50, _lib.ptr(perm, i64))
+        c = np.random.random()
+        outs.append((a, b, perm.tolist(), c))
+    assert outs[0] == outs[1]
+    np.random.seed(77)
+    ref = (np.random.random(), np.random.random(),
+        np.random.permutation(50).tolist(), np.random.random())
+    assert outs[0] == ref
