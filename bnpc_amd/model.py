@@ -702,8 +702,7 @@ class CRP:
         self._rg_init_split(cells)
         self.rg_params_merge = self._beta_draw(*self._rg_all_counts(cells))
         for _ in range(scan_no):
-            self._rg_scan_split(cells)
-            self._rg_scan_merge(cells)
+            self._rg_scan_both(cells)
         if move == 'split':
             return self._do_rg_split_MH(cells, size_data)
         return self._do_rg_merge_MH(cells, size_data)
@@ -765,6 +764,24 @@ class CRP:
         prob_par = self._rg_scan_params(cells, trans_prob)
         if trans_prob:
             return prob_cl + prob_par
+
+    def _rg_scan_both(self, cells):
+        """One intermediate scan of the launch states, = _rg_scan_split
+        followed by _rg_scan_merge (libs/CRP.py:535-537): the restricted
+        assignment scan, then the parameter updates of the two split clusters
+        and of the merged cluster.  No draw separates the three MH updates and
+        they do not depend on each other, so they are ONE batch (rows in the
+        reference's order i, j, merge)."""
+        if cells.size != 2:
+            self._rg_scan_assign(cells)
+        ci, cj = self._rg_split_counts(cells)
+        counts = (np.stack([ci[0], cj[0], ci[0] + cj[0]]),
+            np.stack([ci[1], cj[1], ci[1] + cj[1]]))
+        old = np.concatenate([self.rg_params_split,
+            self.rg_params_merge[None, :]])
+        new, _, _ = self._mh_batch(old, counts, False)
+        self.rg_params_split = new[:2]
+        self.rg_params_merge = new[2]
 
     def _rg_scan_merge(self, cells, trans_prob=False):
         """libs/CRP.py:581-587"""
