@@ -317,7 +317,8 @@ def main():
                 'chains': world, 'data_seed': 0, 'mcmc_seed': args.seed,
                 'K0': K0, 'K_after_warmup': K_warm, 'K_end': K_end,
             },
-            'first_step_s': round(first_step_s, 4),
+            'first_step_s': None if first_step_s is None
+                else round(first_step_s, 4),
             'ML_end': ml_end,
             'roofline': roofline,
             'cpu_baseline': cpu,
