@@ -302,8 +302,9 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         line = {
-            'metric': 'MCMC steps/s, 5k cells x 1k muts (+ cell x cluster '
-                'log-lik evals/s in ll_evals_per_s_K0)',
+            'metric': ('MCMC steps/s, 5k cells x 1k muts' if args.config == 'c3'
+                else f'MCMC steps/s, {N} cells x {M} muts')
+                + ' (+ cell x cluster log-lik evals/s in ll_evals_per_s_K0)',
             'value': round(value, 3), 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
