@@ -421,15 +421,23 @@ class CRP:
         ctx = self._dev()
         N = self.cells_total
         K = ids.size
+        tile_timing = os.environ.get('BNPC_TIMING') == '2'
+        if tile_timing:
+            import time
+            t0 = time.perf_counter()
         if whole:
             view, n_rows = VIEW_ALL, N
         else:
             view, n_rows = VIEW_SWEEP, pos_end - pos
             ctx.view_set(VIEW_SWEEP, perm[pos:pos_end])
         ld = K + 16
+        theta = self.parameters[ids]
+        if tile_timing:
+            t1 = time.perf_counter()
         # pinned host buffer of the context: read (and extended) in place
-        ll = ctx.ll_theta_pinned(view, self.parameters[ids], self.FP, self.FN,
-            ld)
+        ll = ctx.ll_theta_pinned(view, theta, self.FP, self.FN, ld)
+        if tile_timing:
+            t2 = time.perf_counter()
 
         col_of_id = np.full(N, -1, dtype=np.int64)
         col_of_id[ids] = np.arange(K)
@@ -483,6 +491,11 @@ class CRP:
             assignment[cell] = new_id
             n_new += 1
         live = order[:st.n_active]
+        if tile_timing:
+            t3 = time.perf_counter()
+            print(f'[bnpc]   tile [{pos},{pos_end}) K={K}: gather '
+                f'{t1 - t0:.3f}s  device+D2H {t2 - t1:.3f}s  sweep '
+                f'{t3 - t2:.3f}s', flush=True)
         return col_id[live].copy(), col_size[live].copy(), n_new
 
     def init_new_cluster(self, cell_id):
