@@ -790,6 +790,12 @@ extern "C" int bnpc_view_size(const bnpc_ctx *c, int view, int64_t *n)
     return 0;
 }
 
+static int env_flag(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 // clusters per wave: least padded work, weighted by the scalar-pipe overhead
 // that a wider tile amortises
 static int pick_kw(int64_t K)
@@ -814,9 +820,11 @@ static void pick_msplit(int64_t waves, int Mt, bool allowed, int *MS,
 {
     *MS = 1;
     *m_chunk = Mt;
-    if (!allowed || waves >= 4096) return;
-    int64_t want = (4096 + waves - 1) / waves;
-    if (want > 64) want = 64;
+    const int64_t target = env_flag("BNPC_MSPLIT_WAVES", 4096);
+    if (!allowed || waves >= target) return;
+    int64_t want = (target + waves - 1) / waves;
+    const int64_t cap = env_flag("BNPC_MSPLIT_MAX", 64);
+    if (want > cap) want = cap;
     int chunk = (int)((Mt + want - 1) / want);
     chunk = (chunk + 7) / 8 * 8;
     if (chunk < 16) chunk = 16;
@@ -827,11 +835,6 @@ static void pick_msplit(int64_t waves, int Mt, bool allowed, int *MS,
     }
 }
 
-static int env_flag(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 
 // the cells x clusters x mutations launch itself (tables are resident)
 template <int KW>
