@@ -421,24 +421,28 @@ template <int CB>
 __global__ __launch_bounds__(256) void k_ll8_asm(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
-    double *__restrict__ out, int xcd_remap)
+    double *__restrict__ out, int xcd_remap, int MS, int m_chunk)
 {
     constexpr int KW = 8;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     long long bx, g;
-    ll_tile_coords((unsigned)((nblk + 4 * CB - 1) / (4 * CB)),
+    ll_tile_coords((unsigned)((nblk + 4 * CB - 1) / (4 * CB)) * (unsigned)MS,
                    (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
+    const int ms = (int)(bx % MS);      // mutation chunk of this wave
+    bx /= MS;
     const long long blk0 = (bx * 4 + wave) * CB;
     if (blk0 >= nblk) return;
+    const int m_begin = ms * m_chunk;
+    const int m_len = ((m_begin + m_chunk < Mt) ? m_chunk : Mt - m_begin);
 
     // mask rows of the wave's CB blocks, as offsets from the one `masks` base
     // (a block past the end re-reads the wave's first block, never stored)
     size_t mo[CB];
 #pragma unroll
     for (int c = 0; c < CB; c++)
-        mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad;
-    const double *__restrict__ tp = T + (size_t)g * Mt * (2 * KW);
+        mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad + m_begin;
+    const double *__restrict__ tp = T + ((size_t)g * Mt + m_begin) * (2 * KW);
 
     double acc[CB][KW];
 #pragma unroll
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait
     // for the current stage FIRST, then issue the next stage's loads, then
     // the masked adds run under those loads.
-    for (int m = 0; m < Mt; m += 2) {           // Mt is a multiple of 8
+    for (int m = 0; m < m_len; m += 2) {        // chunks are multiples of 8
         __builtin_amdgcn_s_waitcnt(0xC07F);     // stage A landed
 #pragma unroll
         for (int c = 0; c < CB; c++) mb[c] = masks[mo[c] + m + 1];
@@ -478,7 +482,9 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     for (int c = 0; c < CB; c++) {
         const long long slot = (blk0 + c) * 64 + lane;
         if (blk0 + c < nblk && slot < n) {
-            double *o = out + (size_t)slot * ldo + (size_t)g * KW;
+            double *o = (MS > 1)
+                ? out + ((size_t)ms * n + slot) * K + (size_t)g * KW
+                : out + (size_t)slot * ldo + (size_t)g * KW;
 #pragma unroll
             for (int j = 0; j < KW; j++)
                 if (g * KW + j < K) o[j] = acc[c][j];
@@ -846,40 +852,36 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     ARGCHK(nwg < (1ll << 31), "launch too large");
     const int xcd = env_flag("BNPC_XCD_REMAP", 1);
     const int impl = env_flag("BNPC_LL_ASM", 2);    // 0 C++, 1 asm, 2 asm x2
-    if (KW == 8 && MS == 1 && impl == 2 && ((v.nblk + 7) / 8) * G >= 2048)
-        hipLaunchKernelGGL(k_ll8_asm<2>,
-                           dim3((unsigned)(((v.nblk + 7) / 8) * G)), dim3(256),
-                           0, c->stream, (const ulonglong2 *)v.masks.p,
-                           c->Mpad, c->Mt, (long long)v.n, (long long)v.nblk,
+    double *dst = d_out;
+    if (MS > 1) {
+        if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double))) return 1;
+        dst = (double *)c->part.p;
+    }
+    const int64_t wg2 = ((v.nblk + 7) / 8) * G * MS;
+    if (KW == 8 && impl == 2 && wg2 >= env_flag("BNPC_ASM2_MIN_WGS", 448))
+        hipLaunchKernelGGL(k_ll8_asm<2>, dim3((unsigned)wg2), dim3(256), 0,
+                           c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
+                           c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
-                           d_out, xcd);
-    else if (KW == 8 && MS == 1 && impl >= 1)
+                           dst, xcd, MS, m_chunk);
+    else if (KW == 8 && impl >= 1)
         hipLaunchKernelGGL(k_ll8_asm<1>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
-                           d_out, xcd);
-    else {
-        double *dst = d_out;
-        if (MS > 1) {
-            if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double)))
-                return 1;
-            dst = (double *)c->part.p;
-        }
+                           dst, xcd, MS, m_chunk);
+    else
         hipLaunchKernelGGL(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
                            dst, xcd, MS, m_chunk);
-        if (MS > 1) {
-            HIPCHK(hipGetLastError());
-            const long long total = (long long)v.n * K;
-            hipLaunchKernelGGL(k_ll_combine,
-                               dim3((unsigned)((total + 255) / 256)),
-                               dim3(256), 0, c->stream,
-                               (const double *)c->part.p, (long long)v.n,
-                               (int)K, MS, (long long)ldo, d_out);
-        }
+    if (MS > 1) {
+        HIPCHK(hipGetLastError());
+        const long long total = (long long)v.n * K;
+        hipLaunchKernelGGL(k_ll_combine, dim3((unsigned)((total + 255) / 256)),
+                           dim3(256), 0, c->stream, (const double *)c->part.p,
+                           (long long)v.n, (int)K, MS, (long long)ldo, d_out);
     }
     HIPCHK(hipGetLastError());
     return 0;
