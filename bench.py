@@ -246,6 +246,9 @@ def main():
             'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
             'traffic_source': traffic_src,
+            'note': 'arithmetic intensity ~4K FP64 adds/byte: for K >= 2 the '
+                'kernel is FP64-VALU-bound, not HBM-bound (SURVEY.md 8(d)); '
+                'the binding roof is in `valu`',
             'shape': {'N': N, 'M': M, 'K': K0},
             'launch_ms': round(ms, 4),
             'algorithmic_bytes': int(alg_bytes),
