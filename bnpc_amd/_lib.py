@@ -51,6 +51,9 @@ SIGNATURES = {
         C.c_double, _pd, _i64]),
     'bnpc_ll_theta_pinned': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
         C.c_double, _i64, C.POINTER(_pd)]),
+    'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
+    'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
+        C.c_double, _i64, C.POINTER(_pd)]),
     'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
     'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
     'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
@@ -304,6 +307,28 @@ class Context:
         check(self._lib.bnpc_ll_theta_pinned(self._h, view,
             ptr(theta, C.c_float), K, float(FP), float(FN), ld,
             C.byref(host)), 'll_theta_pinned')
+        if n == 0:
+            return np.empty((0, ld))
+        return np.ctypeslib.as_array(host, shape=(n, ld))
+
+    def theta_put(self, row0, theta):
+        """Store parameter rows on the device (row index = cluster id)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        if theta.ndim == 1:
+            theta = theta[None, :]
+        assert theta.shape[1] == self.M
+        check(self._lib.bnpc_theta_put(self._h, int(row0),
+            ptr(theta, C.c_float), theta.shape[0]), 'theta_put')
+
+    def ll_rows_pinned(self, view, rows, FP, FN, ld):
+        """ll_theta_pinned with the clusters' parameters taken from the
+        resident store (rows = cluster ids)."""
+        rows = as_i64(rows)
+        n = self.view_size(view)
+        host = _pd()
+        check(self._lib.bnpc_ll_rows_pinned(self._h, view,
+            ptr(rows, C.c_int64), rows.size, float(FP), float(FN), ld,
+            C.byref(host)), 'll_rows_pinned')
         if n == 0:
             return np.empty((0, ld))
         return np.ctypeslib.as_array(host, shape=(n, ld))

@@ -96,6 +96,9 @@ struct bnpc_ctx {
     View views[BNPC_MAX_VIEWS];
     // scratch
     DevBuf theta, tabs, tab_in, out, cells, chunks, cnt, partial, part;
+    DevBuf theta_store, row_idx;    // resident parameter rows + selection
+    int64_t store_rows = 0;
+    const long long *use_rows = nullptr;    // non-null: tables from the store
     // resident per-cluster counts of the last bnpc_colcounts_by_label
     DevBuf lab_cnt;
     int64_t lab_K = 0;
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(256) void k_gather_transpose(
 // ---------------------------------------------------------------------------
 template <int KW>
 __global__ __launch_bounds__(256) void k_tables_theta(
-    const float *__restrict__ theta, int K, int M, int Mt, double FP,
-    double FN, double *__restrict__ T)
+    const float *__restrict__ theta, const long long *__restrict__ rows,
+    int K, int M, int Mt, double FP, double FN, double *__restrict__ T)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int g = blockIdx.y;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void k_tables_theta(
         const int k = g * KW + j;
         double l1 = 0.0, l0 = 0.0;
         if (k < K && m < M) {
-            const float th = theta[(size_t)k * M + m];
+            const float th = theta[(size_t)(rows ? rows[k] : k) * M + m];
             const double th64 = (double)th;
             const double om64 = (double)(1.0f - th);
             l1 = log(th64 * pFN1 + om64 * FP);
@@ -734,7 +737,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
                       &c->chunks, &c->cnt, &c->partial, &c->part,
-                      &c->lab_cnt};
+                      &c->lab_cnt, &c->theta_store, &c->row_idx};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (View &v : c->views)
@@ -900,8 +903,10 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     dim3 tgrid((unsigned)((c->Mt + 255) / 256), (unsigned)G);
     if (from_theta)
         hipLaunchKernelGGL(k_tables_theta<KW>, tgrid, dim3(256), 0, c->stream,
-                           (const float *)c->theta.p, (int)K, (int)c->M,
-                           c->Mt, FP, FN, (double *)c->tabs.p);
+                           c->use_rows ? (const float *)c->theta_store.p
+                                       : (const float *)c->theta.p,
+                           c->use_rows, (int)K, (int)c->M, c->Mt, FP, FN,
+                           (double *)c->tabs.p);
     else
         hipLaunchKernelGGL(k_tables_relayout<KW>, tgrid, dim3(256), 0,
                            c->stream, (const double *)c->tab_in.p,
@@ -987,6 +992,71 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     ARGCHK(ldo >= K, "ldo smaller than K");
     *host = nullptr;
     int rc = bnpc_ll_theta(c, view, theta, K, FP, FN, nullptr, ldo);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
+    if (bytes == 0) return 0;
+    if (ensure_pin(c, bytes)) return 1;
+    HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *host = (double *)c->pin;
+    return 0;
+}
+
+// Resident parameter rows: row r of the store = parameters of cluster id r.
+extern "C" int bnpc_theta_put(bnpc_ctx *c, int64_t row0, const float *theta,
+                              int64_t R)
+{
+    ARGCHK(c && theta, "NULL argument");
+    ARGCHK(row0 >= 0 && R > 0, "bad row range");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t row_bytes = (size_t)c->M * sizeof(float);
+    const size_t need = (size_t)(row0 + R) * row_bytes;
+    if (need > c->theta_store.cap) {
+        // grow, keeping the rows already stored
+        DevBuf bigger;
+        if (ensure(bigger, need + need / 2)) return 1;
+        if (c->theta_store.p) {
+            HIPCHK(hipMemcpyAsync(bigger.p, c->theta_store.p,
+                                  (size_t)c->store_rows * row_bytes,
+                                  hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(c->theta_store.p));
+        }
+        c->theta_store = bigger;
+    }
+    HIPCHK(hipMemcpyAsync((char *)c->theta_store.p + (size_t)row0 * row_bytes,
+                          theta, (size_t)R * row_bytes, hipMemcpyHostToDevice,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));     // theta is only borrowed
+    if (row0 + R > c->store_rows) c->store_rows = row0 + R;
+    return 0;
+}
+
+// bnpc_ll_theta_pinned with the K parameter vectors taken from the resident
+// store: cluster k uses store row rows[k] (no host gather, no re-upload).
+extern "C" int bnpc_ll_rows_pinned(bnpc_ctx *c, int view, const int64_t *rows,
+                                   int64_t K, double FP, double FN,
+                                   int64_t ldo, double **host)
+{
+    ARGCHK(c && host && rows, "NULL argument");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(K > 0, "K must be positive");
+    ARGCHK(FP > 0.0 && FP < 1.0 && FN > 0.0 && FN < 1.0,
+           "error rates must lie in (0, 1)");
+    for (int64_t k = 0; k < K; k++)
+        ARGCHK(rows[k] >= 0 && rows[k] < c->store_rows,
+               "row is not in the resident parameter store");
+    if (ldo == 0) ldo = K;
+    ARGCHK(ldo >= K, "ldo smaller than K");
+    *host = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure(c->row_idx, K * sizeof(long long))) return 1;
+    HIPCHK(hipMemcpyAsync(c->row_idx.p, rows, K * sizeof(long long),
+                          hipMemcpyHostToDevice, c->stream));
+    c->use_rows = (const long long *)c->row_idx.p;
+    int rc = ll_common(c, view, K, ldo, true, FP, FN, nullptr);
+    c->use_rows = nullptr;
     if (rc) return rc;
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
     if (bytes == 0) return 0;

@@ -397,6 +397,10 @@ class CRP:
             rows_fit = max(64, budget // (8 * (K + 16)))
             whole = pos == 0 and rows_fit >= N
             pos_end = N if whole else min(N, pos + rows_fit)
+            if pos == 0 and not whole:
+                # tiled sweep: the parameter rows stay resident on the device
+                # (row = cluster id); tiles select the live ones by index
+                self._dev().theta_put(0, self.parameters[:int(ids.max()) + 1])
             ids, sizes, n_new = self._gibbs_window(
                 perm, pos, pos_end, whole, ids, sizes, assignment, post_new,
                 crp_prior)
@@ -431,11 +435,14 @@ class CRP:
             view, n_rows = VIEW_SWEEP, pos_end - pos
             ctx.view_set(VIEW_SWEEP, perm[pos:pos_end])
         ld = K + 16
-        theta = self.parameters[ids]
         if tile_timing:
             t1 = time.perf_counter()
         # pinned host buffer of the context: read (and extended) in place
-        ll = ctx.ll_theta_pinned(view, theta, self.FP, self.FN, ld)
+        if whole:
+            ll = ctx.ll_theta_pinned(view, self.parameters[ids], self.FP,
+                self.FN, ld)
+        else:
+            ll = ctx.ll_rows_pinned(view, ids, self.FP, self.FN, ld)
         if tile_timing:
             t2 = time.perf_counter()
 
@@ -469,6 +476,8 @@ class CRP:
             cell = int(st.new_cell)
             new_id = int(np.flatnonzero(col_of_id < 0)[0])
             self.parameters[new_id] = self._init_cl_params_new([cell])
+            if not whole:
+                ctx.theta_put(new_id, self.parameters[new_id])
             if st.n_cols == ld:
                 grow = max(16, ld // 4)
                 ll = np.concatenate(

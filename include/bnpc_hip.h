@@ -97,6 +97,17 @@ int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
                          int64_t K, double FP, double FN, int64_t ldo,
                          double **host);
 
+/* Resident parameter rows for tiled sweeps: store row r holds the float32
+ * parameter vector of cluster id r (libs/CRP.py:155-180 keeps them in an
+ * N x M array indexed by id).  bnpc_theta_put copies R rows starting at row0;
+ * bnpc_ll_rows_pinned is bnpc_ll_theta_pinned with cluster k taken from store
+ * row rows[k] - no host-side gather `parameters[cl_ids]` (libs/CRP.py:224) and
+ * no re-upload per tile. */
+int bnpc_theta_put(bnpc_ctx *ctx, int64_t row0, const float *theta, int64_t R);
+int bnpc_ll_rows_pinned(bnpc_ctx *ctx, int view, const int64_t *rows,
+                        int64_t K, double FP, double FN, int64_t ldo,
+                        double **host);
+
 /* Same sums from caller-built element tables: L1[k,m] is the value an
  * observed 1 contributes, L0[k,m] an observed 0 (both K x M float64).  With
  * tables built by the caller's NumPy this reproduces the reference's sums bit

@@ -63,6 +63,20 @@ class FakeContext:
         out = np.empty((n, ld))
         return self.ll_theta(view, theta, FP, FN, out=out)
 
+    def theta_put(self, row0, theta):
+        theta = np.atleast_2d(np.asarray(theta, dtype=np.float32))
+        store = getattr(self, 'store', np.zeros((0, self.M), np.float32))
+        need = row0 + theta.shape[0]
+        if need > store.shape[0]:
+            store = np.concatenate([store,
+                np.zeros((need - store.shape[0], self.M), np.float32)])
+        store[row0:need] = theta
+        self.store = store
+
+    def ll_rows_pinned(self, view, rows, FP, FN, ld):
+        return self.ll_theta_pinned(view, self.store[np.asarray(rows)], FP,
+            FN, ld)
+
     def ll_tables(self, view, L1, L0, out=None):
         self._count('ll_tables')
         L1 = np.atleast_2d(np.asarray(L1, dtype=np.float64))

@@ -558,3 +558,29 @@ def test_pinned_result_buffer():
     ctx.ll_total(theta, [0.01], [0.2])
     assert np.array_equal(view[:, :6], want)
     ctx.close()
+
+
+def test_resident_parameter_rows():
+    """bnpc_theta_put + bnpc_ll_rows_pinned == bnpc_ll_theta on the gathered
+    rows (bit for bit), also after rows were overwritten / the store grew."""
+    rng = np.random.RandomState(6)
+    data = (rng.random_sample((400, 130)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    params = np.clip(rng.uniform(size=(50, 130)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    ctx = _lib.Context(data=data)
+    ctx.theta_put(0, params[:30])
+    rows = np.array([3, 29, 0, 17, 8])
+    want = ctx.ll_theta(0, params[rows], 0.01, 0.2)
+    got = ctx.ll_rows_pinned(0, rows, 0.01, 0.2, rows.size + 16)
+    assert np.array_equal(got[:, :rows.size], want)
+    params[17] = np.float32(0.25)
+    ctx.theta_put(17, params[17])                 # overwrite one row
+    ctx.theta_put(45, params[45:50])              # grow past the end
+    rows = np.array([17, 49, 45, 3])
+    want = ctx.ll_theta(0, params[rows], 0.01, 0.2)
+    got = ctx.ll_rows_pinned(0, rows, 0.01, 0.2, 4)
+    assert np.array_equal(got, want)
+    with pytest.raises(RuntimeError, match='resident parameter store'):
+        ctx.ll_rows_pinned(0, np.array([50]), 0.01, 0.2, 1)
+    ctx.close()
