@@ -147,7 +147,7 @@ def load_pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or
     None.  The counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_v5_final.json')
+    path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_v8_final.json')
     try:
         with open(path) as f:
             pmc = json.load(f)
@@ -240,9 +240,9 @@ def main():
         ms, alg_bytes = time_ll(K0)
         gbs = alg_bytes / (ms * 1e-3) / 1e9
         evals = N * K0 / (ms * 1e-3)
-        traffic, traffic_src = load_pmc_traffic('k_ll8_asm<2>')
+        traffic, traffic_src = load_pmc_traffic('k_ll8_asm<2, false>')
         roofline = {
-            'kernel': 'k_ll8_asm<2>', 'bound': 'hbm',
+            'kernel': 'k_ll8_asm<2, false>', 'bound': 'hbm',
             'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
             'traffic_source': traffic_src,

@@ -420,24 +420,30 @@ __device__ __forceinline__ void ll_step8(double (&a)[8],
 // 128 cells: the 16 table doubles of a mutation are loaded once and feed 32
 // masked adds, halving the scalar-pipe and scalar-cache work per add.
 // Same sums, same order, same bits as k_ll<8>.
-template <int CB>
+// SPLIT = false: one wave sums all mutations of its tile (the large launches:
+// first sweep, tiles).  SPLIT = true: the mutation-split form for small
+// launches (partial sums + k_ll_combine).  Two symbols, so that per-kernel
+// profiles do not mix millisecond launches with microsecond ones.
+template <int CB, bool SPLIT>
 __global__ __launch_bounds__(256) void k_ll8_asm(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
-    double *__restrict__ out, int xcd_remap, int MS, int m_chunk)
+    double *__restrict__ out, int xcd_remap, int MS_arg, int m_chunk)
 {
     constexpr int KW = 8;
+    const int MS = SPLIT ? MS_arg : 1;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     long long bx, g;
     ll_tile_coords((unsigned)((nblk + 4 * CB - 1) / (4 * CB)) * (unsigned)MS,
                    (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
-    const int ms = (int)(bx % MS);      // mutation chunk of this wave
-    bx /= MS;
+    const int ms = SPLIT ? (int)(bx % MS) : 0;  // mutation chunk of this wave
+    if (SPLIT) bx /= MS;
     const long long blk0 = (bx * 4 + wave) * CB;
     if (blk0 >= nblk) return;
-    const int m_begin = ms * m_chunk;
-    const int m_len = ((m_begin + m_chunk < Mt) ? m_chunk : Mt - m_begin);
+    const int m_begin = SPLIT ? ms * m_chunk : 0;
+    const int m_len = SPLIT
+        ? ((m_begin + m_chunk < Mt) ? m_chunk : Mt - m_begin) : Mt;
 
     // mask rows of the wave's CB blocks, as offsets from the one `masks` base
     // (a block past the end re-reads the wave's first block, never stored)
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     for (int c = 0; c < CB; c++) {
         const long long slot = (blk0 + c) * 64 + lane;
         if (blk0 + c < nblk && slot < n) {
-            double *o = (MS > 1)
+            double *o = (SPLIT && MS > 1)
                 ? out + ((size_t)ms * n + slot) * K + (size_t)g * KW
                 : out + (size_t)slot * ldo + (size_t)g * KW;
 #pragma unroll
@@ -861,18 +867,21 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         dst = (double *)c->part.p;
     }
     const int64_t wg2 = ((v.nblk + 7) / 8) * G * MS;
-    if (KW == 8 && impl == 2 && wg2 >= env_flag("BNPC_ASM2_MIN_WGS", 448))
-        hipLaunchKernelGGL(k_ll8_asm<2>, dim3((unsigned)wg2), dim3(256), 0,
-                           c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
-                           c->Mt, (long long)v.n, (long long)v.nblk,
-                           (const double *)c->tabs.p, (int)K, (long long)ldo,
-                           dst, xcd, MS, m_chunk);
-    else if (KW == 8 && impl >= 1)
-        hipLaunchKernelGGL(k_ll8_asm<1>, dim3((unsigned)nwg), dim3(256), 0,
-                           c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
-                           c->Mt, (long long)v.n, (long long)v.nblk,
-                           (const double *)c->tabs.p, (int)K, (long long)ldo,
-                           dst, xcd, MS, m_chunk);
+#define LAUNCH_ASM(CB_, SPLIT_, GRID_)                                        \
+    hipLaunchKernelGGL((k_ll8_asm<CB_, SPLIT_>), dim3((unsigned)(GRID_)),     \
+                       dim3(256), 0, c->stream,                              \
+                       (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,        \
+                       (long long)v.n, (long long)v.nblk,                    \
+                       (const double *)c->tabs.p, (int)K, (long long)ldo,    \
+                       dst, xcd, MS, m_chunk)
+    if (KW == 8 && impl == 2 && wg2 >= env_flag("BNPC_ASM2_MIN_WGS", 448)) {
+        if (MS > 1) LAUNCH_ASM(2, true, wg2);
+        else LAUNCH_ASM(2, false, wg2);
+    } else if (KW == 8 && impl >= 1) {
+        if (MS > 1) LAUNCH_ASM(1, true, nwg);
+        else LAUNCH_ASM(1, false, nwg);
+    }
+#undef LAUNCH_ASM
     else
         hipLaunchKernelGGL(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
