@@ -1,24 +1,36 @@
-"""Sampler driver: chain pool, per-step move schedule, trace storage.
+"""Sampler driver: chain -> GPU placement, the per-step move schedule, traces.
 
-The caller side of the hot path.  Behaviour follows the reference driver
-/root/reference/libs/MCMC.py (MCMC :26-193, Chain :200-342, Chain_steps
-:349-388, Chain_time :395-440) so that the model classes (GPU-backed
-``bnpc_amd.model`` or the CPU oracle) see exactly the reference's call
-sequence and the global legacy ``np.random`` stream is consumed in the
-reference's order:
+The caller side of the hot path.  What the driver has to do is fixed by the
+reference (/root/reference/libs/MCMC.py: MCMC :26-193, Chain :200-342,
+Chain_steps :349-388, Chain_time :395-440), because the model classes - the
+GPU-backed ``bnpc_amd.model`` and the CPU oracle alike - must see the
+reference's call sequence and the global legacy ``np.random`` stream must be
+consumed in the reference's order:
 
     step := [u<sm_prob ? split_merge : Gibbs] -> [u<dpa_prob ? DP alpha]
             -> update_parameters -> [learning & u<error_prob ? error rates]
-            -> update_results (ML, MAP, alpha, FN, FP, assignment, params)
+            -> record (ML, MAP, alpha, FN, FP, assignment, params)
 
-Differences from the reference, all additive:
-  * worker exceptions are re-raised in the parent (the reference drops them,
-    MCMC.py:113-120),
-  * a chain index -> GPU mapping: worker i exports BNPC_DEVICE=i mod #GPUs
-    before the model creates its device context (one chain per GPU, no
-    collective - SURVEY.md section 8(e)),
-  * `learning errors` is detected by the model's surface, not only by its
-    module path (MCMC.py:206-209), so the CPU oracle can be driven too.
+How it is organised is this build's own:
+
+  * `TraceStore`   the per-chain sample storage (the `results` dict every
+                   downstream consumer reads), pre-allocated and grown in
+                   blocks;
+  * `Tally`        acceptance counters of the MH moves, by name;
+  * `advance()`    ONE step of the move schedule, a free function of
+                   (model, knobs, tally);
+  * `StepBudget` / `Deadline`   when a chain stops and which steps are
+                   burn-in;
+  * `Chain`        glues the four; `Chain_steps` / `Chain_time` are the two
+                   constructors the reference's names promise;
+  * `MCMC`         seeds, the fork pool (worker i -> GPU i mod #GPUs: one chain
+                   per GPU, no collective - SURVEY.md section 8(e)), lugsail
+                   extension rounds.
+
+Deliberate differences from the reference, all additive: worker exceptions are
+re-raised in the parent (the reference drops them, MCMC.py:113-120);
+error-rate learning is detected by the model's surface as well as by its
+module path (MCMC.py:206-209), so the CPU oracle can be driven too.
 """
 from copy import deepcopy
 from datetime import datetime
@@ -29,23 +41,13 @@ import numpy as np
 
 np.seterr(divide='raise', over='ignore', under='ignore', invalid='raise')
 
+KFD_NODES = '/sys/class/kfd/kfd/topology/nodes'
 
-def _visible_gpus():
-    """Number of GPUs to spread chains over (no HIP call: fork-safe)."""
-    env = os.environ.get('BNPC_NUM_DEVICES')
-    if env:
-        return max(1, int(env))
+
+# ---------------------------------------------------------------- placement
+def _node_has_simds(node):
     try:
-        n = len([d for d in os.listdir('/sys/class/kfd/kfd/topology/nodes')
-            if _is_gpu_node(d)])
-        return max(1, n)
-    except OSError:
-        return 1
-
-
-def _is_gpu_node(node):
-    try:
-        with open(f'/sys/class/kfd/kfd/topology/nodes/{node}/properties') as f:
+        with open(os.path.join(KFD_NODES, node, 'properties')) as f:
             for line in f:
                 if line.startswith('simd_count'):
                     return int(line.split()[1]) > 0
@@ -54,95 +56,389 @@ def _is_gpu_node(node):
     return False
 
 
+def _visible_gpus():
+    """GPUs to spread chains over, read from sysfs: no HIP call happens in
+    the parent, so the pool can still fork."""
+    forced = os.environ.get('BNPC_NUM_DEVICES')
+    if forced:
+        return max(1, int(forced))
+    try:
+        return max(1, sum(_node_has_simds(d) for d in os.listdir(KFD_NODES)))
+    except OSError:
+        return 1
+
+
+def _bind_worker_to_gpu(chain_index):
+    os.environ.setdefault('BNPC_DEVICE', str(chain_index % _visible_gpus()))
+
+
+# ------------------------------------------------------------------- traces
+class TraceStore:
+    """Samples of one chain, in the layout of the reference's
+    `Chain.results` (MCMC.py:231-305) because posterior inference, PSRF and
+    the writers index it by these keys:
+
+        ML, MAP, DP_alpha, FN, FP   float64 (slot 0 = state after init)
+        assignments                 int (slots x cells)
+        params                      float32 (post-burn-in slots x clusters x
+                                    mutations), clusters in ascending-id
+                                    order, zero-padded to the largest cluster
+                                    count seen; created at the first
+                                    post-burn-in sample
+        burn_in, PSRF, ...          scalars added by the owners
+    """
+
+    SCALARS = ('ML', 'MAP', 'DP_alpha', 'FN', 'FP')
+    GROW_BLOCK = 200
+
+    def __init__(self, slots, n_cells, n_muts):
+        self.n_cells = n_cells
+        self.n_muts = n_muts
+        self.data = {key: np.zeros(slots) for key in self.SCALARS}
+        self.data['assignments'] = np.zeros((slots, n_cells), dtype=int)
+
+    @property
+    def slots(self):
+        return self.data['ML'].size
+
+    def grow(self, extra=None, with_params=False):
+        """Append `extra` empty slots (default: a block, at most doubling)."""
+        extra = extra or min(self.GROW_BLOCK, self.slots)
+        d = self.data
+        if with_params and 'params' in d:
+            k_max = d['params'].shape[1]
+            d['params'] = np.append(d['params'],
+                np.zeros((extra, k_max, self.n_muts)), axis=0)
+        for key in self.SCALARS:
+            d[key] = np.append(d[key], np.zeros(extra))
+        d['assignments'] = np.append(d['assignments'],
+            np.zeros((extra, self.n_cells), int), axis=0)
+
+    def put_state(self, slot, model):
+        """a8: the total log-likelihood of every step is what the 1e-6 parity
+        criterion is checked on (MCMC.py:252-258)."""
+        d = self.data
+        log_lik = model.get_ll_full()
+        d['ML'][slot] = log_lik
+        d['MAP'][slot] = log_lik + model.get_lprior_full()
+        d['DP_alpha'][slot] = model.DP_a
+        d['FN'][slot] = model.FN
+        d['FP'][slot] = model.FP
+        d['assignments'][slot] = model.assignment
+
+    def put_params(self, slot, model):
+        """MCMC.py:260-282: parameter rows of the populated clusters."""
+        d = self.data
+        live = np.sort(np.fromiter(model.cells_per_cluster.keys(), dtype=int))
+        if 'params' not in d:
+            d['params'] = np.zeros((self.slots - slot, live.size, self.n_muts),
+                dtype=np.float32)
+        wider = live.size - d['params'].shape[1]
+        if wider > 0:
+            d['params'] = np.pad(d['params'], [(0, 0), (0, wider), (0, 0)],
+                mode='constant')
+        row = slot - (self.slots - d['params'].shape[0])
+        d['params'][row][:live.size] = model.parameters[live]
+
+    def drop_unused_tail(self):
+        """Slots never written still hold MAP == 0 (MCMC.py:431-436)."""
+        unused = int((self.data['MAP'] == 0).sum())
+        if unused:
+            self.data = {key: val[:-unused] for key, val in self.data.items()}
+
+
+class Tally:
+    """[accepted, declined] per MH move since the last report."""
+
+    MOVES = ('parameters', 'splits', 'merges', 'FP', 'FN')
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.counts = {name: np.zeros(2) for name in self.MOVES}
+
+    def add(self, name, accepted_declined):
+        self.counts[name] += accepted_declined
+
+    def report(self, fix_assign, learning_errors):
+        from bnpc_amd.io import show_MH_acceptance
+        show_MH_acceptance(self.counts['parameters'], 'parameters', 1)
+        names = [] if fix_assign else ['splits', 'merges']
+        names += ['FP', 'FN'] if learning_errors else []
+        for name in names:
+            show_MH_acceptance(self.counts[name], name, 2)
+        self.reset()
+
+
+# ------------------------------------------------------------ move schedule
+def advance(model, knobs, tally, fix_assign=False, learning_errors=False):
+    """One step of the sampler (MCMC.py:320-342).  Each `np.random.random()`
+    is a draw of the reference's stream at the reference's position; the
+    error-rate draw exists only for models that learn their error rates, the
+    first two only when assignments are free."""
+    if not fix_assign:
+        if np.random.random() < knobs['sm_prob']:
+            outcome, move = model.update_assignments_split_merge(
+                knobs['sm_ratios'], knobs['sm_steps'])
+            tally.add('splits' if move == 0 else 'merges', outcome)
+        else:
+            model.update_assignments_Gibbs()
+        if np.random.random() < knobs['dpa_prob']:
+            model.update_DP_alpha()
+
+    declined, accepted = model.update_parameters()
+    tally.add('parameters', (accepted, declined))
+
+    if learning_errors and np.random.random() < knobs['error_prob']:
+        FP_outcome, FN_outcome = model.update_error_rates()
+        tally.add('FP', FP_outcome)
+        tally.add('FN', FN_outcome)
+
+
+def _learns_errors(model):
+    return type(model).__module__ == 'libs.CRP_learning_errors' \
+        or callable(getattr(model, 'update_error_rates', None))
+
+
+def _before(value, limit):
+    """`value < limit`; False when the two cannot be compared (a burn-in that
+    was invalidated)."""
+    try:
+        return bool(value < limit)
+    except TypeError:
+        return False
+
+
+# ------------------------------------------------------------------ budgets
+class StepBudget:
+    """`count` steps, the first `burn_in` of them warm-up."""
+
+    def __init__(self, count, burn_in):
+        self.count = count
+        self.burn_in = burn_in
+
+    def initial_slots(self):
+        return self.count + 1
+
+    def first_sample_is_warmup(self):
+        return self.burn_in != 0
+
+
+class Deadline:
+    """Run until `end_time`; samples before `burn_in` (a time) are warm-up."""
+
+    def __init__(self, end_time, burn_in):
+        self.end_time = end_time
+        self.burn_in = burn_in
+
+    def initial_slots(self):
+        return 500
+
+    def first_sample_is_warmup(self):
+        return True
+
+
+# -------------------------------------------------------------------- chain
+class Chain:
+    """One MCMC chain = model + move knobs + budget + traces."""
+
+    def __init__(self, model, knobs, no, budget, verbosity=1,
+                fix_assign=False):
+        self.model = model
+        self.mcmc = knobs
+        self.no = no
+        self.budget = budget
+        self.burn_in = budget.burn_in
+        self.verbosity = verbosity
+        self.fix_assign = fix_assign
+        self.learning_errors = _learns_errors(model)
+        self.tally = Tally()
+        self.trace = TraceStore(budget.initial_slots(), model.cells_total,
+            model.muts_total)
+        self.update_results(0, budget.first_sample_is_warmup())
+
+    def __str__(self):
+        return f'Chain: {self.no:0>2d}'
+
+    @property
+    def results(self):
+        return self.trace.data
+
+    def get_result(self):
+        return self.trace.data
+
+    def get_steps(self):
+        return self.trace.slots
+
+    def do_step(self):
+        advance(self.model, self.mcmc, self.tally, self.fix_assign,
+            self.learning_errors)
+
+    def update_results(self, step, burn_in=True):
+        """Record the state after `step` (MCMC.py:242-282)."""
+        trace = self.trace
+        if step == trace.slots:     # open-ended runs outgrow their traces
+            try:
+                trace.grow(with_params=not burn_in)
+            except MemoryError:     # wrap around; nothing is burn-in any more
+                step %= trace.slots
+                self.burn_in = np.nan
+        trace.put_state(step, self.model)
+        if not burn_in:
+            trace.put_params(step, self.model)
+
+    def _report(self, headline):
+        print(f'\t{self}\tstep:\t{headline}\n\t\tmean MH accept. ratio:')
+        self.tally.report(self.fix_assign, self.learning_errors)
+
+
+class Chain_steps(Chain):
+    """A chain with a fixed number of steps (MCMC.py:349-388)."""
+
+    def __init__(self, model, no, steps, burn_in, mcmc, verbosity=1,
+                fix_assign=False):
+        super().__init__(model, mcmc, no, StepBudget(steps, burn_in),
+            verbosity, fix_assign)
+
+    def set_steps(self, n):
+        self.budget.count = n
+
+    def add_slots(self, n):
+        self.trace.grow(n, with_params=True)
+
+    def run(self, init_steps=0):
+        todo = self.budget.count
+        # reference quirk kept: fewer than 9 steps make the report interval
+        # zero and the modulo raises ZeroDivisionError (MCMC.py:378)
+        interval = (todo + 1) // 10
+        for step in range(1, todo + 1):
+            if step % interval == 0 and self.verbosity > 1:
+                self._report(f'{step + init_steps: >3} / {todo + init_steps}')
+            self.do_step()
+            self.update_results(step + init_steps,
+                _before(step, self.burn_in))
+        self.trace.data['burn_in'] = self.burn_in
+
+
+class Chain_time(Chain):
+    """A chain that runs until a wall-clock deadline (MCMC.py:395-440)."""
+
+    def __init__(self, model, no, end_time, burn_in, mcmc, verbosity=1,
+                fix_assign=False):
+        super().__init__(model, mcmc, no, Deadline(end_time, burn_in),
+            verbosity, fix_assign)
+
+    def run(self):
+        end = self.budget.end_time
+        step = 0
+        now = datetime.now()
+        while now <= end:
+            if step % 1000 == 0 and self.verbosity > 1:
+                left = (end - now).seconds / 60
+                self._report(f'{step: >3}\t(remaining: {left:.1f} mins.)')
+            step += 1
+            self.do_step()
+            self.update_results(step, _before(now, self.burn_in))
+            now = datetime.now()
+        self.trace.drop_unused_tail()
+        kept = self.trace.data['params'].shape[0]
+        self.trace.data['burn_in'] = self.trace.slots - kept
+
+
+# ------------------------------------------------------------------- driver
 class MCMC:
-    """MCMC.py:26-193"""
+    """Seeds and runs the chains (MCMC.py:26-193)."""
+
+    PROPOSAL_SD = (0.1, 0.25, 0.5)
+    LUGSAIL_ROUND = 200
 
     def __init__(self, model, sm_prob=0.33, dpa_prob=0.5, error_prob=0.1,
                 sm_ratios=[0.75, 0.25], sm_steps=5):
         self.model = model
         self.chains = []
         self.seeds = []
-        self.params = {
-            'sm_prob': sm_prob,
-            'dpa_prob': dpa_prob,
-            'error_prob': error_prob,
-            'param_proposal_sd': np.array([0.1, 0.25, 0.5]),
-            'sm_ratios': sm_ratios,
-            'sm_steps': sm_steps,
-        }
+        self.params = dict(sm_prob=sm_prob, dpa_prob=dpa_prob,
+            error_prob=error_prob, sm_ratios=sm_ratios, sm_steps=sm_steps,
+            param_proposal_sd=np.array(self.PROPOSAL_SD))
 
     def __str__(self):
-        return ('Move probabilitites:\n'
-            '\tSplit/merge:\t{sm_prob}\n\t\tsplit/merge ratio:\t{sm_ratios}\n'
-            '\t\tintermediate Gibbs:\t{sm_steps}\n'
-            '\tCRP a_0 update:\t{dpa_prob}\n'
-            '\tErrors update:\t{error_prob}\n').format(**self.params)
-
-    def get_results(self):
-        results = [chain.get_result() for chain in self.chains]
-        if not results or 'burn_in' not in results[0]:
-            raise RuntimeError('Error in sampling from MCMC')
-        return results
+        p = self.params
+        return ''.join([
+            'Move probabilitites:\n',
+            f'\tSplit/merge:\t{p["sm_prob"]}\n',
+            f'\t\tsplit/merge ratio:\t{p["sm_ratios"]}\n',
+            f'\t\tintermediate Gibbs:\t{p["sm_steps"]}\n',
+            f'\tCRP a_0 update:\t{p["dpa_prob"]}\n',
+            f'\tErrors update:\t{p["error_prob"]}\n'])
 
     def get_seeds(self):
         return self.seeds
 
-    def run(self, run_var, seed, n=1, verbosity=1, assign_file='', debug=False):
-        """MCMC.py:79-123"""
-        cutoff = None
-        if isinstance(run_var[0], (int, np.integer)):
-            chain_type = Chain_steps
-        elif isinstance(run_var[0], float):
-            chain_type = Chain_steps
-            cutoff = run_var[0]
-            run_var = (max(10, int(1 / (cutoff ** 2 - 1))), 0)
-            verbosity_ls = verbosity
-            verbosity = 0
-        else:
-            chain_type = Chain_time
+    def get_results(self):
+        out = [chain.get_result() for chain in self.chains]
+        if not out or 'burn_in' not in out[0]:
+            raise RuntimeError('Error in sampling from MCMC')
+        return out
 
+    @staticmethod
+    def _plan(run_var):
+        """Termination modes (MCMC.py:79-94): (int steps, burn-in steps),
+        (float PSRF cutoff, _) or (end time, burn-in time)."""
+        head = run_var[0]
+        if isinstance(head, (int, np.integer)):
+            return Chain_steps, run_var, None
+        if isinstance(head, float):
+            first_round = max(10, int(1 / (head ** 2 - 1)))
+            return Chain_steps, (first_round, 0), head
+        return Chain_time, run_var, None
+
+    def run(self, run_var, seed, n=1, verbosity=1, assign_file='', debug=False):
+        chain_type, run_var, cutoff = self._plan(run_var)
+        assign = None
         if assign_file:
             from bnpc_amd.io import load_txt
             assign = load_txt(assign_file)
-        else:
-            assign = None
 
-        cores = min(n, mp.cpu_count())
+        workers = min(n, mp.cpu_count())
+        # master seed -> one seed per chain (MCMC.py:100-104)
         if seed > 0:
             np.random.seed(seed)
-        self.seeds = np.random.randint(0, 2 ** 32 - 1, cores)
+        self.seeds = np.random.randint(0, 2 ** 32 - 1, workers)
 
-        if debug:
+        if debug:       # single chain in this process
             np.random.seed(self.seeds[0])
             print(f'\nSeed set to: {self.seeds[0]}\n')
             self.chains.append(
                 self.run_chain(chain_type, run_var, assign, 0, 2))
             return
 
-        self._pool_map(self.run_chain,
-            [(chain_type, run_var, assign, i, verbosity)
-                for i in range(cores)], self.chains.append)
-        self.chains.sort(key=lambda c: c.no)
-
+        quiet = 0 if cutoff else verbosity
+        jobs = [(chain_type, run_var, assign, i, quiet)
+            for i in range(workers)]
+        self._fan_out(self.run_chain, jobs, self.chains.append)
+        self.chains.sort(key=lambda chain: chain.no)
         if cutoff:
-            self.run_lugsail_chains(cutoff, cores, verbosity_ls)
+            self.run_lugsail_chains(cutoff, workers, verbosity)
 
     @staticmethod
-    def _pool_map(fn, arg_list, callback):
-        errors = []
-        pool = mp.get_context('fork').Pool(len(arg_list))
-        for args in arg_list:
-            pool.apply_async(fn, args, callback=callback,
-                error_callback=errors.append)
+    def _fan_out(fn, jobs, on_done):
+        """One forked worker per job; a failure in any of them is raised here
+        after all have finished."""
+        failures = []
+        pool = mp.get_context('fork').Pool(len(jobs))
+        for job in jobs:
+            pool.apply_async(fn, job, callback=on_done,
+                error_callback=failures.append)
         pool.close()
         pool.join()
-        if errors:
-            raise RuntimeError(f'chain worker failed: {errors[0]!r}') \
-                from errors[0]
+        if failures:
+            raise RuntimeError(f'chain worker failed: {failures[0]!r}') \
+                from failures[0]
 
     def run_chain(self, chain_type, run_var, assign, i, verbosity):
-        """MCMC.py:126-135 (+ chain -> GPU mapping)"""
-        os.environ.setdefault('BNPC_DEVICE', str(i % _visible_gpus()))
+        """Worker body (MCMC.py:126-135): seed, private model copy, init, run."""
+        _bind_worker_to_gpu(i)
         np.random.seed(self.seeds[i])
         model = deepcopy(self.model)
         model.init(assign=assign)
@@ -151,261 +447,48 @@ class MCMC:
         chain.run()
         return chain
 
-    def run_lugsail_chains(self, cutoff, cores, verbosity, n=200):
-        """MCMC.py:138-177"""
+    def run_lugsail_chains(self, cutoff, cores, verbosity, n=None):
+        """Extend all chains in rounds of `n` steps until the lugsail PSRF
+        estimate passes `cutoff` (MCMC.py:138-177)."""
         from bnpc_amd.postproc import get_lugsail_batch_means_est
-        steps_run = self.chains[0].results['ML'].size
+        n = n or self.LUGSAIL_ROUND
+        done = self.chains[0].results['ML'].size
         while True:
             PSRF = get_lugsail_batch_means_est(
-                [(c.results['ML'], steps_run // 2) for c in self.chains])
+                [(c.results['ML'], done // 2) for c in self.chains])
             if verbosity > 1:
-                print(f'\tPSRF at {steps_run}:\t{PSRF:.5f}')
+                print(f'\tPSRF at {done}:\t{PSRF:.5f}')
             for chain in self.chains:
-                chain.results.setdefault('PSRF', []).append((steps_run, PSRF))
+                chain.results.setdefault('PSRF', []).append((done, PSRF))
             if PSRF <= cutoff:
                 break
             try:
-                self._pool_map(self.extend_chain,
+                self._fan_out(self.extend_chain,
                     [(i, n) for i in range(cores)], self.replace_chain)
             except KeyboardInterrupt:
                 print('Manual termination')
                 break
-            steps_run += n
+            done += n
 
-        burn_in = (steps_run // 2) + 1
+        burn_in = (done // 2) + 1
         for chain in self.chains:
-            chain.results['burn_in'] = burn_in
-            chain.results['params'] = chain.results['params'][burn_in:]
-            chain.results['PSRF_cutoff'] = cutoff
+            res = chain.results
+            res['burn_in'] = burn_in
+            res['params'] = res['params'][burn_in:]
+            res['PSRF_cutoff'] = cutoff
 
     def extend_chain(self, chain_no, add_steps):
-        """MCMC.py:180-189 (re-seeds with the chain's seed, as the reference)"""
-        os.environ.setdefault('BNPC_DEVICE', str(chain_no % _visible_gpus()))
+        """MCMC.py:180-189; the worker re-seeds with the chain's own seed, as
+        the reference does."""
+        _bind_worker_to_gpu(chain_no)
         np.random.seed(self.seeds[chain_no])
         chain = self.chains[chain_no]
-        old_steps = chain.get_steps()
-        chain._extend_results(add_steps, False)
+        already = chain.get_steps()
+        chain.add_slots(add_steps)
         chain.set_steps(add_steps)
-        chain.run(init_steps=old_steps - 1)
+        chain.run(init_steps=already - 1)
         return chain_no, chain
 
-    def replace_chain(self, new_chain):
-        self.chains[new_chain[0]] = new_chain[1]
-
-
-class Chain:
-    """One MCMC chain: the move schedule and its trace store.
-
-    Follows libs/MCMC.py:200-342.  `results` keeps the reference's layout
-    because everything downstream reads it: float traces ML, MAP, DP_alpha,
-    FN, FP (entry 0 = initial state), `assignments` (samples x cells),
-    after burn-in `params` (samples x clusters x mutations float32, clusters in
-    sorted-id order, zero-padded to the largest cluster count seen), and
-    `burn_in`.
-    """
-
-    SCALAR_TRACES = ('ML', 'MAP', 'DP_alpha', 'FN', 'FP')
-    # rows of MH_counter (cols: accepted, declined)
-    ROW_PARAMS, ROW_SPLIT, ROW_MERGE, ROW_FP, ROW_FN = range(5)
-
-    def __init__(self, model, mcmc, no, verbosity=1, fix_assign=False):
-        self.model = model
-        self.mcmc = mcmc
-        self.no = no
-        # the reference keys this on the module path (MCMC.py:206-209)
-        self.learning_errors = \
-            type(model).__module__ == 'libs.CRP_learning_errors' \
-            or callable(getattr(model, 'update_error_rates', None))
-        self.results = {}
-        self.MH_counter = np.zeros((5, 2))
-        self.verbosity = verbosity
-        self.fix_assign = fix_assign
-
-    def __str__(self):
-        return f'Chain: {self.no:0>2d}'
-
-    def get_result(self):
-        return self.results
-
-    def run(self, *args):
-        pass
-
-    # ------------------------------------------------------------ traces
-    def init_results(self, steps):
-        for key in self.SCALAR_TRACES:
-            self.results[key] = np.zeros(steps)
-        self.results['assignments'] = np.zeros(
-            (steps, self.model.cells_total), dtype=int)
-
-    def _capacity(self):
-        return self.results['ML'].size
-
-    def update_results(self, step, burn_in=True):
-        """Record the state after `step` (MCMC.py:242-282)."""
-        free_slots = self._capacity() - step
-        if free_slots == 0:         # time-limited runs grow their traces
-            try:
-                self._extend_results(burn_in=burn_in)
-            except MemoryError:
-                step %= self._capacity()
-                self.burn_in = np.nan
-        self._record_state(step)
-        if not burn_in:
-            self._record_parameters(step, free_slots)
-
-    def _record_state(self, step):
-        model, res = self.model, self.results
-        log_lik = model.get_ll_full()
-        res['ML'][step] = log_lik
-        res['MAP'][step] = log_lik + model.get_lprior_full()
-        res['DP_alpha'][step] = model.DP_a
-        res['FN'][step] = model.FN
-        res['FP'][step] = model.FP
-        res['assignments'][step] = model.assignment
-
-    def _record_parameters(self, step, free_slots):
-        model, res = self.model, self.results
-        live = np.sort(np.fromiter(model.cells_per_cluster.keys(), dtype=int))
-        if 'params' not in res:
-            res['params'] = np.zeros(
-                (free_slots, live.size, model.muts_total), dtype=np.float32)
-        trace = res['params']
-        if live.size > trace.shape[1]:
-            trace = res['params'] = np.pad(trace,
-                [(0, 0), (0, live.size - trace.shape[1]), (0, 0)],
-                mode='constant')
-        first_kept = self._capacity() - trace.shape[0] + 1
-        trace[step - first_kept + 1][:live.size] = model.parameters[live]
-
-    def _extend_results(self, add_size=None, burn_in=True):
-        """MCMC.py:285-305"""
-        res = self.results
-        extra = add_size or min(200, self._capacity())
-        if not burn_in:
-            res['params'] = np.append(res['params'], np.zeros(
-                (extra, res['params'].shape[1], self.model.muts_total)),
-                axis=0)
-        for key in self.SCALAR_TRACES:
-            res[key] = np.append(res[key], np.zeros(extra))
-        res['assignments'] = np.append(res['assignments'],
-            np.zeros((extra, self.model.cells_total), int), axis=0)
-
-    # ------------------------------------------------------------ reporting
-    def stdout_progress(self):
-        from bnpc_amd.io import show_MH_acceptance
-        rows = [(self.ROW_PARAMS, 'parameters', 1)]
-        if not self.fix_assign:
-            rows += [(self.ROW_SPLIT, 'splits', 2), (self.ROW_MERGE, 'merges', 2)]
-        if self.learning_errors:
-            rows += [(self.ROW_FP, 'FP', 2), (self.ROW_FN, 'FN', 2)]
-        for row, name, tabs in rows:
-            show_MH_acceptance(self.MH_counter[row], name, tabs)
-        self.MH_counter = np.zeros((5, 2))
-
-    # ------------------------------------------------------------ one step
-    def do_step(self):
-        """The move schedule (MCMC.py:320-342).  Every `np.random.random()`
-        below is a draw of the reference's stream, in its order; the error
-        draw only happens for models that learn their error rates."""
-        model, prob = self.model, self.mcmc
-        if not self.fix_assign:
-            if np.random.random() < prob['sm_prob']:
-                outcome, move = model.update_assignments_split_merge(
-                    prob['sm_ratios'], prob['sm_steps'])
-                row = self.ROW_SPLIT if move == 0 else self.ROW_MERGE
-                self.MH_counter[row] += outcome
-            else:
-                model.update_assignments_Gibbs()
-            if np.random.random() < prob['dpa_prob']:
-                model.update_DP_alpha()
-
-        declined, accepted = model.update_parameters()
-        self.MH_counter[self.ROW_PARAMS] += (accepted, declined)
-
-        if self.learning_errors \
-                and np.random.random() < prob['error_prob']:
-            FP_outcome, FN_outcome = model.update_error_rates()
-            self.MH_counter[self.ROW_FP] += FP_outcome
-            self.MH_counter[self.ROW_FN] += FN_outcome
-
-
-class Chain_steps(Chain):
-    """A chain that runs a fixed number of steps (MCMC.py:349-388)."""
-
-    def __init__(self, model, no, steps, burn_in, mcmc, verbosity=1,
-                fix_assign=False):
-        super().__init__(model, mcmc, no, verbosity, fix_assign)
-        self.steps = steps + 1
-        self.burn_in = burn_in
-        self.init_results(steps + 1)
-        self.update_results(0, burn_in != 0)
-
-    def set_steps(self, n):
-        self.steps = n + 1
-
-    def get_steps(self):
-        return self._capacity()
-
-    def stdout_progress(self, step_no, total):
-        print(f'\t{self}\tstep:\t{step_no: >3} / {total - 1}\n'
-            '\t\tmean MH accept. ratio:')
-        super().stdout_progress()
-
-    def _in_burn_in(self, step):
-        try:
-            return step < self.burn_in
-        except TypeError:
-            return False
-
-    def run(self, init_steps=0):
-        # reference quirk kept: with fewer than 9 steps the report interval
-        # is zero and the modulo below raises ZeroDivisionError
-        report_every = self.steps // 10
-        last = self.steps + init_steps
-        for step in range(1, self.steps):
-            if step % report_every == 0 and self.verbosity > 1:
-                self.stdout_progress(step + init_steps, last)
-            self.do_step()
-            self.update_results(step + init_steps, self._in_burn_in(step))
-        self.results['burn_in'] = self.burn_in
-
-
-class Chain_time(Chain):
-    """A chain that runs until a wall-clock deadline (MCMC.py:395-440)."""
-
-    def __init__(self, model, no, end_time, burn_in, mcmc, verbosity=1,
-                fix_assign=False):
-        super().__init__(model, mcmc, no, verbosity, fix_assign)
-        self.end_time = end_time
-        self.burn_in = burn_in
-        self.init_results(500)
-        self.update_results(0)
-
-    def stdout_progress(self, step_no, total):
-        print(f'\t{self}\tstep:\t{step_no: >3}\t(remaining: {total:.1f} mins.)'
-            '\n\t\tmean MH accept. ratio:')
-        super().stdout_progress()
-
-    def run(self):
-        step = 0
-        while True:
-            now = datetime.now()
-            if now > self.end_time:
-                break
-            if step % 1000 == 0 and self.verbosity > 1:
-                self.stdout_progress(step, (self.end_time - now).seconds / 60)
-            step += 1
-            self.do_step()
-            try:
-                warming_up = now < self.burn_in
-            except TypeError:
-                warming_up = False
-            self.update_results(step, warming_up)
-
-        # drop the unused tail of the pre-allocated traces
-        unused = int((self.results['MAP'] == 0).sum())
-        if unused:
-            self.results = {key: values[:-unused]
-                for key, values in self.results.items()}
-        self.results['burn_in'] = self._capacity() \
-            - self.results['params'].shape[0]
+    def replace_chain(self, numbered_chain):
+        chain_no, chain = numbered_chain
+        self.chains[chain_no] = chain
