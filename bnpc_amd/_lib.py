@@ -67,6 +67,7 @@ SIGNATURES = {
     'bnpc_mt_permutation': (C.c_int, [C.POINTER(MT19937), _i64, _pi64]),
     'bnpc_mt_mh_draws': (C.c_int, [C.POINTER(MT19937), _i64, _i64, _i64,
         _pi32, _pd, _pd]),
+    'bnpc_log_diff_pi': (C.c_int, [_pd, _pd, _i64, _pd]),
     'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
     'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,
@@ -216,6 +217,18 @@ def mh_draws(G, M, n_sd):
         check(load().bnpc_mt_mh_draws(rng, G, M, n_sd, ptr(sd_idx, C.c_int32),
             ptr(U, C.c_double), ptr(u, C.c_double)), 'mh_draws')
     return sd_idx, U, u
+
+
+def log_diff_pi(log_p, log_q):
+    """log(exp(log_p) - exp(log_q)) with SciPy's complex-logsumexp arithmetic
+    (include/bnpc_hip.h: bnpc_log_diff_pi); 1-D float64 in, 1-D out."""
+    log_p = np.ascontiguousarray(log_p, dtype=np.float64)
+    log_q = np.ascontiguousarray(log_q, dtype=np.float64)
+    out = np.empty_like(log_p)
+    check(load().bnpc_log_diff_pi(ptr(log_p, C.c_double),
+        ptr(log_q, C.c_double), log_p.size, ptr(out, C.c_double)),
+        'log_diff_pi')
+    return out
 
 
 class Context:

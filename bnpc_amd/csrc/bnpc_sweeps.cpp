@@ -134,6 +134,28 @@ extern "C" int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M,
     return 0;
 }
 
+// scipy.special.logsumexp([p, q + pi*1j], axis=0).real for q <= p, term by
+// term as NumPy evaluates it: complex exp of (q - p, pi) = exp(q - p) *
+// (cos pi, sin pi); the maximal term is split off and contributes 0 to the
+// sum; complex log1p = log(hypot(re + 1, im)); + log(1) + p.
+extern "C" int bnpc_log_diff_pi(const double *log_p, const double *log_q,
+                                int64_t n, double *out)
+{
+    if ((!log_p || !log_q || !out) && n > 0) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    double sin_pi, cos_pi;
+    sincos(3.141592653589793, &sin_pi, &cos_pi);
+    for (int64_t i = 0; i < n; i++) {
+        const double E = exp(log_q[i] - log_p[i]);
+        const double re = E * cos_pi + 1.0;
+        const double im = E * sin_pi;
+        out[i] = (log(hypot(re, im)) + 0.0) + log_p[i];
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Gibbs sweep
 // ---------------------------------------------------------------------------

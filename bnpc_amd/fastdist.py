@@ -25,7 +25,7 @@ try:        # SciPy's own building blocks of truncnorm (private module)
 except Exception:           # pragma: no cover
     _HAVE_PARTS = False
 
-_state = {'checked': False, 'fast': False, 'shared': False}
+_state = {'checked': False, 'fast': False, 'shared': False, 'left': False}
 
 
 # -- direct forms ------------------------------------------------------------
@@ -64,16 +64,43 @@ def _gamma_logpdf_direct(x, a, loc, scale):
 #    by the proposal's ppf and its forward log-density (scipy's _ppf and
 #    _logpdf each recompute it) --------------------------------------------
 def _tn_mass(a, b):
-    """scipy's _log_gauss_mass(a, b).  When every interval straddles zero
-    (a <= 0 < b, its 'central' case: always true for proposals around a value
-    strictly inside the bounds) that is log1p(-ndtr(a) - ndtr(-b)) for all
-    elements - evaluated directly, without the per-case masks and the complex
-    scratch array; anything else goes to SciPy."""
+    """scipy's _log_gauss_mass(a, b), per element:
+
+      central (a <= 0 < b; a proposal around a value strictly inside the
+               bounds): log1p(-ndtr(a) - ndtr(-b)), evaluated directly without
+               the per-case masks and the complex scratch array;
+      left    (b <= 0; a profile entry sitting ON the upper clip, where the
+               float32 difference TMAX - theta is exactly 0): SciPy takes
+               logsumexp([logcdf(b), logcdf(a) + pi*1j]) through complex
+               arithmetic - restated natively (_lib.log_diff_pi) and used only
+               if the self-check found it bit-identical;
+      anything else goes to SciPy."""
     a = np.asarray(a)
     b = np.asarray(b)
-    if a.shape == b.shape and (a <= 0).all() and (b > 0).all():
+    if a.shape != b.shape or a.ndim == 0:
+        return _cd._log_gauss_mass(a, b)
+    central = (a <= 0) & (b > 0)
+    if central.all():
         return _sc.log1p(-_sc.ndtr(a) - _sc.ndtr(-b))
-    return _cd._log_gauss_mass(a, b)
+    if not _state['left'] or (a > 0).any():
+        return _cd._log_gauss_mass(a, b)
+    # the central form on everything (cheaper than gathering the central
+    # elements), then the left-of-zero elements are overwritten
+    with np.errstate(all='ignore'):
+        out = _sc.log1p(-_sc.ndtr(a) - _sc.ndtr(-b))
+    where = np.flatnonzero(~central)
+    flat = out.reshape(-1)
+    flat[where] = _mass_left(a.reshape(-1)[where], b.reshape(-1)[where])
+    return flat.reshape(a.shape)
+
+
+def _mass_left(a, b):
+    from bnpc_amd import _lib
+    if not b.any():         # every interval ends exactly at 0
+        log_p = np.full(b.shape, _cd._norm_logcdf(0.0))
+    else:
+        log_p = _cd._norm_logcdf(b)
+    return _lib.log_diff_pi(log_p, _cd._norm_logcdf(a))
 
 
 def _log_sum(p, q):
@@ -92,21 +119,23 @@ def _log_sum(p, q):
 
 
 def _tn_ppf_shared(q, a, b, loc, scale, lgm):
+    """truncnorm._ppf with the mass given: scipy's left-tail form where
+    a < 0, its mirrored right-tail form elsewhere (a == 0: a profile entry on
+    the lower clip).  The left form is evaluated on every element - cheaper
+    than gathering - and the few others are overwritten through an index."""
     q, a, b, lgm = np.broadcast_arrays(q, a, b, lgm)
-    left = a < 0
-    out = np.empty_like(q)
+    other = np.flatnonzero(a >= 0)
     with np.errstate(divide='ignore', invalid='ignore'):
-        if left.all():
+        if other.size < a.size:
             out = _sc.ndtri_exp(_log_sum(_cd._norm_logcdf(a),
                 np.log(q) + lgm))
         else:
-            if left.any():
-                out[left] = _sc.ndtri_exp(_log_sum(
-                    _cd._norm_logcdf(a[left]), np.log(q[left]) + lgm[left]))
-            right = ~left
-            out[right] = -_sc.ndtri_exp(_log_sum(
-                _cd._norm_logcdf(-b[right]),
-                np.log1p(-q[right]) + lgm[right]))
+            out = np.empty(a.shape)
+        if other.size:
+            qr, br, mr = (v.reshape(-1)[other] for v in (q, b, lgm))
+            out = np.ascontiguousarray(out)
+            out.reshape(-1)[other] = -_sc.ndtri_exp(_log_sum(
+                _cd._norm_logcdf(-br), np.log1p(-qr) + mr))
     return out * scale + loc
 
 
@@ -131,6 +160,27 @@ def _tn_logpdf_public(x, a, b, loc, scale):
 
 def _beta_logpdf_public(x, p, q):
     return _beta.logpdf(x, p, q)
+
+
+def _left_case_is_exact(rng):
+    """Bit-compare the native left-of-zero mass with SciPy's on intervals
+    ending at 0 (the case that occurs), ending below 0, tiny, wide and
+    degenerate ones."""
+    try:
+        n = 4096
+        width = np.concatenate([rng.uniform(1e-9, 12, size=n // 2),
+            10.0 ** rng.uniform(-12, 1.2, size=n // 2)])
+        b = np.where(rng.uniform(size=n) < .6, 0.0,
+            -(10.0 ** rng.uniform(-9, 1, size=n)))
+        a = b - width
+        a[:4] = [-40.0, -1e3, -1e-300, -5e-324]
+        b[:4] = 0.0
+        with np.errstate(all='ignore'):
+            want = _cd._log_gauss_mass(a, b)
+            got = _mass_left(a, b)
+        return bool(np.array_equal(want, got, equal_nan=True))
+    except Exception:
+        return False
 
 
 def selfcheck():
@@ -189,6 +239,7 @@ def selfcheck():
                 == _gamma_logpdf_direct(x, aa, lo, 1))
         _state['fast'] = bool(ok)
         if ok and _HAVE_PARTS:
+            _state['left'] = _left_case_is_exact(rng)
             with np.errstate(all='ignore'):
                 lgm = _tn_mass(a, b)
                 shared = np.array_equal(

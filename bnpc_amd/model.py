@@ -130,6 +130,7 @@ class CRP:
         state['_ctx'] = None
         state['_newcl'] = None
         state['_lab'] = None
+        state['_prior_rows'] = None
         data = state.pop('data')
         state['_data_codes'] = np.where(np.isnan(data), 3, data) \
             .astype(np.int8)
@@ -528,18 +529,57 @@ class CRP:
         draws stay in the reference's per-cluster order)."""
         lab = self._label_counts()
         ids = lab['ids']
-        new, _, declined = self._mh_batch(self.parameters[ids],
-            (lab['n1'], lab['n0']), False)
+        old = self.parameters[ids]
+        new, _, declined = self._mh_batch(old, (lab['n1'], lab['n0']), False,
+            old_prior=self._known_prior(ids, old), keep_prior=ids)
         self.parameters[ids] = new
         return declined.sum(), (self.muts_total - declined).sum()
 
-    def _mh_batch(self, old, counts, trans_prob):
+    # The Beta prior log-density of a profile that has not changed since the
+    # last update is the value computed then (an elementwise function of
+    # theta): every entry of the result is either the proposal's density
+    # (accepted) or the old one (declined).  Rows are verified against a copy
+    # of theta before they are trusted, so writes to `parameters` from anywhere
+    # (new clusters, split/merge, callers) simply miss.
+    _PRIOR_CACHE_ELEMS = 1 << 22
+
+    def _known_prior(self, ids, theta):
+        """(G, M) Beta log-density of `theta` = parameters[ids], rows taken
+        from the last update where theta is unchanged, or None (uniform
+        prior / nothing cached / too large to keep)."""
+        cache = getattr(self, '_prior_rows', None)
+        if self.beta_prior_uniform or not cache \
+                or theta.size > self._PRIOR_CACHE_ELEMS:
+            return None
+        out = np.empty(theta.shape)
+        missing = []
+        for g, cl in enumerate(ids):
+            hit = cache.get(int(cl))
+            if hit is not None and np.array_equal(hit[0], theta[g]):
+                out[g] = hit[1]
+            else:
+                missing.append(g)
+        if missing:
+            out[missing] = fastdist.beta_logpdf(theta[missing], self.p, self.q)
+        return out
+
+    def _remember_prior(self, ids, theta, prior):
+        if theta.size > self._PRIOR_CACHE_ELEMS:
+            self._prior_rows = None
+            return
+        self._prior_rows = {int(cl): (theta[g].copy(), prior[g])
+            for g, cl in enumerate(ids)}
+
+    def _mh_batch(self, old, counts, trans_prob, old_prior=None,
+                keep_prior=None):
         """MH_cluster_params (libs/CRP.py:314-344) for G clusters at once.
 
         old: (G, M) float32; counts: (n1, n0) each (G, M).  RNG order per
         cluster, as in the reference: choice(sd, M) -> truncnorm.rvs (its M
         uniforms) -> random(M); the arithmetic in between does not draw, so
-        it is hoisted out of the loop and batched."""
+        it is hoisted out of the loop and batched.  `old_prior`: the Beta
+        log-density of `old` if the caller has it; `keep_prior`: cluster ids
+        under which the log-density of the result is remembered."""
         G, M = old.shape
         sd_idx, U, lu = _lib.mh_draws(G, M, self.param_proposal_sd.size)
         std = self.param_proposal_sd[sd_idx]
@@ -549,41 +589,56 @@ class CRP:
             pool = _host_pool()
             n_parts = min(n_parts, pool._max_workers) if pool else 1
         if pool is None or n_parts < 2:
-            new, A, decline = self._mh_math(old, std, U, lu, n1, n0,
-                trans_prob)
+            new, A, decline, prior = self._mh_math(old, std, U, lu, n1, n0,
+                trans_prob, old_prior)
         else:
             # large batches (first steps, config 4/5): the per-element SciPy
             # math of row blocks runs on host threads (ufuncs release the
             # GIL); elementwise, so the values do not depend on the split
             edges = np.linspace(0, G, n_parts + 1, dtype=int)
-            parts = list(pool.map(
-                lambda lo_hi: self._mh_math(*(x[lo_hi[0]:lo_hi[1]] for x in
-                    (old, std, U, lu, n1, n0)), trans_prob),
-                zip(edges[:-1], edges[1:])))
+
+            def block(lo_hi):
+                lo, hi = lo_hi
+                return self._mh_math(*(x[lo:hi] for x in
+                    (old, std, U, lu, n1, n0)), trans_prob,
+                    None if old_prior is None else old_prior[lo:hi])
+            parts = list(pool.map(block, zip(edges[:-1], edges[1:])))
             new, A, decline = (np.concatenate([p[i] for p in parts])
                 for i in range(3))
+            prior = None if parts[0][3] is None \
+                else np.concatenate([p[3] for p in parts])
+        if keep_prior is not None and prior is not None:
+            self._remember_prior(keep_prior, new, prior)
         if trans_prob:
             prob = np.cumsum(A, axis=1)[:, -1]
         else:
             prob = np.full(G, np.nan)
         return new, prob, decline.sum(axis=1)
 
-    def _mh_math(self, old, std, U, lu, n1, n0, trans_prob):
+    def _mh_math(self, old, std, U, lu, n1, n0, trans_prob, old_prior=None):
         """Proposal, log acceptance ratio and accept/decline of a block of
-        clusters (no random draws in here)."""
+        clusters (no random draws in here).  Also returns the Beta prior
+        log-density of the resulting profiles (None under a uniform prior)."""
         with np.errstate(divide='raise', over='ignore', under='ignore',
                 invalid='raise'):       # error state is per thread
             a = (TMIN - old) / std
             b = (TMAX - old) / std
             draw, fwd_logpdf = fastdist.tn_propose(U, a, b, old, std)
             new = draw.astype(np.float32)
+            priors = None
+            if not self.beta_prior_uniform:
+                if old_prior is None:
+                    old_prior = fastdist.beta_logpdf(old, self.p, self.q)
+                priors = (fastdist.beta_logpdf(new, self.p, self.q), old_prior)
             A = self._get_log_A(new, old, None, a, b, std, trans_prob,
-                counts=(n1, n0), fwd=fwd_logpdf(new))
+                counts=(n1, n0), fwd=fwd_logpdf(new), priors=priors)
             decline = np.log(lu) >= A
             new[decline] = old[decline]
+            if priors is not None:
+                priors = np.where(decline, priors[1], priors[0])
             if trans_prob:
                 A[decline] = np.log(-1 * np.expm1(A[decline]))
-        return new, A, decline
+        return new, A, decline, priors
 
     def MH_cluster_params(self, old_params, cells, trans_prob=False,
                 counts=None):
@@ -597,9 +652,10 @@ class CRP:
         return new[0], prob[0], declined[0]
 
     def _get_log_A(self, new_params, old_params, cells, a, b, std, clip=False,
-                counts=None, fwd=None):
+                counts=None, fwd=None, priors=None):
         """libs/CRP.py:347-383 (any leading batch dimension); `fwd` may carry
-        the forward proposal log-density if the caller already has it."""
+        the forward proposal log-density and `priors` the Beta log-densities
+        of (new, old) if the caller already has them."""
         if counts is None:
             counts = self._counts_of(cells)
         if fwd is None:
@@ -613,6 +669,8 @@ class CRP:
 
         if self.beta_prior_uniform:
             new_prior = old_prior = 0
+        elif priors is not None:
+            new_prior, old_prior = priors
         else:
             new_prior = fastdist.beta_logpdf(new_params, self.p, self.q)
             old_prior = fastdist.beta_logpdf(old_params, self.p, self.q)

@@ -180,6 +180,19 @@ int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out);
 int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
                      int32_t *sd_idx, double *U, double *u);
 
+/* log(exp(log_p[i]) - exp(log_q[i])) for log_q <= log_p, evaluated with the
+ * arithmetic of scipy.special.logsumexp([log_p, log_q + pi*1j], axis=0).real
+ * - which is how scipy.stats.truncnorm computes the Gaussian mass of an
+ * interval that lies left of zero (scipy/stats/_continuous_distns.py
+ * _log_diff / _log_gauss_mass; reached from truncnorm.logpdf / rvs at
+ * libs/CRP.py:331,351-357 whenever a profile entry sits on the upper clip):
+ *     E = exp(q - p); out = (log(hypot(1 - E, E * sin(pi))) + 0) + p
+ * with the C library's exp / sincos / hypot / log, i.e. the functions NumPy's
+ * complex exp and log1p resolve to.  The binding bit-compares it against SciPy
+ * once per process and does not use it if anything differs. */
+int bnpc_log_diff_pi(const double *log_p, const double *log_q, int64_t n,
+                     double *out);
+
 /* The sequential per-cell loop of CRP.update_assignments_Gibbs
  * (libs/CRP.py:260-288, with _normalize_log_probs :88-100 and
  * np.random.choice(p=...) :276-277) over a precomputed log-likelihood matrix.

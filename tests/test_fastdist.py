@@ -38,6 +38,35 @@ def test_bit_identical_to_public_api(shape):
             beta(p, q).logpdf(new))
 
 
+def test_mass_of_intervals_on_the_clips_is_bit_identical():
+    """Profile entries ON the upper clip give intervals (a, 0] (SciPy's
+    complex-logsumexp 'left' case, restated natively), entries on the lower
+    clip give [0, b): all three cases mixed in one array."""
+    from scipy.stats import _continuous_distns as cd
+    assert F.selfcheck() and F._state['left'] is True
+    rng = np.random.RandomState(3)
+    for shape in ((4000,), (9, 501)):
+        old = np.clip(rng.uniform(size=shape), TMIN, TMAX).astype(np.float32)
+        where = rng.uniform(size=shape)
+        old[where < .3] = np.float32(TMAX)
+        old[where > .8] = np.float32(TMIN)
+        std = rng.choice(np.array([0.1, 0.25, 0.5]), size=shape)
+        a, b = (TMIN - old) / std, (TMAX - old) / std
+        assert (b == 0).any() and (a == 0).any()
+        assert np.array_equal(F._tn_mass(a, b), cd._log_gauss_mass(a, b))
+        U = rng.uniform(size=shape)
+        draw, fwd = F.tn_propose(U, a, b, old, std)
+        assert np.array_equal(draw,
+            truncnorm.ppf(U, a, b, loc=old, scale=std))
+        new = draw.astype(np.float32)
+        assert np.array_equal(fwd(new),
+            truncnorm.logpdf(new, a, b, loc=old, scale=std))
+    # an interval right of zero is not ours: SciPy's own path, same bits
+    a = np.array([-1.0, 0.5, -2.0])
+    b = np.array([0.0, 1.5, 1.0])
+    assert np.array_equal(F._tn_mass(a, b), cd._log_gauss_mass(a, b))
+
+
 def test_rvs_consumes_the_global_stream_like_scipy():
     rng = np.random.RandomState(2)
     old = np.clip(rng.uniform(size=500), TMIN, TMAX).astype(np.float32)

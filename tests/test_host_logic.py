@@ -376,3 +376,40 @@ def test_threaded_host_batches_are_bit_identical(monkeypatch):
     assert o.update_parameters() == outs[1][0]
     assert np.array_equal(o.parameters[ids], outs[1][1])
     P._POOL.clear()
+
+
+def test_prior_density_cache_changes_nothing(monkeypatch):
+    """update_parameters reuses the Beta log-density of unchanged profiles
+    (model._known_prior): same draws, same parameters, bit for bit, as with
+    the cache switched off - also when rows are overwritten behind its back."""
+    data = synth(21, 60, 90, 4, 0.15)
+
+    def walk(cache_elems):
+        monkeypatch.setattr(P.CRP, '_PRIOR_CACHE_ELEMS', cache_elems)
+        np.random.seed(77)
+        m = make(P, 'fixed', data, pb=(.25, .25))
+        m.init()
+        out = []
+        for step in range(8):
+            m.update_assignments_Gibbs()
+            if step == 3:       # a write the cache has not seen
+                first = next(iter(m.cells_per_cluster))
+                m.parameters[first, ::7] = np.float32(0.5)
+            if step == 5:
+                m.update_assignments_split_merge([.75, .25], 2)
+            out.append(m.update_parameters())
+            out.append(m.parameters[sorted(m.cells_per_cluster)].copy())
+        return out, m
+
+    ref, _ = walk(0)
+    got, m = walk(1 << 22)
+    assert m._prior_rows and set(m._prior_rows) == set(m.cells_per_cluster)
+    for r, g in zip(ref, got):
+        assert np.array_equal(np.asarray(r), np.asarray(g))
+    # a cached row is only trusted while theta is unchanged
+    ids = np.array(sorted(m.cells_per_cluster))
+    theta = m.parameters[ids].copy()
+    theta[0, 0] = np.float32(0.123)
+    from bnpc_amd import fastdist
+    assert np.array_equal(m._known_prior(ids, theta),
+        fastdist.beta_logpdf(theta, m.p, m.q))
