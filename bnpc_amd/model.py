@@ -360,8 +360,11 @@ class CRP:
             + np.cumsum(self.CRP_prior[sizes])[-1]
         if not self.beta_prior_uniform:
             ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
-            lprior += np.cumsum(fastdist.beta_logpdf(
-                self.parameters[ids], self.p, self.q).ravel())[-1]
+            theta = self.parameters[ids]
+            density = self._known_prior(ids, theta)     # rows kept by the MH
+            if density is None:
+                density = fastdist.beta_logpdf(theta, self.p, self.q)
+            lprior += np.cumsum(density.ravel())[-1]
         return lprior
 
     # ---------------------------------------------------------------- Gibbs
