@@ -140,6 +140,30 @@ class TraceStore:
         row = slot - (self.slots - d['params'].shape[0])
         d['params'][row][:live.size] = model.parameters[live]
 
+    def __getstate__(self):
+        """Chains return from their workers through a pipe: cluster labels
+        travel in the narrowest integer type that holds them."""
+        state = self.__dict__.copy()
+        data = dict(state['data'])
+        labels = data.get('assignments')
+        if isinstance(labels, np.ndarray) and labels.dtype.kind == 'i' \
+                and labels.size:
+            for narrow in (np.int16, np.int32):
+                if labels.min() >= np.iinfo(narrow).min \
+                        and labels.max() <= np.iinfo(narrow).max:
+                    data['assignments'] = labels.astype(narrow)
+                    state['_label_dtype'] = labels.dtype.str
+                    break
+        state['data'] = data
+        return state
+
+    def __setstate__(self, state):
+        wide = state.pop('_label_dtype', None)
+        self.__dict__.update(state)
+        if wide is not None:
+            self.data['assignments'] = \
+                self.data['assignments'].astype(np.dtype(wide))
+
     def drop_unused_tail(self):
         """Slots never written still hold MAP == 0 (MCMC.py:431-436)."""
         unused = int((self.data['MAP'] == 0).sum())

@@ -123,9 +123,11 @@ class CRP:
 
     def __getstate__(self):
         """Pickle / deepcopy (libs/MCMC.py:115-128): the device context and
-        its caches are dropped, and the float64 data matrix travels as int8
-        codes 0 | 1 | 3 (8x smaller: the chain hand-off through the pool's
-        pipes is 2 GB per direction at config 5 otherwise)."""
+        its caches are dropped; the float64 data matrix travels as int8 codes
+        0 | 1 | 3 and the (N, M) parameter table as the rows of the populated
+        clusters only (rows of unpopulated ids are never read before they are
+        overwritten, libs/CRP.py:291-294, 455-457).  The chain hand-off
+        through the pool's pipes is 3 GB per direction at config 5 otherwise."""
         state = self.__dict__.copy()
         state['_ctx'] = None
         state['_newcl'] = None
@@ -134,15 +136,29 @@ class CRP:
         data = state.pop('data')
         state['_data_codes'] = np.where(np.isnan(data), 3, data) \
             .astype(np.int8)
+        theta = state.get('parameters')
+        if isinstance(theta, np.ndarray) and theta.ndim == 2 \
+                and self.cells_per_cluster is not None \
+                and 4 * len(self.cells_per_cluster) < theta.shape[0]:
+            live = np.sort(np.fromiter(self.cells_per_cluster.keys(),
+                dtype=np.int64))
+            del state['parameters']
+            state['_theta_rows'] = (theta.shape, theta.dtype.str, live,
+                theta[live])
         return state
 
     def __setstate__(self, state):
         codes = state.pop('_data_codes', None)
+        rows = state.pop('_theta_rows', None)
         self.__dict__.update(state)
         if codes is not None:
             data = codes.astype(np.float64)
             data[codes == 3] = np.nan
             self.data = data
+        if rows is not None:
+            shape, dtype, live, values = rows
+            self.parameters = np.zeros(shape, dtype=np.dtype(dtype))
+            self.parameters[live] = values
 
     def _dev(self):
         """The device context of this chain, created on first use."""

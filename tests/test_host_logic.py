@@ -280,6 +280,53 @@ def test_pickle_and_deepcopy_drop_the_device_context():
         assert clone._ctx is not None
 
 
+def test_hand_off_is_compact_and_lossless():
+    """What crosses the pool's pipes (libs/MCMC.py:113-120): parameter rows of
+    populated clusters only, labels in a narrow integer type - and a chain
+    that is pickled mid-run continues exactly like one that is not."""
+    from bnpc_amd.mcmc import Chain_steps
+    data = synth(6, 80, 50, 3, 0.1)
+    knobs = dict(sm_prob=.33, dpa_prob=.25, error_prob=.25,
+        sm_ratios=[.75, .25], sm_steps=2,
+        param_proposal_sd=np.array([0.1, 0.25, 0.5]))
+
+    def start():
+        np.random.seed(11)
+        m = make(P, 'learn', data)
+        m.init()
+        chain = Chain_steps(m, 1, 24, 8, knobs, 0, False)
+        for i in range(1, 13):
+            chain.do_step()
+            chain.update_results(i, i < 8)
+        return chain
+
+    a, b = start(), start()
+    assert len(a.model.cells_per_cluster) * 4 < 80
+    state = a.model.__getstate__()
+    assert 'parameters' not in state
+    shape, _, live, rows = state['_theta_rows']
+    assert shape == (80, 50) and rows.shape == (live.size, 50)
+    rng = np.random.get_state()
+    assert rows.nbytes * 4 < a.model.parameters.nbytes
+    wire = a.trace.__getstate__()['data']['assignments']
+    assert wire.dtype == np.int16 and np.array_equal(wire,
+        a.results['assignments'])
+    a = pickle.loads(pickle.dumps(a))
+    assert a.results['assignments'].dtype == b.results['assignments'].dtype
+    live_ids = sorted(a.model.cells_per_cluster)
+    assert np.array_equal(a.model.parameters[live_ids],
+        b.model.parameters[live_ids])
+    outs = []
+    for chain in (a, b):
+        np.random.set_state(rng)
+        for i in range(13, 25):
+            chain.do_step()
+            chain.update_results(i, False)
+        outs.append(chain.results)
+    for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP', 'assignments', 'params'):
+        assert np.array_equal(outs[0][key], outs[1][key]), key
+
+
 def test_module_path_of_the_drop_in_classes():
     import libs.CRP
     import libs.CRP_learning_errors
