@@ -11,7 +11,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libbnpc_hip.so')
 
-MAX_VIEWS = 4
+MAX_VIEWS = 5
 MAX_TRIALS = 4
 
 _i64 = C.c_int64
@@ -54,6 +54,9 @@ SIGNATURES = {
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, C.POINTER(_pd)]),
+    'bnpc_ll_rows_issue': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
+        C.c_double, _i64, C.c_int]),
+    'bnpc_ll_rows_wait': (C.c_int, [_ctx, C.c_int, C.POINTER(_pd)]),
     'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
     'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
     'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
@@ -345,6 +348,20 @@ class Context:
         if n == 0:
             return np.empty((0, ld))
         return np.ctypeslib.as_array(host, shape=(n, ld))
+
+    def ll_rows_issue(self, view, rows, FP, FN, ld, slot):
+        """Start ll_rows_pinned for pinned buffer `slot` (0 | 1) and return."""
+        rows = as_i64(rows)
+        check(self._lib.bnpc_ll_rows_issue(self._h, view,
+            ptr(rows, C.c_int64), rows.size, float(FP), float(FN), ld, slot),
+            'll_rows_issue')
+
+    def ll_rows_wait(self, slot, n_rows, ld):
+        """The (n_rows, ld) result of the tile issued on `slot`."""
+        host = _pd()
+        check(self._lib.bnpc_ll_rows_wait(self._h, slot, C.byref(host)),
+            'll_rows_wait')
+        return np.ctypeslib.as_array(host, shape=(n_rows, ld))
 
     def ll_tables(self, view, L1, L0, out=None):
         L1 = np.ascontiguousarray(L1, dtype=np.float64)

@@ -106,6 +106,14 @@ struct bnpc_ctx {
     void *pin = nullptr;
     size_t pin_cap = 0;
     void *pin_small = nullptr;
+    // double-buffered pinned results of issued (asynchronous) tiles
+    void *tile_pin[2] = {nullptr, nullptr};
+    size_t tile_cap[2] = {0, 0};
+    size_t tile_bytes[2] = {0, 0};
+    void *tile_rows[2] = {nullptr, nullptr};    // pinned staging of the ids
+    size_t tile_rows_cap[2] = {0, 0};
+    hipEvent_t tile_done[2] = {nullptr, nullptr};
+    bool tile_pending[2] = {false, false};
     // configuration of the last k_ll launch (bnpc_bench_ll re-issues it)
     int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
@@ -751,6 +759,11 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->rows) (void)hipFree(c->rows);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
+    for (int s = 0; s < 2; s++) {
+        if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
+        if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
+        if (c->tile_done[s]) (void)hipEventDestroy(c->tile_done[s]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1074,6 +1087,77 @@ extern "C" int bnpc_ll_rows_pinned(bnpc_ctx *c, int view, const int64_t *rows,
                           c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *host = (double *)c->pin;
+    return 0;
+}
+
+static int ensure_host(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return 0;
+    if (*p) HIPCHK(hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return 0;
+}
+
+// bnpc_ll_rows_pinned without the final wait: everything is enqueued on the
+// context's stream and an event marks the completion of the copy into the
+// slot's own pinned buffer.
+extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
+                                  int64_t K, double FP, double FN, int64_t ldo,
+                                  int slot)
+{
+    ARGCHK(c && rows, "NULL argument");
+    ARGCHK(slot == 0 || slot == 1, "slot must be 0 or 1");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(K > 0, "K must be positive");
+    ARGCHK(FP > 0.0 && FP < 1.0 && FN > 0.0 && FN < 1.0,
+           "error rates must lie in (0, 1)");
+    ARGCHK(!c->tile_pending[slot], "slot has an unconsumed tile");
+    for (int64_t k = 0; k < K; k++)
+        ARGCHK(rows[k] >= 0 && rows[k] < c->store_rows,
+               "row is not in the resident parameter store");
+    if (ldo == 0) ldo = K;
+    ARGCHK(ldo >= K, "ldo smaller than K");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
+    ARGCHK(bytes > 0, "empty view");
+    if (!c->tile_done[slot])
+        HIPCHK(hipEventCreateWithFlags(&c->tile_done[slot],
+                                       hipEventDisableTiming));
+    if (ensure_host(&c->tile_pin[slot], &c->tile_cap[slot], bytes)) return 1;
+    if (ensure_host(&c->tile_rows[slot], &c->tile_rows_cap[slot],
+                    K * sizeof(long long)))
+        return 1;
+    memcpy(c->tile_rows[slot], rows, K * sizeof(long long));
+    if (ensure(c->row_idx, K * sizeof(long long))) return 1;
+    HIPCHK(hipMemcpyAsync(c->row_idx.p, c->tile_rows[slot],
+                          K * sizeof(long long), hipMemcpyHostToDevice,
+                          c->stream));
+    c->use_rows = (const long long *)c->row_idx.p;
+    int rc = ll_common(c, view, K, ldo, true, FP, FN, nullptr);
+    c->use_rows = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->tile_pin[slot], c->out.p, bytes,
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->tile_done[slot], c->stream));
+    c->tile_bytes[slot] = bytes;
+    c->tile_pending[slot] = true;
+    return 0;
+}
+
+extern "C" int bnpc_ll_rows_wait(bnpc_ctx *c, int slot, double **host)
+{
+    ARGCHK(c && host, "NULL argument");
+    ARGCHK(slot == 0 || slot == 1, "slot must be 0 or 1");
+    *host = nullptr;
+    ARGCHK(c->tile_pending[slot], "no tile was issued on this slot");
+    HIPCHK(hipSetDevice(c->device));
+    c->tile_pending[slot] = false;
+    HIPCHK(hipEventSynchronize(c->tile_done[slot]));
+    *host = (double *)c->tile_pin[slot];
     return 0;
 }
 

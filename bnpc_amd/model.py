@@ -75,6 +75,22 @@ def _host_pool():
     return _POOL['pool']
 
 
+def _rowwise(fn, x):
+    """fn(x) for an elementwise `fn` over a 2-D array, row blocks on the host
+    threads when the array is large (same values: elementwise)."""
+    parts = _host_parts(x.size, x.shape[0])
+    pool = _host_pool() if parts > 1 else None
+    if pool is None:
+        return fn(x)
+    parts = min(parts, pool._max_workers)
+    edges = np.linspace(0, x.shape[0], parts + 1, dtype=int)
+    return np.concatenate(list(pool.map(lambda lo_hi: fn(x[lo_hi[0]:lo_hi[1]]),
+        zip(edges[:-1], edges[1:]))))
+
+
+# spare columns of an issued tile: clusters (re)born before / while it is walked
+_TILE_SPARE = 48
+
 VIEW_ALL = 0      # identity view: all cells
 VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
 VIEW_ONE = 2      # a single cell (get_lpost_single)
@@ -379,7 +395,8 @@ class CRP:
             theta = self.parameters[ids]
             density = self._known_prior(ids, theta)     # rows kept by the MH
             if density is None:
-                density = fastdist.beta_logpdf(theta, self.p, self.q)
+                density = _rowwise(
+                    lambda t: fastdist.beta_logpdf(t, self.p, self.q), theta)
             lprior += np.cumsum(density.ravel())[-1]
         return lprior
 
@@ -411,22 +428,46 @@ class CRP:
         K_start = ids.size
 
         budget = int(os.environ.get('BNPC_SWEEP_BYTES', 256 << 20))
-        pos, opened, tiles = 0, 0, 0
-        while pos < N:
-            K = ids.size
-            rows_fit = max(64, budget // (8 * (K + 16)))
-            whole = pos == 0 and rows_fit >= N
-            pos_end = N if whole else min(N, pos + rows_fit)
-            if pos == 0 and not whole:
-                # tiled sweep: the parameter rows stay resident on the device
-                # (row = cluster id); tiles select the live ones by index
-                self._dev().theta_put(0, self.parameters[:int(ids.max()) + 1])
-            ids, sizes, n_new = self._gibbs_window(
-                perm, pos, pos_end, whole, ids, sizes, assignment, post_new,
-                crp_prior)
-            opened += n_new
-            tiles += 1
-            pos = pos_end
+        ctx = self._dev()
+        if budget // (8 * (ids.size + 16)) >= N:
+            # the whole matrix in one launch, rows = cell ids
+            ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids], self.FP,
+                self.FN, ids.size + 16)
+            ids, sizes, born = self._gibbs_window(perm, 0, N, VIEW_ALL, ll,
+                ids, ids, sizes, (), assignment, post_new, crp_prior)
+            opened, tiles = len(born), 1
+        else:
+            # Tiled sweep.  The parameter rows stay resident on the device
+            # (row = cluster id) and tiles select clusters by index.  Tile
+            # t+1 is ISSUED before the host walks tile t, for the clusters
+            # alive at that moment - a superset of what it will need, minus
+            # the few clusters (re)born while tile t is walked, whose columns
+            # are evaluated when the tile is picked up.
+            ctx.theta_put(0, self.parameters[:int(ids.max()) + 1])
+
+            def issue(start, slot):
+                rows = max(64, budget // (8 * (ids.size + _TILE_SPARE)))
+                tile = dict(pos=start, end=min(N, start + rows), slot=slot,
+                    view=VIEW_SWEEP + slot, cols=ids.copy(),
+                    ld=ids.size + _TILE_SPARE)
+                ctx.view_set(tile['view'], perm[start:tile['end']])
+                ctx.ll_rows_issue(tile['view'], tile['cols'], self.FP,
+                    self.FN, tile['ld'], slot)
+                return tile
+
+            opened, tiles, born = 0, 0, ()
+            tile = issue(0, 0)
+            while tile is not None:
+                ll = ctx.ll_rows_wait(tile['slot'], tile['end'] - tile['pos'],
+                    tile['ld'])
+                ahead = issue(tile['end'], tile['slot'] ^ 1) \
+                    if tile['end'] < N else None
+                ids, sizes, born = self._gibbs_window(perm, tile['pos'],
+                    tile['end'], tile['view'], ll, tile['cols'], ids, sizes,
+                    born, assignment, post_new, crp_prior)
+                opened += len(born)
+                tiles += 1
+                tile = ahead
         if timing:
             print(f'[bnpc] gibbs N={N} K={K_start}->{ids.size}: '
                 f'{time.perf_counter() - t_start:.3f}s in {tiles} tile(s), '
@@ -436,50 +477,59 @@ class CRP:
         self.cells_per_cluster = {
             int(i): int(n) for i, n in zip(ids, sizes)}
 
-    def _gibbs_window(self, perm, pos, pos_end, whole, ids, sizes, assignment,
-                post_new, crp_prior):
-        """Positions [pos, pos_end) of the sweep against the clusters `ids`
-        (dict order) with `sizes`.  Returns the live clusters (dict order)
-        after the window."""
+    def _gibbs_window(self, perm, pos, pos_end, view, ll, cols, ids, sizes,
+                stale, assignment, post_new, crp_prior):
+        """Positions [pos, pos_end) of the sweep.
+
+        ll: (rows, ld) matrix whose first cols.size columns were evaluated for
+        the cluster ids `cols` (rows = cell ids for VIEW_ALL, tile positions
+        otherwise); `ids`/`sizes`: the clusters alive now, dict order - a
+        subset of `cols` plus the ids in `stale` (clusters (re)born after the
+        matrix was issued: their columns are evaluated here).  Returns the
+        live clusters (dict order) after the window and the ids born in it."""
         lib = _lib.load()
         ctx = self._dev()
         N = self.cells_total
-        K = ids.size
+        whole = view == VIEW_ALL
+        n_rows, ld = ll.shape
         tile_timing = os.environ.get('BNPC_TIMING') == '2'
         if tile_timing:
             import time
             t0 = time.perf_counter()
-        if whole:
-            view, n_rows = VIEW_ALL, N
-        else:
-            view, n_rows = VIEW_SWEEP, pos_end - pos
-            ctx.view_set(VIEW_SWEEP, perm[pos:pos_end])
-        ld = K + 16
-        if tile_timing:
-            t1 = time.perf_counter()
-        # pinned host buffer of the context: read (and extended) in place
-        if whole:
-            ll = ctx.ll_theta_pinned(view, self.parameters[ids], self.FP,
-                self.FN, ld)
-        else:
-            ll = ctx.ll_rows_pinned(view, ids, self.FP, self.FN, ld)
-        if tile_timing:
-            t2 = time.perf_counter()
 
+        # column of every live cluster: its slot in the issued matrix, or a
+        # fresh one behind them
+        col_in_ll = np.full(N, -1, dtype=np.int64)
+        col_in_ll[cols] = np.arange(cols.size)
+        if len(stale):
+            col_in_ll[np.asarray(stale, dtype=np.int64)] = -1
+        live_col = col_in_ll[ids]
+        late = np.flatnonzero(live_col < 0)
+        n_cols = cols.size + late.size
+        if n_cols + 1 > ld:
+            ll = np.concatenate([ll, np.empty((n_rows, n_cols + 16 - ld))],
+                axis=1)
+            ld = ll.shape[1]
+        if late.size:
+            live_col[late] = cols.size + np.arange(late.size)
+            ll[:, cols.size:n_cols] = ctx.ll_theta(view,
+                self.parameters[ids[late]], self.FP, self.FN)
+
+        K = ids.size
         col_of_id = np.full(N, -1, dtype=np.int64)
-        col_of_id[ids] = np.arange(K)
+        col_of_id[ids] = live_col
         col_id = np.full(ld, -1, dtype=np.int64)
-        col_id[:K] = ids
+        col_id[live_col] = ids
         col_size = np.zeros(ld, dtype=np.int64)
-        col_size[:K] = sizes
+        col_size[live_col] = sizes
         order = np.zeros(ld, dtype=np.int64)
-        order[:K] = np.arange(K)
+        order[:K] = live_col
         scratch = np.empty(2 * (ld + 1), dtype=np.float64)
 
-        st = _lib.GibbsState(N, ld, K, K, pos, -1, pos_end,
+        st = _lib.GibbsState(N, ld, n_cols, K, pos, -1, pos_end,
             -1 if whole else pos)
         i64, f64 = C.c_int64, C.c_double
-        n_new = 0
+        born = []
         while True:
             with _lib.NumpyStream() as rng:
                 _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), rng,
@@ -518,14 +568,13 @@ class CRP:
             st.n_active += 1
             st.n_cols += 1
             assignment[cell] = new_id
-            n_new += 1
+            born.append(new_id)
         live = order[:st.n_active]
         if tile_timing:
-            t3 = time.perf_counter()
-            print(f'[bnpc]   tile [{pos},{pos_end}) K={K}: gather '
-                f'{t1 - t0:.3f}s  device+D2H {t2 - t1:.3f}s  sweep '
-                f'{t3 - t2:.3f}s', flush=True)
-        return col_id[live].copy(), col_size[live].copy(), n_new
+            print(f'[bnpc]   tile [{pos},{pos_end}) cols={cols.size} '
+                f'late={late.size} born={len(born)}: host '
+                f'{time.perf_counter() - t0:.3f}s', flush=True)
+        return col_id[live].copy(), col_size[live].copy(), born
 
     def init_new_cluster(self, cell_id):
         """libs/CRP.py:291-294"""

@@ -39,7 +39,7 @@ extern "C" {
 
 typedef struct bnpc_ctx bnpc_ctx;
 
-#define BNPC_MAX_VIEWS 4
+#define BNPC_MAX_VIEWS 5
 #define BNPC_MAX_TRIALS 4
 
 /* ---- library / device ---------------------------------------------------- */
@@ -107,6 +107,18 @@ int bnpc_theta_put(bnpc_ctx *ctx, int64_t row0, const float *theta, int64_t R);
 int bnpc_ll_rows_pinned(bnpc_ctx *ctx, int view, const int64_t *rows,
                         int64_t K, double FP, double FN, int64_t ldo,
                         double **host);
+
+/* The same evaluation split in two, so that a tiled sweep overlaps the device
+ * work of tile t+1 with the host's sequential loop over tile t
+ * (libs/CRP.py:260-288 is sequential per cell, the likelihood rows are not):
+ * bnpc_ll_rows_issue enqueues tables + sums + the copy into pinned buffer
+ * `slot` (0 or 1) and returns at once; bnpc_ll_rows_wait blocks until that
+ * buffer is complete and returns it (slots x ldo doubles, valid until the next
+ * issue on the same slot).  Other calls on the context may be made in between;
+ * they queue behind the issued work. */
+int bnpc_ll_rows_issue(bnpc_ctx *ctx, int view, const int64_t *rows, int64_t K,
+                       double FP, double FN, int64_t ldo, int slot);
+int bnpc_ll_rows_wait(bnpc_ctx *ctx, int slot, double **host);
 
 /* Same sums from caller-built element tables: L1[k,m] is the value an
  * observed 1 contributes, L0[k,m] an observed 0 (both K x M float64).  With

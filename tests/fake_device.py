@@ -65,6 +65,7 @@ class FakeContext:
 
     def theta_put(self, row0, theta):
         theta = np.atleast_2d(np.asarray(theta, dtype=np.float32))
+        self._poison_in_flight(row0, theta.shape[0])
         store = getattr(self, 'store', np.zeros((0, self.M), np.float32))
         need = row0 + theta.shape[0]
         if need > store.shape[0]:
@@ -72,6 +73,27 @@ class FakeContext:
                 np.zeros((need - store.shape[0], self.M), np.float32)])
         store[row0:need] = theta
         self.store = store
+
+    def ll_rows_issue(self, view, rows, FP, FN, ld, slot):
+        self._count('ll_rows_issue')
+        tiles = self.__dict__.setdefault('tiles', {})
+        assert slot in (0, 1) and slot not in tiles
+        tiles[slot] = (np.asarray(rows).copy(),
+            self.ll_rows_pinned(view, rows, FP, FN, ld))
+
+    def ll_rows_wait(self, slot, n_rows, ld):
+        _, out = self.tiles.pop(slot)
+        assert out.shape == (n_rows, ld)
+        return out
+
+    def _poison_in_flight(self, row0, n):
+        """A parameter row rewritten while a tile is in flight makes that
+        tile's column for the id meaningless: NaN it, so that a model reading
+        it cannot go unnoticed."""
+        for rows, out in getattr(self, 'tiles', {}).values():
+            hit = np.flatnonzero((rows >= row0) & (rows < row0 + n))
+            out[:, hit] = np.nan
+            self.poisoned = getattr(self, 'poisoned', 0) + hit.size
 
     def ll_rows_pinned(self, view, rows, FP, FN, ld):
         return self.ll_theta_pinned(view, self.store[np.asarray(rows)], FP,

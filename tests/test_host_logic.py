@@ -112,6 +112,37 @@ def test_tiled_sweep_equals_whole_matrix_sweep(budget, monkeypatch):
         np.random.seed(1)
         p.update_assignments_Gibbs()
         assert p._ctx.calls['view_set'] >= 3      # several tiles were used
+        assert p._ctx.calls['ll_rows_issue'] >= 3 and not p._ctx.tiles
+
+
+def test_tiles_issued_ahead_never_serve_a_reborn_cluster(monkeypatch):
+    """Tile t+1 is evaluated while tile t is walked.  A cluster that dies in
+    tile t and whose id is re-used by a cluster born in tile t has a stale
+    column in tile t+1 (the stand-in device poisons it with NaN): the sweep
+    must evaluate that cluster afresh - and still equal the oracle."""
+    monkeypatch.setenv('BNPC_SWEEP_BYTES', '20000')
+    rng = np.random.RandomState(8)
+    profiles = (rng.random_sample((30, 40)) < 0.5).astype(float)
+    data = np.repeat(profiles, 8, axis=0)[rng.permutation(240)]
+    data[rng.random_sample(data.shape) < 0.05] = np.nan
+    poisoned = 0
+    for seed in range(6):
+        models = []
+        for mod in (O, P):
+            m = mod.CRP(data, DP_alpha=[60, 1], param_beta=[.25, .25],
+                FN_error=0.02, FP_error=0.02)
+            np.random.seed(seed)
+            m.init()                # ~150 clusters of 1-2 cells: many die
+            np.random.seed(50 + seed)
+            m.update_assignments_Gibbs()
+            models.append(m)
+        o, p = models
+        assert np.array_equal(o.assignment, p.assignment)
+        assert list(o.cells_per_cluster.items()) == \
+            list(p.cells_per_cluster.items())
+        assert p._ctx.calls['ll_rows_issue'] >= 3
+        poisoned += getattr(p._ctx, 'poisoned', 0)
+    assert poisoned > 0         # the situation did occur
 
 
 @pytest.mark.parametrize('kind', ['fixed', 'learn'])
