@@ -106,6 +106,11 @@ struct bnpc_ctx {
     void *pin = nullptr;
     size_t pin_cap = 0;
     void *pin_small = nullptr;
+    // side lane: a second stream with its own scratch, used by the small
+    // synchronous calls (one column for a cluster opened mid-sweep) while an
+    // issued tile occupies the main stream - they must not queue behind it
+    hipStream_t side_stream = nullptr;
+    DevBuf side_theta, side_tabs, side_out, side_part;
     // double-buffered pinned results of issued (asynchronous) tiles
     void *tile_pin[2] = {nullptr, nullptr};
     size_t tile_cap[2] = {0, 0};
@@ -142,6 +147,31 @@ static int ensure_pin(bnpc_ctx *c, size_t bytes)
     c->pin_cap = cap;
     return 0;
 }
+
+// While a tile is in flight, run a call on the side lane: swap the stream and
+// the scratch buffers the likelihood path uses, restore on scope exit.
+struct SideLane {
+    bnpc_ctx *c;
+    bool on;
+    explicit SideLane(bnpc_ctx *ctx)
+        : c(ctx), on(ctx->side_stream
+                     && (ctx->tile_pending[0] || ctx->tile_pending[1]))
+    {
+        if (on) flip();
+    }
+    ~SideLane()
+    {
+        if (on) flip();
+    }
+    void flip()
+    {
+        std::swap(c->stream, c->side_stream);
+        std::swap(c->theta, c->side_theta);
+        std::swap(c->tabs, c->side_tabs);
+        std::swap(c->out, c->side_out);
+        std::swap(c->part, c->side_part);
+    }
+};
 
 // ---------------------------------------------------------------------------
 // K1: gather rows of a cell list and transpose 64x64 bit tiles into lane masks
@@ -749,9 +779,12 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
                       &c->chunks, &c->cnt, &c->partial, &c->part,
-                      &c->lab_cnt, &c->theta_store, &c->row_idx};
+                      &c->lab_cnt, &c->theta_store, &c->row_idx,
+                      &c->side_theta, &c->side_tabs, &c->side_out,
+                      &c->side_part};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (View &v : c->views)
@@ -767,6 +800,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     delete c;
     return 0;
 }
@@ -993,11 +1027,15 @@ extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
            "error rates must lie in (0, 1)");
     HIPCHK(hipSetDevice(c->device));
     if (K == 0) return 0;
+    SideLane lane(c);
     const size_t bytes = (size_t)K * c->M * sizeof(float);
     if (ensure(c->theta, bytes)) return 1;
     HIPCHK(hipMemcpyAsync(c->theta.p, theta, bytes, hipMemcpyHostToDevice,
                           c->stream));
-    return ll_common(c, view, K, ldo, true, FP, FN, out);
+    int rc = ll_common(c, view, K, ldo, true, FP, FN, out);
+    if (lane.on && !out && rc == 0)     // the lane must be idle when it flips
+        HIPCHK(hipStreamSynchronize(c->stream));
+    return rc;
 }
 
 // Same as bnpc_ll_theta, but the result lands in a context-owned PINNED host
@@ -1013,6 +1051,8 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     if (ldo == 0) ldo = K;
     ARGCHK(ldo >= K, "ldo smaller than K");
     *host = nullptr;
+    ARGCHK(!c->tile_pending[0] && !c->tile_pending[1],
+           "not available while an issued tile is in flight");
     int rc = bnpc_ll_theta(c, view, theta, K, FP, FN, nullptr, ldo);
     if (rc) return rc;
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
@@ -1047,6 +1087,7 @@ extern "C" int bnpc_theta_put(bnpc_ctx *c, int64_t row0, const float *theta,
         }
         c->theta_store = bigger;
     }
+    SideLane lane(c);
     HIPCHK(hipMemcpyAsync((char *)c->theta_store.p + (size_t)row0 * row_bytes,
                           theta, (size_t)R * row_bytes, hipMemcpyHostToDevice,
                           c->stream));
@@ -1127,6 +1168,9 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
     if (!c->tile_done[slot])
         HIPCHK(hipEventCreateWithFlags(&c->tile_done[slot],
                                        hipEventDisableTiming));
+    if (!c->side_stream)
+        HIPCHK(hipStreamCreateWithFlags(&c->side_stream,
+                                        hipStreamNonBlocking));
     if (ensure_host(&c->tile_pin[slot], &c->tile_cap[slot], bytes)) return 1;
     if (ensure_host(&c->tile_rows[slot], &c->tile_rows_cap[slot],
                     K * sizeof(long long)))

@@ -445,8 +445,11 @@ class CRP:
             # are evaluated when the tile is picked up.
             ctx.theta_put(0, self.parameters[:int(ids.max()) + 1])
 
+            tile_bytes = min(budget,
+                int(os.environ.get('BNPC_TILE_BYTES', 64 << 20)))
+
             def issue(start, slot):
-                rows = max(64, budget // (8 * (ids.size + _TILE_SPARE)))
+                rows = max(64, tile_bytes // (8 * (ids.size + _TILE_SPARE)))
                 tile = dict(pos=start, end=min(N, start + rows), slot=slot,
                     view=VIEW_SWEEP + slot, cols=ids.copy(),
                     ld=ids.size + _TILE_SPARE)
