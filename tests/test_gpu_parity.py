@@ -359,18 +359,21 @@ def test_config2_chain_matches_oracle():
     np.testing.assert_allclose(rp['ML'], ro['ML'], rtol=1e-9)
 
 
-def test_config3_full_size_trajectory_matches_oracle_fixture(golden_dir):
-    """BASELINE config 3 at FULL size (5000 x 1000, 20 % missing, learned
-    errors, CLI-default moves), 9 steps including the first sweep from
-    K0 = 3152 clusters: the device chain walks the trajectory the CPU oracle
-    produced (tests/golden/make_c3_trajectory.py, ~3 CPU-minutes)."""
+@pytest.mark.parametrize('cfg', ['c3', 'c4'])
+def test_full_size_trajectory_matches_oracle_fixture(cfg, golden_dir):
+    """BASELINE configs 3 and 4 at FULL size (5000 x 1000 and 10000 x 2000,
+    20 % missing, learned errors, CLI-default moves), 9 steps including the
+    first sweep from K0 = 3152 / 6325 clusters (config 4: after four
+    split/merge attempts at K0, each with a K0 x M proposal batch): the device
+    chain walks the trajectory the CPU oracle produced
+    (tests/golden/make_c3_trajectory.py; 3 and 24 CPU-minutes)."""
     import bench
     import libs.CRP_learning_errors as dev
     from bnpc_amd.mcmc import MCMC
     import contextlib
     import io
-    t = np.load(os.path.join(golden_dir, 'c3_trajectory.npz'))
-    N, M, C, miss, learned = bench.CONFIGS['c3']
+    t = np.load(os.path.join(golden_dir, f'{cfg}_trajectory.npz'))
+    N, M, C, miss, learned = bench.CONFIGS[cfg]
     data = bench.synth(0, N, M, C, miss)
     model = bench.make_model(None, dev, data, learned)
     mcmc = MCMC(model, error_prob=.25, **bench.MCMC_PARAMS)
