@@ -71,6 +71,7 @@ SIGNATURES = {
     'bnpc_mt_mh_draws': (C.c_int, [C.POINTER(MT19937), _i64, _i64, _i64,
         _pi32, _pd, _pd]),
     'bnpc_log_diff_pi': (C.c_int, [_pd, _pd, _i64, _pd]),
+    'bnpc_dominated_cdf': (C.c_int, [_i64, _i64, _pd]),
     'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
     'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,

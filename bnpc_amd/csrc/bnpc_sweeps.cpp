@@ -162,6 +162,53 @@ extern "C" int bnpc_log_diff_pi(const double *log_p, const double *log_q,
 static const double LOG_EPS = -34.538776394910684;   // np.log(1e-15)
 static const double EXP_LOG_EPS = exp(LOG_EPS);       // the probability floor
 
+// floor_sums(k)[j] = the floor added to 0.0 j times, one by one (what a
+// sequential cumsum over j clipped probabilities holds), for j <= k.
+static const double *floor_sums(int64_t k)
+{
+    static thread_local std::vector<double> sums(1, 0.0);
+    while ((int64_t)sums.size() <= k + 1)
+        sums.push_back(sums.back() + EXP_LOG_EPS);
+    return sums.data();
+}
+
+// For x in [1, 2): fl(x + floor) = x + FLOOR_STEP * 2^-52, because the floor
+// is 4.5036 ulps of such x - never a tie.  Checked once against the adder.
+static int64_t floor_step_ulps()
+{
+    const double x = 1.0 + 12345 * 0x1p-52;
+    const double y = x + EXP_LOG_EPS;
+    const int64_t step = (int64_t)((y - x) * 0x1p52);
+    const double frac = EXP_LOG_EPS * 0x1p52 - (double)(step - 1);
+    // the rounding must not be a near-tie and must be the same at both ends
+    if (!(frac > 0.501 && frac < 0.999)) return -1;
+    const double z = (2.0 - 64 * 0x1p-52) + EXP_LOG_EPS;
+    if ((int64_t)((z - (2.0 - 64 * 0x1p-52)) * 0x1p52) != step) return -1;
+    return step;
+}
+static const int64_t FLOOR_STEP = floor_step_ulps();
+
+// The running sums the dominated fast path of bnpc_gibbs_sweep uses instead
+// of walking np.cumsum: cdf[a], a = 0..A, of the probability vector that is
+// 1.0 at `top` and the floor elsewhere (exported for the tests).
+extern "C" int bnpc_dominated_cdf(int64_t A, int64_t top, double *cdf)
+{
+    if (!cdf || A < 0 || top < 0 || top > A) {
+        bnpc_set_error("bad argument: dominated_cdf");
+        return 2;
+    }
+    if (FLOOR_STEP <= 0) {
+        bnpc_set_error("closed form not available on this host");
+        return 1;
+    }
+    const double *fs = floor_sums(top);
+    const double at_top = fs[top] + 1.0;
+    for (int64_t a = 0; a <= A; a++)
+        cdf[a] = a < top ? fs[a + 1]
+            : at_top + (double)(FLOOR_STEP * (a - top)) * 0x1p-52;
+    return 0;
+}
+
 extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                                 const int64_t *perm, const double *ll,
                                 const double *post_new,
@@ -259,22 +306,37 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // _normalize_log_probs (CRP.py:88-100) + choice(p=): cdf = cumsum(p);
         // cdf /= cdf[-1]; searchsorted(u, right).
         const double ptop = post[top];
-        double run = 0.0;
-        if (second - ptop < -39.0 - log((double)(A + 1))) {
+        const double u_dominated = -39.0 - log((double)(A + 1));
+        int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
+        if (FLOOR_STEP > 0 && second - ptop < u_dominated) {
             // One cluster dominates: the tail sum of exponentials is below
             // 2^-55, so log1p(tail) == tail < half an ulp of 1: the winner's
             // probability is exp(-tail) == 1.0 exactly and every other entry
             // sits below the floor log(1e-15) and is clipped to it.  No
             // exponential has to be evaluated (the usual case once the
-            // clusters have separated), with bit-identical probabilities.
-            for (int64_t a = 0; a <= A; a++) {
-                run += (a == top) ? 1.0 : EXP_LOG_EPS;
-                cdf[a] = run;
+            // clusters have separated), with bit-identical probabilities -
+            // and the running sums np.cumsum would produce are known without
+            // walking them: `top` copies of the floor added one by one
+            // (floor_sums), then + 1.0, then every further floor moves the
+            // sum, which now lies in [1, 2), by exactly FLOOR_STEP ulps.
+            const double *fs = floor_sums(top);
+            const double at_top = fs[top] + 1.0;
+            auto cdf_at = [&](int64_t a) {
+                return a < top ? fs[a + 1]
+                    : at_top + (double)(FLOOR_STEP * (a - top)) * 0x1p-52;
+            };
+            const double total = cdf_at(A);
+            const double u = mt_double(rng);
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cdf_at(mid) / total > u) hi = mid;
+                else lo = mid + 1;
             }
         } else {
             // exp() is still skipped where its result is known exactly:
             // exp(d) == 0.0 for d < -746 (below the smallest subnormal), and
             // every entry clipped at log(1e-15) contributes exp(LOG_EPS).
+            double run = 0.0;
             double tail = 0.0;
             for (int64_t a = 0; a <= A; a++) {
                 if (a == top) continue;
@@ -288,14 +350,13 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 else run += exp(v > 0.0 ? 0.0 : v);
                 cdf[a] = run;
             }
-        }
-        const double total = cdf[A];
-        const double u = mt_double(rng);
-        int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (cdf[mid] / total > u) hi = mid;
-            else lo = mid + 1;
+            const double total = cdf[A];
+            const double u = mt_double(rng);
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (cdf[mid] / total > u) hi = mid;
+                else lo = mid + 1;
+            }
         }
         int64_t pick = lo;
         if (pick > A) pick = A;

@@ -205,6 +205,13 @@ int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
 int bnpc_log_diff_pi(const double *log_p, const double *log_q, int64_t n,
                      double *out);
 
+/* Checker hook: the cumulative sums np.cumsum(p) holds for the probability
+ * vector p[top] = 1.0, p[a != top] = 1e-15-floor (a = 0..A) - the case in
+ * which one cluster dominates _normalize_log_probs (libs/CRP.py:88-100).  The
+ * native sweep evaluates them in closed form instead of walking the array;
+ * the tests compare this with NumPy's cumsum bit for bit. */
+int bnpc_dominated_cdf(int64_t A, int64_t top, double *cdf);
+
 /* The sequential per-cell loop of CRP.update_assignments_Gibbs
  * (libs/CRP.py:260-288, with _normalize_log_probs :88-100 and
  * np.random.choice(p=...) :276-277) over a precomputed log-likelihood matrix.

@@ -282,3 +282,52 @@ def test_stream_in_place_and_copy_fallback(monkeypatch):
     ref = (np.random.random(), np.random.random(),
         np.random.permutation(50).tolist(), np.random.random())
     assert outs[0] == ref
+
+
+def test_dominated_cdf_closed_form_equals_numpy_cumsum():
+    """One cluster dominates -> p = (floor, ..., 1.0, ..., floor).  The native
+    sweep does not walk np.cumsum(p) but evaluates it in closed form
+    (bnpc_dominated_cdf): identical bits for every position of the winner,
+    from 1 to 40000 entries."""
+    lib = _lib.load()
+    floor = np.exp(np.clip(np.array([-1e3]), O.log_EPSILON, 0))[0]
+    rng = np.random.RandomState(0)
+    for A in (0, 1, 2, 7, 300, 4097, 40000):
+        tops = {0, A, A // 2, A // 3} | set(rng.randint(0, A + 1, 4).tolist())
+        for top in sorted(tops):
+            p = np.full(A + 1, floor)
+            p[top] = 1.0
+            want = np.cumsum(p)
+            got = np.empty(A + 1)
+            _lib.check(lib.bnpc_dominated_cdf(A, top, _lib.ptr(got, f64)),
+                'dominated_cdf')
+            assert np.array_equal(want, got), (A, top)
+    assert lib.bnpc_dominated_cdf(3, 4, _lib.ptr(np.empty(4), f64)) == 2
+
+
+def test_dominated_rows_with_thousands_of_clusters():
+    """The shape of a first sweep: thousands of live clusters, one of them
+    far ahead for every cell.  Native loop == NumPy loop."""
+    rng = np.random.RandomState(3)
+    N, K = 2100, 2000
+    ll = -rng.random_sample((N, K)) * 50 - 400
+    best = rng.randint(0, K, N)
+    ll[np.arange(N), best] = -5.0
+    post_new = np.full(N, -300.0)
+    post_new[::97] = -1.0           # some cells open a cluster instead
+    alpha = 2.5
+    crp_prior = np.append(0, O.CRP.log_CRP_prior(
+        np.append(np.arange(1, N + 1), alpha), N, alpha))
+    labels = np.append(np.arange(K), rng.randint(0, K, N - K))
+    sizes = {}
+    for lab in labels:
+        sizes[int(lab)] = sizes.get(int(lab), 0) + 1
+    new_columns = [-rng.random_sample(N) * 5 - 2 for _ in range(N)]
+    np.random.seed(9)
+    ref = reference_gibbs(ll, post_new, crp_prior, labels, dict(sizes),
+        new_columns)
+    np.random.seed(9)
+    got = native_gibbs(ll, post_new, crp_prior, labels, dict(sizes),
+        new_columns)
+    assert np.array_equal(ref[0], got[0]) and ref[1] == got[1]
+    assert ref[2] == got[2] and ref[2] > 0
