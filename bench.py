@@ -44,7 +44,10 @@ CONFIGS = {
     'c2': (1000, 200, 10, 0.10, False),
     'c3': (5000, 1000, 10, 0.20, True),
     'c4': (10000, 2000, 20, 0.20, True),
+    'c5': (50000, 5000, 50, 0.20, True),   # -smp 0.5 -sms 5 (MOVE_OVERRIDES)
 }
+# move settings that differ from the CLI defaults (BASELINE.json configs)
+MOVE_OVERRIDES = {'c5': dict(sm_prob=.5, sm_steps=5)}
 
 
 def synth(seed, N, M, C, miss, FP_true=0.001, FN_true=0.1):
@@ -72,10 +75,11 @@ def make_model(mod_fixed, mod_learn, data, learned):
 MCMC_PARAMS = dict(sm_prob=.33, dpa_prob=.25, sm_ratios=[.75, .25], sm_steps=3)
 
 
-def new_chain(model, learned, total_steps):
+def new_chain(model, learned, total_steps, config=None):
     from bnpc_amd.mcmc import Chain_steps
     params = dict(MCMC_PARAMS, error_prob=.25 if learned else 0.,
         param_proposal_sd=np.array([0.1, 0.25, 0.5]))
+    params.update(MOVE_OVERRIDES.get(config, {}))
     return Chain_steps(model, 1, total_steps, int(total_steps * .33), params,
         0, False)
 
@@ -191,7 +195,7 @@ def main():
     model.init()
     K0 = len(model.cells_per_cluster)
     total = args.warmup + args.steps
-    chain = new_chain(model, learned, total)
+    chain = new_chain(model, learned, total, args.config)
     burn = int(total * .33)
 
     # ---- warm-up (untimed): includes the first sweep from K0 clusters ----
@@ -240,7 +244,9 @@ def main():
         ms, alg_bytes = time_ll(K0)
         gbs = alg_bytes / (ms * 1e-3) / 1e9
         evals = N * K0 / (ms * 1e-3)
-        traffic, traffic_src = load_pmc_traffic('k_ll8_asm<2, false>')
+        # the committed PMC passes were taken on config 3's first-sweep shape
+        traffic, traffic_src = load_pmc_traffic('k_ll8_asm<2, false>') \
+            if args.config == 'c3' else (None, None)
         roofline = {
             'kernel': 'k_ll8_asm<2, false>', 'bound': 'hbm',
             'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -277,7 +283,7 @@ def main():
         om.DP_a, om.FP, om.FN = snap['DP_a'], snap['FP'], snap['FN']
         om.init_DP_prior()
         np.random.set_state(snap['rng'])
-        ochain = new_chain(om, learned, args.cpu_steps)
+        ochain = new_chain(om, learned, args.cpu_steps, args.config)
         t0 = time.perf_counter()
         for i in range(1, args.cpu_steps + 1):
             step(ochain, i, 0)
@@ -317,7 +323,10 @@ def main():
                 'workload': f'{args.config}: synthetic {N} cells x {M} muts, '
                     f'{int(miss * 100)}% missing, '
                     f'{"learned" if learned else "fixed"} errors, '
-                    '1 chain per GPU, CLI-default moves',
+                    '1 chain per GPU, '
+                    + ('moves ' + str(MOVE_OVERRIDES[args.config])
+                        if args.config in MOVE_OVERRIDES
+                        else 'CLI-default moves'),
                 'chains': world, 'data_seed': 0, 'mcmc_seed': args.seed,
                 'K0': K0, 'K_after_warmup': K_warm, 'K_end': K_end,
             },
