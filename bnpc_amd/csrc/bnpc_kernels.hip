@@ -243,6 +243,33 @@ __global__ __launch_bounds__(256) void k_tables_theta(
     }
 }
 
+// K4a for small launches: one thread per (cluster, mutation) instead of one
+// per mutation with a loop over the group's clusters - K x Mt threads rather
+// than G x Mt, so a converged K ~ 10 still fills some of the chip.  Same
+// expression, same values.
+template <int KW>
+__global__ __launch_bounds__(256) void k_tables_theta_flat(
+    const float *__restrict__ theta, const long long *__restrict__ rows,
+    int K, int M, int Mt, int G, double FP, double FN, double *__restrict__ T)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)G * KW * Mt) return;
+    const int kk = (int)(idx / Mt);             // padded cluster index
+    const int m = (int)(idx - (long long)kk * Mt);
+    const int g = kk / KW, j = kk - g * KW;
+    double l1 = 0.0, l0 = 0.0;
+    if (kk < K && m < M) {
+        const float th = theta[(size_t)(rows ? rows[kk] : kk) * M + m];
+        const double th64 = (double)th;
+        const double om64 = (double)(1.0f - th);
+        l1 = log(th64 * (1.0 - FN) + om64 * FP);
+        l0 = log(th64 * FN + om64 * (1.0 - FP));
+    }
+    double *t = T + ((size_t)g * Mt + m) * (2 * KW);
+    t[j] = l1;
+    t[KW + j] = l0;
+}
+
 // K4b: re-layout caller-built tables L1/L0 [K][M] into T[g][m][2*KW]
 template <int KW>
 __global__ __launch_bounds__(256) void k_tables_relayout(
@@ -957,7 +984,17 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     if (ensure(c->tabs, ((size_t)G * c->Mt + 8) * 2 * KW * sizeof(double)))
         return 1;
     dim3 tgrid((unsigned)((c->Mt + 255) / 256), (unsigned)G);
-    if (from_theta)
+    if (from_theta && G * KW * (int64_t)c->Mt
+            <= env_flag("BNPC_TABLES_FLAT_MAX", 1 << 20)) {
+        const int64_t threads = G * KW * (int64_t)c->Mt;
+        hipLaunchKernelGGL(k_tables_theta_flat<KW>,
+                           dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                           0, c->stream,
+                           c->use_rows ? (const float *)c->theta_store.p
+                                       : (const float *)c->theta.p,
+                           c->use_rows, (int)K, (int)c->M, c->Mt, (int)G, FP,
+                           FN, (double *)c->tabs.p);
+    } else if (from_theta)
         hipLaunchKernelGGL(k_tables_theta<KW>, tgrid, dim3(256), 0, c->stream,
                            c->use_rows ? (const float *)c->theta_store.p
                                        : (const float *)c->theta.p,
