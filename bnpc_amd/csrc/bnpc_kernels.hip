@@ -111,6 +111,13 @@ struct bnpc_ctx {
     // issued tile occupies the main stream - they must not queue behind it
     hipStream_t side_stream = nullptr;
     DevBuf side_theta, side_tabs, side_out, side_part;
+    // pinned staging arena for small host <-> device payloads (parameter
+    // rows, cell lists, counts): a copy from/to pinned memory is a plain DMA
+    // enqueue, a copy from/to pageable memory is staged by the runtime at
+    // ~10 us apiece.  Reset at the start of every call that uses it; every
+    // such call ends with a stream synchronisation.
+    void *stage = nullptr;
+    size_t stage_used = 0;
     // double-buffered pinned results of issued (asynchronous) tiles
     void *tile_pin[2] = {nullptr, nullptr};
     size_t tile_cap[2] = {0, 0};
@@ -134,6 +141,60 @@ static int ensure(DevBuf &b, size_t bytes)
     HIPCHK(hipMalloc(&b.p, cap));
     b.cap = cap;
     return 0;
+}
+
+#define STAGE_BYTES ((size_t)4 << 20)
+
+// a slot of the staging arena, or nullptr when the payload is too large
+static void *stage_slot(bnpc_ctx *c, size_t bytes)
+{
+    if (!c->stage) {
+        if (hipHostMalloc(&c->stage, STAGE_BYTES, hipHostMallocDefault)
+                != hipSuccess) {
+            c->stage = nullptr;
+            return nullptr;
+        }
+    }
+    const size_t at = (c->stage_used + 255) & ~(size_t)255;
+    if (at + bytes > STAGE_BYTES) return nullptr;
+    c->stage_used = at + bytes;
+    return (char *)c->stage + at;
+}
+
+// host -> device on the context's stream; `src` may be released on return
+// only if the caller synchronises the stream before it returns itself
+static int h2d(bnpc_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    void *slot = stage_slot(c, bytes);
+    if (slot) {
+        memcpy(slot, src, bytes);
+        src = slot;
+    }
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+// device -> host, completed by the caller's stream synchronisation followed
+// by d2h_finish (which moves the staged bytes to their destination)
+struct D2H {
+    void *dst, *slot;
+    size_t bytes;
+};
+
+static int d2h_begin(bnpc_ctx *c, D2H &t, void *dst, const void *src,
+                     size_t bytes)
+{
+    t.dst = dst;
+    t.bytes = bytes;
+    t.slot = stage_slot(c, bytes);
+    HIPCHK(hipMemcpyAsync(t.slot ? t.slot : dst, src, bytes,
+                          hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+static void d2h_finish(const D2H &t)
+{
+    if (t.slot) memcpy(t.dst, t.slot, t.bytes);
 }
 
 static int ensure_pin(bnpc_ctx *c, size_t bytes)
@@ -819,6 +880,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->rows) (void)hipFree(c->rows);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
+    if (c->stage) (void)hipHostFree(c->stage);
     for (int s = 0; s < 2; s++) {
         if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
         if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
@@ -863,8 +925,8 @@ extern "C" int bnpc_view_set(bnpc_ctx *c, int view, const int64_t *cells,
         return 0;
     }
     if (ensure(c->cells, n * sizeof(long long))) return 1;
-    HIPCHK(hipMemcpyAsync(c->cells.p, cells, n * sizeof(long long),
-                          hipMemcpyHostToDevice, c->stream));
+    c->stage_used = 0;
+    if (h2d(c, c->cells.p, cells, n * sizeof(long long))) return 1;
     if (build_view(c, view, (const long long *)c->cells.p, n)) return 1;
     // the caller's buffer is only borrowed: finish the copy before returning
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1053,9 +1115,12 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     return 0;
 }
 
-extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
-                             int64_t K, double FP, double FN, double *out,
-                             int64_t ldo)
+// `drain`: synchronise before returning even when nothing is fetched (the
+// staged parameters must have left the arena); bnpc_ll_theta_pinned passes
+// false because its own copy + synchronisation follow on the same stream.
+static int ll_theta_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
+                         double FP, double FN, double *out, int64_t ldo,
+                         bool drain)
 {
     ARGCHK(c, "ctx is NULL");
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
@@ -1067,12 +1132,23 @@ extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
     SideLane lane(c);
     const size_t bytes = (size_t)K * c->M * sizeof(float);
     if (ensure(c->theta, bytes)) return 1;
-    HIPCHK(hipMemcpyAsync(c->theta.p, theta, bytes, hipMemcpyHostToDevice,
-                          c->stream));
+    c->stage_used = 0;
+    void *slot = stage_slot(c, bytes);
+    if (slot) memcpy(slot, theta, bytes);
+    HIPCHK(hipMemcpyAsync(c->theta.p, slot ? slot : (const void *)theta, bytes,
+                          hipMemcpyHostToDevice, c->stream));
     int rc = ll_common(c, view, K, ldo, true, FP, FN, out);
-    if (lane.on && !out && rc == 0)     // the lane must be idle when it flips
+    // staged parameters / the side lane: nothing may be in flight on return
+    if (((slot && drain) || lane.on) && !out && rc == 0)
         HIPCHK(hipStreamSynchronize(c->stream));
     return rc;
+}
+
+extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
+                             int64_t K, double FP, double FN, double *out,
+                             int64_t ldo)
+{
+    return ll_theta_impl(c, view, theta, K, FP, FN, out, ldo, true);
 }
 
 // Same as bnpc_ll_theta, but the result lands in a context-owned PINNED host
@@ -1090,10 +1166,13 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     *host = nullptr;
     ARGCHK(!c->tile_pending[0] && !c->tile_pending[1],
            "not available while an issued tile is in flight");
-    int rc = bnpc_ll_theta(c, view, theta, K, FP, FN, nullptr, ldo);
+    int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
     if (rc) return rc;
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
-    if (bytes == 0) return 0;
+    if (bytes == 0) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
     if (ensure_pin(c, bytes)) return 1;
     HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
                           c->stream));
@@ -1253,11 +1332,12 @@ extern "C" int bnpc_ll_tables(bnpc_ctx *c, int view, const double *L1,
     if (K == 0) return 0;
     const size_t bytes = (size_t)K * c->M * sizeof(double);
     if (ensure(c->tab_in, 2 * bytes)) return 1;
-    HIPCHK(hipMemcpyAsync(c->tab_in.p, L1, bytes, hipMemcpyHostToDevice,
-                          c->stream));
-    HIPCHK(hipMemcpyAsync((char *)c->tab_in.p + bytes, L0, bytes,
-                          hipMemcpyHostToDevice, c->stream));
-    return ll_common(c, view, K, ldo, false, 0.0, 0.0, out);
+    c->stage_used = 0;
+    if (h2d(c, c->tab_in.p, L1, bytes)) return 1;
+    if (h2d(c, (char *)c->tab_in.p + bytes, L0, bytes)) return 1;
+    int rc = ll_common(c, view, K, ldo, false, 0.0, 0.0, out);
+    if (!out && rc == 0) HIPCHK(hipStreamSynchronize(c->stream));
+    return rc;
 }
 
 // ---- column counts ---------------------------------------------------------
@@ -1265,6 +1345,7 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
                             const int64_t *seg_offsets, int64_t G,
                             DevBuf &cnt)
 {
+    c->stage_used = 0;
     const size_t cnt_bytes = (size_t)2 * G * c->M * sizeof(int32_t);
     if (ensure(cnt, cnt_bytes)) return 1;
     HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_bytes, c->stream));
@@ -1279,11 +1360,9 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
     if (chunks.empty()) return 0;
     if (ensure(c->cells, n_cells * sizeof(long long))) return 1;
     if (ensure(c->chunks, chunks.size() * sizeof(Chunk))) return 1;
-    HIPCHK(hipMemcpyAsync(c->cells.p, cells, n_cells * sizeof(long long),
-                          hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->chunks.p, chunks.data(),
-                          chunks.size() * sizeof(Chunk),
-                          hipMemcpyHostToDevice, c->stream));
+    if (h2d(c, c->cells.p, cells, n_cells * sizeof(long long))) return 1;
+    if (h2d(c, c->chunks.p, chunks.data(), chunks.size() * sizeof(Chunk)))
+        return 1;
     int *n1 = (int *)cnt.p;
     int *n0 = n1 + (size_t)G * c->M;
     // the chunk list lives in a std::vector: finish the copy before it dies
@@ -1318,11 +1397,12 @@ extern "C" int bnpc_colcounts(bnpc_ctx *c, const int64_t *cells,
     HIPCHK(hipSetDevice(c->device));
     if (colcounts_device(c, cells, n, seg_offsets, G, c->cnt)) return 1;
     const size_t half = (size_t)G * c->M * sizeof(int32_t);
-    HIPCHK(hipMemcpyAsync(n1, c->cnt.p, half, hipMemcpyDeviceToHost,
-                          c->stream));
-    HIPCHK(hipMemcpyAsync(n0, (char *)c->cnt.p + half, half,
-                          hipMemcpyDeviceToHost, c->stream));
+    D2H a, b;
+    if (d2h_begin(c, a, n1, c->cnt.p, half)) return 1;
+    if (d2h_begin(c, b, n0, (char *)c->cnt.p + half, half)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
+    d2h_finish(a);
+    d2h_finish(b);
     return 0;
 }
 
@@ -1360,11 +1440,12 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
     c->lab_K = K;
     if (n1 && n0) {
         const size_t half = (size_t)K * c->M * sizeof(int32_t);
-        HIPCHK(hipMemcpyAsync(n1, c->lab_cnt.p, half, hipMemcpyDeviceToHost,
-                              c->stream));
-        HIPCHK(hipMemcpyAsync(n0, (char *)c->lab_cnt.p + half, half,
-                              hipMemcpyDeviceToHost, c->stream));
+        D2H a, b;
+        if (d2h_begin(c, a, n1, c->lab_cnt.p, half)) return 1;
+        if (d2h_begin(c, b, n0, (char *)c->lab_cnt.p + half, half)) return 1;
         HIPCHK(hipStreamSynchronize(c->stream));
+        d2h_finish(a);
+        d2h_finish(b);
     }
     return 0;
 }
@@ -1388,8 +1469,8 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
     if (!c->pin_small)
         HIPCHK(hipHostMalloc(&c->pin_small, TOTAL_BLOCKS * 4 * sizeof(double),
                              hipHostMallocDefault));
-    HIPCHK(hipMemcpyAsync(c->theta.p, theta, bytes, hipMemcpyHostToDevice,
-                          c->stream));
+    c->stage_used = 0;
+    if (h2d(c, c->theta.p, theta, bytes)) return 1;
     double fp[4] = {0.5, 0.5, 0.5, 0.5}, fn[4] = {0.5, 0.5, 0.5, 0.5};
     for (int e = 0; e < E; e++) {
         fp[e] = FP[e];

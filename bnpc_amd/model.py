@@ -431,8 +431,11 @@ class CRP:
         ctx = self._dev()
         if budget // (8 * (ids.size + 16)) >= N:
             # the whole matrix in one launch, rows = cell ids
+            # a few spare columns for clusters opened during the sweep (the
+            # matrix is re-allocated with more if they run out)
+            spare = max(4, min(16, ids.size // 4))
             ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids], self.FP,
-                self.FN, ids.size + 16)
+                self.FN, ids.size + spare)
             ids, sizes, born = self._gibbs_window(perm, 0, N, VIEW_ALL, ll,
                 ids, ids, sizes, (), assignment, post_new, crp_prior)
             opened, tiles = len(born), 1
