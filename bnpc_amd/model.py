@@ -47,6 +47,7 @@ TMAX = 1 - TMIN
 log_EPSILON = np.log(EPSILON)
 
 _THREAD_MIN_ELEMS = 1 << 14     # below this NumPy call overhead dominates
+_ELEMS_PER_THREAD = 8192
 _POOL = {}
 
 
@@ -57,7 +58,8 @@ def _host_parts(elems, rows):
     held between ufunc calls)."""
     if elems < _THREAD_MIN_ELEMS or rows < 2:
         return 1
-    parts = 8 if elems >= (1 << 17) else min(4, max(1, elems // 8192))
+    parts = 8 if elems >= (1 << 17) \
+        else min(4, max(1, elems // _ELEMS_PER_THREAD))
     return min(parts, rows)
 
 
