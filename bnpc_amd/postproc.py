@@ -82,13 +82,29 @@ def get_dist(assignments):
     return differ / assignments.shape[0]
 
 
+def _same_cluster(labels):
+    """Condensed (pdist order) indicator of the pairs that share a label:
+    what `1 - pdist(stack([labels, labels]).T, 'hamming')` holds
+    (utils.py:137-138), built row by row from integer comparisons instead of
+    a 2-column float distance."""
+    labels = np.asarray(labels)
+    n = labels.size
+    same = np.empty(n * (n - 1) // 2, dtype=bool)
+    at = 0
+    for i in range(n - 1):
+        np.equal(labels[i + 1:], labels[i], out=same[at:at + n - 1 - i])
+        at += n - 1 - i
+    return same
+
+
 def calc_MPEAR(pi, labels):
     """Posterior expected adjusted Rand index of a clustering
-    (Fritsch & Ickstadt 2009, eq. 13; utils.py:133-145)."""
-    from scipy.spatial.distance import pdist
+    (Fritsch & Ickstadt 2009, eq. 13; utils.py:133-145).  Same elementwise
+    products and the same NumPy reductions as the reference, so the score has
+    the same bits."""
     from scipy.special import binom
-    same = 1 - pdist(np.stack([labels, labels]).T, 'hamming')
-    I_sum, pi_sum = same.sum(), pi.sum()
+    same = _same_cluster(labels)
+    I_sum, pi_sum = float(same.sum()), pi.sum()
     expected = (I_sum * pi_sum) / binom(labels.size, 2)
     return ((same * pi).sum() - expected) \
         / (.5 * (I_sum + pi_sum) - expected)
