@@ -2,7 +2,7 @@
 """End-to-end CLI run at a large shape on one GPU box (dev tool): writes a
 synthetic matrix in the reference's text format, runs run_BnpC.py with several
 chains through the fork pool, all three estimators, and reports timings.
-usage: e2e_cli_big.py N M C chains steps"""
+usage: e2e_cli_big.py N M C chains steps [estimators...]"""
 import os
 import subprocess
 import sys
@@ -28,10 +28,10 @@ out = os.path.join(tmp, 'out')
 t0 = time.time()
 r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_BnpC.py'), path,
     '-n', str(chains), '-s', str(steps), '--seed', '1', '-np', '-o', out,
-    '-e', 'posterior', 'ML', 'MAP'], capture_output=True, text=True)
+    '-e', *(sys.argv[6:] or ['posterior', 'ML', 'MAP'])],
+    capture_output=True, text=True)
 print(r.stdout[-3000:])
 print(r.stderr[-2000:])
 print(f'CLI exit {r.returncode} in {time.time() - t0:.1f}s')
 for f in sorted(os.listdir(out)):
     print(f, os.path.getsize(os.path.join(out, f)))
-truth = np.random.RandomState(0)
