@@ -26,7 +26,8 @@
  *                block of 64 cells ("slots"): bit s of masks[b][m].ones says
  *                cell slot 64*b+s has x = 1 at mutation m.  View 0 is the
  *                identity view (all N cells in order); views 1.. are gathered
- *                cell lists (restricted-Gibbs moves).
+ *                cell lists (restricted-Gibbs moves, single cells, the two
+ *                alternating tiles of a tiled sweep).
  */
 #ifndef BNPC_HIP_H
 #define BNPC_HIP_H
