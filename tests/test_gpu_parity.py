@@ -587,3 +587,45 @@ def test_resident_parameter_rows():
     with pytest.raises(RuntimeError, match='resident parameter store'):
         ctx.ll_rows_pinned(0, np.array([50]), 0.01, 0.2, 1)
     ctx.close()
+
+
+def test_issued_tiles_overlap_other_calls():
+    """bnpc_ll_rows_issue / bnpc_ll_rows_wait: two tiles in flight on their
+    own pinned buffers give the bits of the synchronous call; calls made in
+    between (a column for a freshly opened cluster, a parameter row rewritten
+    - they run on the side lane) neither disturb them nor wait for them."""
+    rng = np.random.RandomState(7)
+    data = (rng.random_sample((900, 200)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    params = np.clip(rng.uniform(size=(300, 200)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    ctx = _lib.Context(data=data)
+    ctx.theta_put(0, params)
+    rows_a = rng.permutation(300)[:250]
+    rows_b = rng.permutation(300)[:120]
+    cells_a, cells_b = np.arange(0, 500), np.arange(400, 900)
+    ctx.view_set(3, cells_a)
+    ctx.view_set(4, cells_b)
+    want_a = ctx.ll_rows_pinned(3, rows_a, 0.01, 0.2, rows_a.size).copy()
+    want_b = ctx.ll_rows_pinned(4, rows_b, 0.02, 0.1, rows_b.size + 5).copy()
+
+    ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 0)
+    ctx.ll_rows_issue(4, rows_b, 0.02, 0.1, rows_b.size + 5, 1)
+    with pytest.raises(RuntimeError, match='unconsumed tile'):
+        ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 0)
+    # side-lane work while both tiles are in flight
+    fresh = np.clip(rng.uniform(size=(1, 200)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    col = ctx.ll_theta(3, fresh, 0.01, 0.2)
+    ctx.theta_put(299, fresh[0])
+    got_b = ctx.ll_rows_wait(1, cells_b.size, rows_b.size + 5)
+    got_a = ctx.ll_rows_wait(0, cells_a.size, rows_a.size)
+    assert np.array_equal(got_a, want_a)
+    assert np.array_equal(got_b[:, :rows_b.size], want_b[:, :rows_b.size])
+    assert np.array_equal(col[:, 0],
+        ctx.ll_theta(0, fresh, 0.01, 0.2)[cells_a, 0])
+    with pytest.raises(RuntimeError, match='no tile was issued'):
+        ctx.ll_rows_wait(0, cells_a.size, rows_a.size)
+    with pytest.raises(RuntimeError, match='slot'):
+        ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 2)
+    ctx.close()
