@@ -96,7 +96,7 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns):
     return assignment, {int(col_id[c]): int(col_size[c]) for c in live}, n_new
 
 
-@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('seed', range(24))
 def test_gibbs_sweep_fuzz(seed):
     rng = np.random.RandomState(seed)
     N = int(rng.choice([1, 2, 17, 60, 200]))
@@ -150,7 +150,7 @@ def reference_rg_scan(ll, DP_a, rg, sample, target=None):
     return rg, O.seqsum(prob)
 
 
-@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('seed', range(24))
 def test_rg_scan_fuzz(seed):
     lib = _lib.load()
     rng = np.random.RandomState(seed)
