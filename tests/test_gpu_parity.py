@@ -144,6 +144,39 @@ def test_ragged_shapes(N, M):
     ctx.close()
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_random_shapes_clusters_and_subsets(seed):
+    """Random N, M, K, missing rate and error rates; a random cell subset as a
+    view; every launch shape the dispatcher can pick (whole-row, mutation
+    split, each cluster tiling)."""
+    rng = np.random.RandomState(1000 + seed)
+    N = int(rng.choice([1, 3, 64, 65, 200, 513, 900]))
+    M = int(rng.choice([1, 7, 64, 129, 300, 1000]))
+    K = int(rng.choice([1, 2, 3, 5, 8, 9, 17, 40, 70]))
+    data = (rng.random_sample((N, M)) < rng.uniform(.05, .6)).astype(float)
+    data[rng.random_sample(data.shape) < rng.uniform(0, .6)] = np.nan
+    theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    theta[rng.random_sample(theta.shape) < .1] = np.float32(1e-5)
+    theta[rng.random_sample(theta.shape) < .1] = np.float32(1 - 1e-5)
+    FP, FN = float(rng.uniform(1e-6, .2)), float(rng.uniform(1e-3, .5))
+    ctx = _lib.Context(data=data)
+    L1, L0 = host_tables(theta, FP, FN)
+    want = table_sums(data, L1, L0)
+    assert np.array_equal(ctx.ll_tables(0, L1, L0), want)
+    np.testing.assert_allclose(ctx.ll_theta(0, theta, FP, FN), want,
+        rtol=1e-12, atol=1e-12)
+    cells = rng.randint(0, N, int(rng.randint(1, 2 * N + 2)))
+    ctx.view_set(1, cells)
+    assert np.array_equal(ctx.ll_tables(1, L1, L0), want[cells])
+    np.testing.assert_allclose(ctx.ll_theta(1, theta, FP, FN), want[cells],
+        rtol=1e-12, atol=1e-12)
+    c1, c0 = ctx.colcounts([cells])
+    assert np.array_equal(c1[0], (data[cells] == 1).sum(axis=0))
+    assert np.array_equal(c0[0], (data[cells] == 0).sum(axis=0))
+    ctx.close()
+
+
 def test_all_missing_all_ones_all_zeros_and_boundary_theta():
     M = 70
     data = np.zeros((6, M))
