@@ -423,7 +423,9 @@ class CRP:
             t_start = time.perf_counter()
         post_new = np.ascontiguousarray(self.get_lpost_single_new_cluster())
         perm = _lib.as_i64(np.random.permutation(N))
-        assignment = _lib.as_i64(self.assignment)
+        # a private copy: the sweep's result is committed at the end, an
+        # exception half-way leaves assignment and cells_per_cluster as they were
+        assignment = np.array(self.assignment, dtype=np.int64, order='C')
         crp_prior = np.ascontiguousarray(self.CRP_prior, dtype=np.float64)
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
@@ -465,17 +467,31 @@ class CRP:
 
             opened, tiles, born = 0, 0, ()
             tile = issue(0, 0)
-            while tile is not None:
-                ll = ctx.ll_rows_wait(tile['slot'], tile['end'] - tile['pos'],
-                    tile['ld'])
-                ahead = issue(tile['end'], tile['slot'] ^ 1) \
-                    if tile['end'] < N else None
-                ids, sizes, born = self._gibbs_window(perm, tile['pos'],
-                    tile['end'], tile['view'], ll, tile['cols'], ids, sizes,
-                    born, assignment, post_new, crp_prior)
-                opened += len(born)
-                tiles += 1
-                tile = ahead
+            in_flight = [tile]
+            try:
+                while tile is not None:
+                    ll = ctx.ll_rows_wait(tile['slot'],
+                        tile['end'] - tile['pos'], tile['ld'])
+                    in_flight.remove(tile)
+                    ahead = None
+                    if tile['end'] < N:
+                        ahead = issue(tile['end'], tile['slot'] ^ 1)
+                        in_flight.append(ahead)
+                    ids, sizes, born = self._gibbs_window(perm, tile['pos'],
+                        tile['end'], tile['view'], ll, tile['cols'], ids,
+                        sizes, born, assignment, post_new, crp_prior)
+                    opened += len(born)
+                    tiles += 1
+                    tile = ahead
+            finally:
+                # an exception must not leave an issued tile behind (the
+                # context refuses to re-use its slot)
+                for left in in_flight:
+                    try:
+                        ctx.ll_rows_wait(left['slot'],
+                            left['end'] - left['pos'], left['ld'])
+                    except RuntimeError:
+                        pass
         if timing:
             print(f'[bnpc] gibbs N={N} K={K_start}->{ids.size}: '
                 f'{time.perf_counter() - t_start:.3f}s in {tiles} tile(s), '

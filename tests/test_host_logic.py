@@ -491,3 +491,36 @@ def test_prior_density_cache_changes_nothing(monkeypatch):
     from bnpc_amd import fastdist
     assert np.array_equal(m._known_prior(ids, theta),
         fastdist.beta_logpdf(theta, m.p, m.q))
+
+
+def test_failed_tiled_sweep_leaves_no_tile_behind(monkeypatch):
+    """An exception in the middle of a tiled sweep: the tile issued ahead is
+    picked up before the error propagates, so the context is usable again."""
+    monkeypatch.setenv('BNPC_SWEEP_BYTES', '30000')
+    data = synth(1, 150, 70, 4, 0.15)
+    p = make(P, 'fixed', data)
+    np.random.seed(11)
+    p.init()
+    real = P.CRP._gibbs_window
+    calls = {'n': 0}
+
+    def flaky(self, *a, **k):
+        calls['n'] += 1
+        if calls['n'] == 2:
+            raise ValueError('boom')
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(P.CRP, '_gibbs_window', flaky)
+    np.random.seed(1)
+    with pytest.raises(ValueError, match='boom'):
+        p.update_assignments_Gibbs()
+    assert not p._ctx.tiles                      # nothing left in flight
+    monkeypatch.setattr(P.CRP, '_gibbs_window', real)
+    o = make(O, 'fixed', data)
+    np.random.seed(11)
+    o.init()
+    for m in (o, p):
+        # the failed sweep never committed its partial result
+        np.random.seed(2)
+        m.update_assignments_Gibbs()
+    assert np.array_equal(o.assignment, p.assignment)
