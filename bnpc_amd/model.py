@@ -423,8 +423,10 @@ class CRP:
             t_start = time.perf_counter()
         post_new = np.ascontiguousarray(self.get_lpost_single_new_cluster())
         perm = _lib.as_i64(np.random.permutation(N))
-        # a private copy: the sweep's result is committed at the end, an
-        # exception half-way leaves assignment and cells_per_cluster as they were
+        # a private copy: the sweep's result is committed at the end, so an
+        # exception half-way leaves assignment and cells_per_cluster consistent
+        # with each other (parameter rows of ids re-used by the aborted sweep
+        # are not restored - the run is over at that point anyway)
         assignment = np.array(self.assignment, dtype=np.int64, order='C')
         crp_prior = np.ascontiguousarray(self.CRP_prior, dtype=np.float64)
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)

