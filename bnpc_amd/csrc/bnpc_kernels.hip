@@ -561,23 +561,34 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     long long bx, g;
-    ll_tile_coords((unsigned)((nblk + 4 * CB - 1) / (4 * CB)) * (unsigned)MS,
-                   (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
-    const int ms = SPLIT ? (int)(bx % MS) : 0;  // mutation chunk of this wave
-    if (SPLIT) bx /= MS;
-    const long long blk0 = (bx * 4 + wave) * CB;
-    if (blk0 >= nblk) return;
+    // SPLIT = false: the 4 waves of a workgroup own 4 different sets of CB
+    // blocks.  SPLIT = true: they own 4 consecutive mutation chunks of the
+    // SAME CB blocks and add their sums in wave order through LDS, so only
+    // ceil(MS / 4) partial planes travel to k_ll_combine.
+    const int MSq = (MS + 3) >> 2;
+    ll_tile_coords(SPLIT
+            ? (unsigned)((nblk + CB - 1) / CB) * (unsigned)MSq
+            : (unsigned)((nblk + 4 * CB - 1) / (4 * CB)),
+        (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
+    const int q = SPLIT ? (int)(bx % MSq) : 0;  // chunk quad of this workgroup
+    if (SPLIT) bx /= MSq;
+    const int ms = SPLIT ? q * 4 + wave : 0;    // mutation chunk of this wave
+    const long long blk0 = SPLIT ? bx * CB : (bx * 4 + wave) * CB;
+    if (blk0 >= nblk) return;           // SPLIT: the whole workgroup leaves
     const int m_begin = SPLIT ? ms * m_chunk : 0;
-    const int m_len = SPLIT
-        ? ((m_begin + m_chunk < Mt) ? m_chunk : Mt - m_begin) : Mt;
+    const int m_len = !SPLIT ? Mt
+        : (ms >= MS ? 0
+            : ((m_begin + m_chunk < Mt) ? m_chunk : Mt - m_begin));
 
     // mask rows of the wave's CB blocks, as offsets from the one `masks` base
     // (a block past the end re-reads the wave's first block, never stored)
     size_t mo[CB];
 #pragma unroll
     for (int c = 0; c < CB; c++)
-        mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad + m_begin;
-    const double *__restrict__ tp = T + ((size_t)g * Mt + m_begin) * (2 * KW);
+        mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad
+            + (m_len > 0 ? m_begin : 0);
+    const double *__restrict__ tp = T
+        + ((size_t)g * Mt + (m_len > 0 ? m_begin : 0)) * (2 * KW);
 
     double acc[CB][KW];
 #pragma unroll
@@ -613,16 +624,38 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
         tp += 32;
     }
 
+    if constexpr (SPLIT) {
+        // sums of the 4 chunks of this workgroup, added in wave order
+        __shared__ double red[4][CB * KW][64];
 #pragma unroll
-    for (int c = 0; c < CB; c++) {
-        const long long slot = (blk0 + c) * 64 + lane;
-        if (blk0 + c < nblk && slot < n) {
-            double *o = (SPLIT && MS > 1)
-                ? out + ((size_t)ms * n + slot) * K + (size_t)g * KW
-                : out + (size_t)slot * ldo + (size_t)g * KW;
+        for (int c = 0; c < CB; c++)
 #pragma unroll
-            for (int j = 0; j < KW; j++)
-                if (g * KW + j < K) o[j] = acc[c][j];
+            for (int j = 0; j < KW; j++) red[wave][c * KW + j][lane] = acc[c][j];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (CB * KW) / 4; i++) {
+            const int ck = wave + 4 * i;
+            const int c = ck / KW, j = ck - c * KW;
+            const double s = ((red[0][ck][lane] + red[1][ck][lane])
+                + red[2][ck][lane]) + red[3][ck][lane];
+            const long long slot = (blk0 + c) * 64 + lane;
+            if (blk0 + c < nblk && slot < n && g * KW + j < K) {
+                double *o = (MSq > 1)
+                    ? out + ((size_t)q * n + slot) * K + (size_t)g * KW
+                    : out + (size_t)slot * ldo + (size_t)g * KW;
+                o[j] = s;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const long long slot = (blk0 + c) * 64 + lane;
+            if (blk0 + c < nblk && slot < n) {
+                double *o = out + (size_t)slot * ldo + (size_t)g * KW;
+#pragma unroll
+                for (int j = 0; j < KW; j++)
+                    if (g * KW + j < K) o[j] = acc[c][j];
+            }
         }
     }
 }
@@ -1003,6 +1036,12 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         dst = (double *)c->part.p;
     }
     const int64_t wg2 = ((v.nblk + 7) / 8) * G * MS;
+    // mutation-split form of the hand-placed kernel: a workgroup's 4 waves
+    // take 4 chunks of the same blocks -> ceil(MS / 4) partial planes
+    const int MSq = (MS + 3) / 4;
+    const int64_t split2 = ((v.nblk + 1) / 2) * G * MSq;
+    const int64_t split1 = v.nblk * G * MSq;
+    int planes = MS;
 #define LAUNCH_ASM(CB_, SPLIT_, GRID_)                                        \
     hipLaunchKernelGGL((k_ll8_asm<CB_, SPLIT_>), dim3((unsigned)(GRID_)),     \
                        dim3(256), 0, c->stream,                              \
@@ -1011,11 +1050,21 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        (const double *)c->tabs.p, (int)K, (long long)ldo,    \
                        dst, xcd, MS, m_chunk)
     if (KW == 8 && impl == 2 && wg2 >= env_flag("BNPC_ASM2_MIN_WGS", 448)) {
-        if (MS > 1) LAUNCH_ASM(2, true, wg2);
-        else LAUNCH_ASM(2, false, wg2);
+        if (MS > 1) {
+            if (MSq == 1) dst = d_out;  // the workgroup already holds the sum
+            LAUNCH_ASM(2, true, split2);
+            planes = MSq;
+        } else {
+            LAUNCH_ASM(2, false, wg2);
+        }
     } else if (KW == 8 && impl >= 1) {
-        if (MS > 1) LAUNCH_ASM(1, true, nwg);
-        else LAUNCH_ASM(1, false, nwg);
+        if (MS > 1) {
+            if (MSq == 1) dst = d_out;
+            LAUNCH_ASM(1, true, split1);
+            planes = MSq;
+        } else {
+            LAUNCH_ASM(1, false, nwg);
+        }
     }
 #undef LAUNCH_ASM
     else
@@ -1024,12 +1073,13 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
                            dst, xcd, MS, m_chunk);
-    if (MS > 1) {
+    if (MS > 1 && planes > 1) {
         HIPCHK(hipGetLastError());
         const long long total = (long long)v.n * K;
         hipLaunchKernelGGL(k_ll_combine, dim3((unsigned)((total + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->part.p,
-                           (long long)v.n, (int)K, MS, (long long)ldo, d_out);
+                           (long long)v.n, (int)K, planes, (long long)ldo,
+                           d_out);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1082,6 +1132,13 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     const size_t out_bytes = (size_t)v.n * ldo * sizeof(double);
     if (ensure(c->out, out_bytes)) return 1;
     int kw = pick_kw(K);
+    // A launch that will be split over the mutations runs the hand-placed
+    // 8-cluster kernel whatever K is: its workgroups reduce 4 chunks through
+    // LDS, which beats the narrower C++ tilings from K = 2 on (measured
+    // K = 2..12: 11-17 us against 11-25 us; profiles/r01/small_launch_study.md)
+    if (K >= 2 && from_theta && env_flag("BNPC_MSPLIT", 1)
+        && v.nblk * ((K + 7) / 8) < env_flag("BNPC_MSPLIT_WAVES", 4096))
+        kw = 8;
     const char *force = getenv("BNPC_KW");
     if (force) {
         int f = atoi(force);
