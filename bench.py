@@ -151,7 +151,7 @@ def load_pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or
     None.  The counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_v9_final.json')
+    path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_v11_final.json')
     try:
         with open(path) as f:
             pmc = json.load(f)
