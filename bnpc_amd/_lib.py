@@ -32,6 +32,21 @@ class GibbsState(C.Structure):
         ('pos_end', _i64), ('row_base', _i64)]
 
 
+class MHArgs(C.Structure):
+    """bnpc_mh_args (include/bnpc_hip.h)"""
+    _fields_ = [('G', _i64), ('M', _i64), ('old_theta', C.c_void_p),
+        ('n1', C.c_void_p), ('n0', C.c_void_p), ('sd', C.c_void_p),
+        ('n_sd', _i64), ('tmin', C.c_double), ('tmax', C.c_double),
+        ('FP', C.c_double), ('FN', C.c_double), ('p', C.c_double),
+        ('q', C.c_double), ('uniform_prior', C.c_int),
+        ('trans_prob', C.c_int), ('known_theta', C.c_void_p),
+        ('known_prior', C.c_void_p), ('sd_idx', C.c_void_p),
+        ('U', C.c_void_p), ('u', C.c_void_p), ('new_theta', C.c_void_p),
+        ('prior_out', C.c_void_p), ('A', C.c_void_p),
+        ('log_prob', C.c_void_p), ('declined', C.c_void_p),
+        ('threads', C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
     'bnpc_last_error': (C.c_char_p, []),
@@ -71,6 +86,11 @@ SIGNATURES = {
     'bnpc_mt_mh_draws': (C.c_int, [C.POINTER(MT19937), _i64, _i64, _i64,
         _pi32, _pd, _pd]),
     'bnpc_log_diff_pi': (C.c_int, [_pd, _pd, _i64, _pd]),
+    'bnpc_mh_batch': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
+        C.POINTER(MHArgs),
+        C.POINTER(C.c_int)]),
+    'bnpc_beta_logpdf_f32': (C.c_int, [C.c_void_p, _pf, _i64, C.c_double,
+        C.c_double, C.c_void_p, C.c_void_p, _pd, _pd, C.c_int]),
     'bnpc_dominated_cdf': (C.c_int, [_i64, _i64, _pd]),
     'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
@@ -221,6 +241,89 @@ def mh_draws(G, M, n_sd):
         check(load().bnpc_mt_mh_draws(rng, G, M, n_sd, ptr(sd_idx, C.c_int32),
             ptr(U, C.c_double), ptr(u, C.c_double)), 'mh_draws')
     return sd_idx, U, u
+
+
+def host_threads():
+    """Size of the native host thread team (BNPC_HOST_THREADS; default
+    min(16, cores); 1 = the calling thread only)."""
+    try:
+        n = int(os.environ.get('BNPC_HOST_THREADS', 0))
+    except ValueError:
+        n = 0
+    if n < 1:
+        n = min(16, os.cpu_count() or 1)
+    return n
+
+
+def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
+            trans_prob, known=None, want_prior=False, draws=None,
+            threads=None):
+    """bnpc_mh_batch: the draws and the arithmetic of MH_cluster_params for
+    the G rows of `old` (float32 G x M).  `draws` = (sd_idx, U, u) evaluates
+    given draws instead of taking them from the global stream.  Returns
+    (status, new, log_prob, declined, prior, (sd_idx, U, u)); status 1: only
+    the draws are valid."""
+    old = np.ascontiguousarray(old, dtype=np.float32)
+    G, M = old.shape
+    n1 = np.ascontiguousarray(n1, dtype=np.int32)
+    n0 = np.ascontiguousarray(n0, dtype=np.int32)
+    sd = np.ascontiguousarray(sd, dtype=np.float64)
+    assert n1.shape == n0.shape == (G, M)
+    if draws is None:
+        sd_idx = np.empty((G, M), dtype=np.int32)
+        U = np.empty((G, M))
+        u = np.empty((G, M))
+    else:
+        sd_idx = np.ascontiguousarray(draws[0], dtype=np.int32)
+        U = np.ascontiguousarray(draws[1], dtype=np.float64)
+        u = np.ascontiguousarray(draws[2], dtype=np.float64)
+    new = np.empty((G, M), dtype=np.float32)
+    A = np.empty((G, M))
+    prior = np.empty((G, M)) if want_prior and not uniform else None
+    log_prob = np.empty(G)
+    declined = np.empty(G, dtype=np.int64)
+    kt = kp = None
+    if known is not None and not uniform:
+        kt = np.ascontiguousarray(known[0], dtype=np.float32)
+        kp = np.ascontiguousarray(known[1], dtype=np.float64)
+        assert kt.shape == kp.shape == (G, M)
+    a = MHArgs(G, M, old.ctypes.data, n1.ctypes.data, n0.ctypes.data,
+        sd.ctypes.data, sd.size, tmin, tmax, FP, FN, p, q, int(bool(uniform)),
+        int(bool(trans_prob)), kt.ctypes.data if kt is not None else None,
+        kp.ctypes.data if kp is not None else None, sd_idx.ctypes.data,
+        U.ctypes.data, u.ctypes.data, new.ctypes.data,
+        prior.ctypes.data if prior is not None else None, A.ctypes.data,
+        log_prob.ctypes.data, declined.ctypes.data,
+        host_threads() if threads is None else threads)
+    status = C.c_int(0)
+    lib = load()
+    if draws is None:
+        with NumpyStream() as rng:
+            check(lib.bnpc_mh_batch(C.addressof(kernels), rng, C.byref(a),
+                C.byref(status)), 'mh_batch')
+    else:
+        check(lib.bnpc_mh_batch(C.addressof(kernels), None, C.byref(a),
+            C.byref(status)), 'mh_batch')
+    return status.value, new, log_prob, declined, prior, (sd_idx, U, u)
+
+
+def beta_logpdf_f32(kernels, x, p, q, known=None, threads=None):
+    """(density array shaped like x, its sum in index order)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape)
+    total = C.c_double(0.0)
+    kt = kp = None
+    if known is not None:
+        kt = np.ascontiguousarray(known[0], dtype=np.float32)
+        kp = np.ascontiguousarray(known[1], dtype=np.float64)
+        assert kt.shape == kp.shape == x.shape
+    check(load().bnpc_beta_logpdf_f32(C.addressof(kernels),
+        ptr(x, C.c_float), x.size, p, q,
+        kt.ctypes.data if kt is not None else None,
+        kp.ctypes.data if kp is not None else None, ptr(out, C.c_double),
+        C.byref(total), host_threads() if threads is None else threads),
+        'beta_logpdf_f32')
+    return out, total.value
 
 
 def log_diff_pi(log_p, log_q):

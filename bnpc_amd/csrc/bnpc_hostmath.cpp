@@ -1,0 +1,466 @@
+// bnpc_hostmath.cpp - the per-element host arithmetic of the parameter moves,
+// batched over clusters and spread over a team of host threads.
+//
+// What is evaluated is fixed by the reference: CRP.MH_cluster_params
+// (/root/reference/libs/CRP.py:314-344) draws a truncated-normal proposal per
+// mutation (SciPy: truncnorm.rvs = ppf of a uniform), and CRP._get_log_A
+// (:347-383) adds its forward / reverse log-density, the Beta prior and the
+// likelihood of the cluster's cells (here n1 * L1 + n0 * L0 from the device's
+// column counts).  How it is evaluated is this build's: one call for all
+// clusters of a step, no interpreter in the loop, threads over (cluster,
+// mutation-chunk) tasks, the random draws of cluster g+1 generated while the
+// team works on cluster g.
+//
+// Bits: every transcendental goes through the function SciPy / NumPy use
+// themselves (bnpc_host_kernels, include/bnpc_hip.h); everything else is
+// plain IEEE arithmetic in the dtypes and association order of the Python
+// expressions (compiled with -ffp-contract=off).  The formulas follow
+// scipy/stats/_continuous_distns.py (1.15): _log_gauss_mass, truncnorm_gen.
+// _ppf / _logpdf, _norm_logpdf, beta_gen._logpdf, and scipy.special.logsumexp
+// for two real terms.
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "bnpc_hip.h"
+#include "bnpc_internal.h"
+
+// ---------------------------------------------------------------------------
+// thread team: persistent workers, one job at a time; rebuilt after fork()
+// ---------------------------------------------------------------------------
+namespace {
+
+class Team {
+public:
+    explicit Team(int workers) : pid_(getpid())
+    {
+        for (int i = 0; i < workers; i++)
+            threads_.emplace_back([this, i] { loop(i + 1); });
+    }
+    int size() const { return (int)threads_.size() + 1; }
+    pid_t pid() const { return pid_; }
+
+    // fn(rank) on `n` ranks (the caller is rank 0); returns when all are done
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n > size()) n = size();
+        if (n <= 1) {
+            fn(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &fn;
+            want_ = n;
+            pending_ = n - 1;
+            generation_++;
+        }
+        start_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(int rank)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                start_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (rank >= want_) continue;
+                job = job_;
+            }
+            (*job)(rank);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                pending_--;
+            }
+            done_.notify_one();
+        }
+    }
+
+    pid_t pid_;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable start_, done_;
+    const std::function<void(int)> *job_ = nullptr;
+    uint64_t generation_ = 0;
+    int want_ = 0, pending_ = 0;
+};
+
+// The team of this PROCESS.  A forked child inherits the object but not the
+// threads: it abandons the parent's team (never destroyed - its std::threads
+// are not joinable there) and starts its own on first use.
+Team *g_team = nullptr;
+std::mutex g_team_mu;
+
+Team *team_for(int threads)
+{
+    std::lock_guard<std::mutex> lk(g_team_mu);
+    if (g_team && g_team->pid() != getpid()) g_team = nullptr;
+    if (!g_team || g_team->size() < threads) {
+        // a larger team replaces a smaller one; the old workers stay parked
+        g_team = new Team(threads - 1);
+    }
+    return g_team;
+}
+
+inline void uloop(bnpc_uloop f, void *data, const double *in, double *out,
+                  intptr_t n)
+{
+    if (n <= 0) return;
+    char *args[2] = {(char *)in, (char *)out};
+    intptr_t dims[1] = {n};
+    intptr_t steps[2] = {(intptr_t)sizeof(double), (intptr_t)sizeof(double)};
+    f(args, dims, steps, data);
+}
+
+constexpr int BLK = 128;       // elements per task
+
+struct Consts {
+    double log_sd[8];          // np.log(sd[i])
+    double log_m1, log_m2;     // np.log(1.0), np.log(2.0)
+    double betaln_pq;
+    float tmin32, tmax32;
+};
+
+// scipy _log_gauss_mass(a, b) of one interval; false: leave it to SciPy
+inline bool gauss_mass(const bnpc_host_kernels *k, double a, double b,
+                       double *out)
+{
+    if (a <= 0.0 && b > 0.0) {          // case_central
+        *out = k->sc_log1p(-k->ndtr(a, 0) - k->ndtr(-b, 0), 0);
+        return true;
+    }
+    if (b <= 0.0 && k->left_ok) {       // case_left: _log_diff of the cdfs
+        *out = bnpc_log_diff_pi1(k->log_ndtr(b, 0), k->log_ndtr(a, 0));
+        return true;
+    }
+    return false;                       // case_right / NaN
+}
+
+// beta._logpdf + rv_continuous.logpdf's support mask, x float32 -> float64
+inline double beta_logpdf1(const bnpc_host_kernels *k, float x32, double p,
+                           double q, double betaln_pq)
+{
+    const double x = (double)x32;
+    if (!((0.0 < x) && (x < 1.0))) return -INFINITY;
+    double l = k->xlog1py(q - 1.0, -x, 0) + k->xlogy(p - 1.0, x, 0);
+    l -= betaln_pq;
+    return l;
+}
+
+// elements [m0, m1) of cluster g; false: an element needs SciPy's own path
+bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
+              const Consts &c, int64_t g, int64_t m0, int64_t m1)
+{
+    const int n = (int)(m1 - m0);
+    const size_t off = (size_t)g * a->M + m0;
+    const float *old = a->old_theta + off;
+    const int32_t *n1 = a->n1 + off, *n0 = a->n0 + off;
+    const int32_t *si = a->sd_idx + off;
+    const double *U = a->U + off, *lu = a->u + off;
+
+    double std_[BLK], lsd[BLK], lo[BLK], hi[BLK], lgm[BLK];
+    double t0[BLK], t1[BLK], t2[BLK], t3[BLK];
+    float nw[BLK];
+
+    // a = (TMIN - old) / std, b = (TMAX - old) / std: the difference is
+    // float32 arithmetic (a Python float against a float32 array)
+    for (int i = 0; i < n; i++) {
+        std_[i] = a->sd[si[i]];
+        lsd[i] = c.log_sd[si[i]];
+        lo[i] = (double)(c.tmin32 - old[i]) / std_[i];
+        hi[i] = (double)(c.tmax32 - old[i]) / std_[i];
+        if (!gauss_mass(k, lo[i], hi[i], &lgm[i])) return false;
+        if (!(lu[i] > 0.0) || !(U[i] > 0.0)) return false;  // log(0) raises
+    }
+
+    // truncnorm._ppf: left form where a < 0, mirrored form elsewhere
+    //   log_Phi = logsumexp([logcdf(a), log(q) + mass])       (a < 0)
+    //   log_Phi = logsumexp([logcdf(-b), log1p(-q) + mass])   (a >= 0)
+    uloop(k->np_log, k->np_log_data, U, t0, n);             // log(q)
+    int nr = 0;
+    int ridx[BLK];
+    for (int i = 0; i < n; i++)
+        if (!(lo[i] < 0.0)) {
+            ridx[nr] = i;
+            t1[nr++] = -U[i];
+        }
+    uloop(k->np_log1p, k->np_log1p_data, t1, t2, nr);       // log1p(-q)
+    for (int j = 0; j < nr; j++) t0[ridx[j]] = t2[j];
+    // p -> t1, q -> t0; top -> t2, min - top -> t3
+    bool tie[BLK];
+    for (int i = 0; i < n; i++) {
+        const bool left = lo[i] < 0.0;
+        const double pp = k->log_ndtr(left ? lo[i] : -hi[i], 0);
+        const double qq = t0[i] + lgm[i];
+        if (!isfinite(pp) || !isfinite(qq)) return false;
+        const double top = pp > qq ? pp : qq;
+        const double bot = pp > qq ? qq : pp;
+        tie[i] = pp == qq;
+        t2[i] = top;
+        t3[i] = bot - top;
+    }
+    uloop(k->np_exp, k->np_exp_data, t3, t1, n);
+    for (int i = 0; i < n; i++)
+        if (tie[i]) t1[i] = 0.0;
+    uloop(k->np_log1p, k->np_log1p_data, t1, t3, n);
+    for (int i = 0; i < n; i++) {
+        const double log_phi = t3[i] + (tie[i] ? c.log_m2 : c.log_m1) + t2[i];
+        double x = k->ndtri_exp(log_phi, 0);
+        if (!(lo[i] < 0.0)) x = -x;
+        x = x * std_[i] + (double)old[i];
+        nw[i] = (float)x;                                   // astype(float32)
+    }
+
+    // forward and reverse proposal log-densities (truncnorm._logpdf around
+    // old / around new), reverse bounds from the float32 proposal
+    double fwd[BLK], rev[BLK];
+    for (int i = 0; i < n; i++) {
+        const double xs = (double)(nw[i] - old[i]) / std_[i];
+        double v = -(xs * xs) / 2.0 - k->norm_pdf_logC;
+        v = v - lgm[i] - lsd[i];
+        fwd[i] = ((lo[i] <= xs) && (xs <= hi[i])) ? v : -INFINITY;
+
+        const double ar = (double)(c.tmin32 - nw[i]) / std_[i];
+        const double br = (double)(c.tmax32 - nw[i]) / std_[i];
+        double mass_r;
+        if (!gauss_mass(k, ar, br, &mass_r)) return false;
+        const double xr = (double)(old[i] - nw[i]) / std_[i];
+        double w = -(xr * xr) / 2.0 - k->norm_pdf_logC;
+        w = w - mass_r - lsd[i];
+        rev[i] = ((ar <= xr) && (xr <= br)) ? w : -INFINITY;
+    }
+
+    // likelihood of the cluster's cells under new / old: n1 * L1 + n0 * L0,
+    // L1 = log(t * (1 - FN) + (1 - t) * FP), L0 = log(t * FN + (1 - t) *
+    // (1 - FP)); (1 - t) in float32 (libs/CRP.py:198-200, 207-212)
+    const double pFN1 = 1.0 - a->FN, pFP0 = 1.0 - a->FP;
+    double ll_new[BLK], ll_old[BLK];
+    for (int pass = 0; pass < 2; pass++) {
+        const float *th = pass == 0 ? nw : old;
+        for (int i = 0; i < n; i++) {
+            const double t64 = (double)th[i];
+            const double om64 = (double)(1.0f - th[i]);
+            t0[i] = t64 * pFN1 + om64 * a->FP;
+            t1[i] = t64 * a->FN + om64 * pFP0;
+        }
+        uloop(k->np_log, k->np_log_data, t0, t2, n);
+        uloop(k->np_log, k->np_log_data, t1, t3, n);
+        double *dst = pass == 0 ? ll_new : ll_old;
+        for (int i = 0; i < n; i++)
+            dst[i] = (double)n1[i] * t2[i] + (double)n0[i] * t3[i];
+    }
+
+    // A = new_ll + new_prior - old_ll - old_prior + rev - fwd
+    double pr_new[BLK], pr_old[BLK];
+    double *A = a->A + off;
+    for (int i = 0; i < n; i++) {
+        if (a->uniform_prior) {
+            pr_new[i] = pr_old[i] = 0.0;
+        } else {
+            pr_new[i] = beta_logpdf1(k, nw[i], a->p, a->q, c.betaln_pq);
+            if (a->known_theta
+                && !memcmp(a->known_theta + off + i, old + i, sizeof(float)))
+                pr_old[i] = a->known_prior[off + i];
+            else
+                pr_old[i] = beta_logpdf1(k, old[i], a->p, a->q, c.betaln_pq);
+        }
+        double v = ll_new[i] + pr_new[i];
+        v = v - ll_old[i];
+        v = v - pr_old[i];
+        v = v + rev[i];
+        v = v - fwd[i];
+        if (a->trans_prob && v > 0.0) v = 0.0;              // np.clip(max=0)
+        A[i] = v;
+    }
+
+    // decline = log(u) >= A
+    uloop(k->np_log, k->np_log_data, lu, t0, n);
+    int nd = 0;
+    int didx[BLK];
+    float *out = a->new_theta + off;
+    double *prior_out = a->prior_out ? a->prior_out + off : nullptr;
+    for (int i = 0; i < n; i++) {
+        const bool decline = t0[i] >= A[i];
+        out[i] = decline ? old[i] : nw[i];
+        if (prior_out) prior_out[i] = decline ? pr_old[i] : pr_new[i];
+        if (decline) {
+            didx[nd] = i;
+            t1[nd++] = A[i];
+        }
+    }
+    if (a->trans_prob && nd) {
+        // A[declined] = log(-1 * expm1(A[declined]))
+        uloop(k->np_expm1, k->np_expm1_data, t1, t2, nd);
+        for (int j = 0; j < nd; j++) {
+            t2[j] = -1.0 * t2[j];
+            if (!(t2[j] > 0.0)) return false;               // log(<= 0) raises
+        }
+        uloop(k->np_log, k->np_log_data, t2, t3, nd);
+        for (int j = 0; j < nd; j++) A[didx[j]] = t3[j];
+    }
+    __atomic_fetch_add(&a->declined[g], (int64_t)nd, __ATOMIC_RELAXED);
+    return true;
+}
+
+}  // namespace
+
+static int check_kernels(const bnpc_host_kernels *k)
+{
+    if (!k || !k->ndtr || !k->log_ndtr || !k->ndtri_exp || !k->sc_log1p
+        || !k->xlogy || !k->xlog1py || !k->betaln || !k->np_log || !k->np_exp
+        || !k->np_log1p || !k->np_expm1) {
+        bnpc_set_error("bad argument: host kernel table incomplete");
+        return 2;
+    }
+    return 0;
+}
+
+extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
+                             const bnpc_mh_args *a, int *status)
+{
+    if (check_kernels(k)) return 2;
+    if (!a || !status || a->G < 0 || a->M < 1 || !a->old_theta || !a->n1
+        || !a->n0 || !a->sd || a->n_sd < 1 || a->n_sd > 8 || !a->sd_idx
+        || !a->U || !a->u || !a->new_theta || !a->A || !a->log_prob
+        || !a->declined || (a->known_theta && !a->known_prior)) {
+        bnpc_set_error("bad argument: mh_batch");
+        return 2;
+    }
+    *status = 0;
+    const int64_t G = a->G, M = a->M;
+    if (G == 0) return 0;
+
+    Consts c;
+    {
+        double one_two[2] = {1.0, 2.0}, lg[2];
+        uloop(k->np_log, k->np_log_data, one_two, lg, 2);
+        c.log_m1 = lg[0];
+        c.log_m2 = lg[1];
+        double sd[8], lsd[8];
+        for (int i = 0; i < a->n_sd; i++) sd[i] = a->sd[i];
+        uloop(k->np_log, k->np_log_data, sd, lsd, a->n_sd);
+        for (int i = 0; i < a->n_sd; i++) c.log_sd[i] = lsd[i];
+        c.betaln_pq = a->uniform_prior ? 0.0 : k->betaln(a->p, a->q, 0);
+        c.tmin32 = (float)a->tmin;
+        c.tmax32 = (float)a->tmax;
+    }
+
+    for (int64_t g = 0; g < G; g++) a->declined[g] = 0;
+    const int64_t chunks = (M + BLK - 1) / BLK;
+    const int64_t tasks = G * chunks;
+    int threads = a->threads;
+    if (threads > tasks) threads = (int)tasks;
+    if (threads < 1) threads = 1;
+
+    std::atomic<int64_t> next(0), rows_ready(rng ? 0 : G);
+    std::atomic<int> bail(0);
+
+    auto work = [&](int rank) {
+        if (rank == 0 && rng) {
+            // the draws, cluster by cluster in the reference's order; the
+            // team starts on a cluster as soon as its draws are published
+            for (int64_t g = 0; g < G; g++) {
+                int32_t *si = a->sd_idx + g * M;
+                double *Ug = a->U + g * M, *ug = a->u + g * M;
+                for (int64_t m = 0; m < M; m++)
+                    si[m] = (int32_t)mt_interval(rng, (uint64_t)(a->n_sd - 1));
+                for (int64_t m = 0; m < M; m++)
+                    Ug[m] = 0.0 + 1.0 * mt_double(rng);
+                for (int64_t m = 0; m < M; m++) ug[m] = mt_double(rng);
+                rows_ready.store(g + 1, std::memory_order_release);
+            }
+        }
+        for (;;) {
+            const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
+            if (t >= tasks) break;
+            const int64_t g = t / chunks, ch = t - g * chunks;
+            while (rows_ready.load(std::memory_order_acquire) <= g)
+                std::this_thread::yield();
+            if (bail.load(std::memory_order_relaxed)) continue;
+            const int64_t m0 = ch * BLK;
+            const int64_t m1 = m0 + BLK < M ? m0 + BLK : M;
+            if (!mh_block(k, a, c, g, m0, m1))
+                bail.store(1, std::memory_order_relaxed);
+        }
+    };
+    if (threads > 1)
+        team_for(threads)->run(threads, work);
+    else
+        work(0);
+
+    if (bail.load()) {
+        *status = 1;
+        return 0;
+    }
+    for (int64_t g = 0; g < G; g++) {
+        const double *A = a->A + g * M;
+        double s = 0.0;
+        if (a->trans_prob) {
+            s = A[0];
+            for (int64_t m = 1; m < M; m++) s += A[m];      // np.cumsum order
+        }
+        a->log_prob[g] = a->trans_prob ? s : NAN;
+    }
+    return 0;
+}
+
+extern "C" int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x,
+                                    int64_t n, double p, double q,
+                                    const float *known_theta,
+                                    const double *known_prior, double *out,
+                                    double *seq_sum, int threads)
+{
+    if (check_kernels(k)) return 2;
+    if (n < 0 || (n > 0 && (!x || !out)) || (known_theta && !known_prior)) {
+        bnpc_set_error("bad argument: beta_logpdf_f32");
+        return 2;
+    }
+    const double bl = k->betaln(p, q, 0);
+    const int64_t chunks = (n + 4 * BLK - 1) / (4 * BLK);
+    if (threads > chunks) threads = (int)chunks;
+    std::atomic<int64_t> next(0);
+    auto work = [&](int) {
+        for (;;) {
+            const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
+            if (t >= chunks) break;
+            const int64_t i1 = (t + 1) * 4 * BLK < n ? (t + 1) * 4 * BLK : n;
+            for (int64_t i = t * 4 * BLK; i < i1; i++) {
+                if (known_theta
+                    && !memcmp(known_theta + i, x + i, sizeof(float)))
+                    out[i] = known_prior[i];
+                else
+                    out[i] = beta_logpdf1(k, x[i], p, q, bl);
+            }
+        }
+    };
+    if (threads > 1)
+        team_for(threads)->run(threads, work);
+    else
+        work(0);
+    if (seq_sum) {
+        double s = 0.0;
+        if (n > 0) {
+            s = out[0];
+            for (int64_t i = 1; i < n; i++) s += out[i];
+        }
+        *seq_sum = s;
+    }
+    return 0;
+}

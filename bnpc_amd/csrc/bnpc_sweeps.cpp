@@ -24,70 +24,6 @@
 #include "bnpc_hip.h"
 #include "bnpc_internal.h"
 
-// ---------------------------------------------------------------------------
-// MT19937 (Matsumoto & Nishimura), state layout of np.random.get_state()
-// ---------------------------------------------------------------------------
-static inline void mt_refill(bnpc_mt19937 *s)
-{
-    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
-    uint32_t *k = s->key;
-    int i;
-    uint32_t y;
-    for (i = 0; i < 624 - 397; i++) {
-        y = (k[i] & UPPER) | (k[i + 1] & LOWER);
-        k[i] = k[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
-    }
-    for (; i < 623; i++) {
-        y = (k[i] & UPPER) | (k[i + 1] & LOWER);
-        k[i] = k[i + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
-    }
-    y = (k[623] & UPPER) | (k[0] & LOWER);
-    k[623] = k[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
-    s->pos = 0;
-}
-
-static inline uint32_t mt_next32(bnpc_mt19937 *s)
-{
-    if (s->pos >= 624) mt_refill(s);
-    uint32_t y = s->key[s->pos++];
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-
-static inline double mt_double(bnpc_mt19937 *s)
-{
-    const int32_t a = (int32_t)(mt_next32(s) >> 5);
-    const int32_t b = (int32_t)(mt_next32(s) >> 6);
-    return (a * 67108864.0 + b) / 9007199254740992.0;
-}
-
-// legacy random_interval: uniform integer in [0, max], masked rejection
-static inline uint64_t mt_interval(bnpc_mt19937 *s, uint64_t max)
-{
-    if (max == 0) return 0;
-    uint64_t mask = max;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
-    mask |= mask >> 32;
-    uint64_t v;
-    if (max <= 0xffffffffull) {
-        while ((v = (mt_next32(s) & mask)) > max) {}
-    } else {
-        for (;;) {
-            const uint64_t hi = mt_next32(s), lo = mt_next32(s);
-            v = ((hi << 32) | lo) & mask;
-            if (v <= max) break;
-        }
-    }
-    return v;
-}
-
 extern "C" double bnpc_mt_random_sample(bnpc_mt19937 *rng)
 {
     return mt_double(rng);
@@ -145,14 +81,7 @@ extern "C" int bnpc_log_diff_pi(const double *log_p, const double *log_q,
         bnpc_set_error("bad argument: NULL");
         return 2;
     }
-    double sin_pi, cos_pi;
-    sincos(3.141592653589793, &sin_pi, &cos_pi);
-    for (int64_t i = 0; i < n; i++) {
-        const double E = exp(log_q[i] - log_p[i]);
-        const double re = E * cos_pi + 1.0;
-        const double im = E * sin_pi;
-        out[i] = (log(hypot(re, im)) + 0.0) + log_p[i];
-    }
+    for (int64_t i = 0; i < n; i++) out[i] = bnpc_log_diff_pi1(log_p[i], log_q[i]);
     return 0;
 }
 

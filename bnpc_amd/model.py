@@ -35,7 +35,7 @@ from scipy.special import gamma as _gamma_fn, gammaln
 from scipy.stats import beta as _beta_dist, truncnorm
 from scipy.stats import gamma as _gamma_dist
 
-from bnpc_amd import _lib, fastdist
+from bnpc_amd import _lib, fastdist, hostkernels
 
 # the reference traps these and uses FloatingPointError as control flow
 # (libs/CRP.py:10)
@@ -97,6 +97,84 @@ VIEW_ALL = 0      # identity view: all cells
 VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
 VIEW_ONE = 2      # a single cell (get_lpost_single)
 VIEW_SWEEP = 3    # a permutation-ordered tile of a tiled Gibbs sweep
+
+
+# -- native batch of the parameter moves (csrc/bnpc_hostmath.cpp) -------------
+_NATIVE = {}
+
+
+def _native_kernels():
+    """The host kernel table if the native batch may be used in this process:
+    BNPC_NATIVE_MH != 0, the table could be assembled, and a batch covering
+    every branch (central / upper-clip / lower-clip intervals, both priors,
+    plain and transition-probability mode, the prior cache, 1 and several
+    threads) came out bit-identical to the SciPy-level evaluation
+    (CRP._mh_math).  Otherwise None: the SciPy-level path is used."""
+    pid = os.getpid()
+    if _NATIVE.get('pid') != pid:
+        _NATIVE.clear()
+        _NATIVE['pid'] = pid
+        _NATIVE['table'] = None
+        if os.environ.get('BNPC_NATIVE_MH', '1') != '0':
+            table = hostkernels.table()
+            if table is not None and _native_batch_is_exact(table):
+                _NATIVE['table'] = table
+    return _NATIVE['table']
+
+
+def _native_batch_is_exact(table):
+    try:
+        rng = np.random.RandomState(20240)
+        G, M = 5, 389
+        probe = CRP.__new__(CRP)
+        probe.param_proposal_sd = np.array([0.1, 0.25, 0.5])
+        ok = True
+        for (p, q), (FP, FN) in (((.25, .25), (0.01, 0.2)),
+                ((1, 1), (0.001, 0.1)), ((.75, 2.0), (1e-15, 1e-15))):
+            probe.p, probe.q, probe.FP, probe.FN = p, q, FP, FN
+            probe.beta_prior_uniform = bool(p == q == 1)
+            old = np.clip(rng.uniform(size=(G, M)), TMIN, TMAX) \
+                .astype(np.float32)
+            old[:, :40] = np.float32(TMIN)      # a == 0: mirrored ppf form
+            old[:, 40:80] = np.float32(TMAX)    # b == 0: mass left of zero
+            old[:, 80:90] = np.float32(0.5)
+            n1 = rng.randint(0, 900, size=(G, M)).astype(np.int32)
+            n0 = rng.randint(0, 900, size=(G, M)).astype(np.int32)
+            n1[0] = n0[0] = 0                   # an empty subset
+            sd_idx = rng.randint(0, 3, size=(G, M)).astype(np.int32)
+            U = rng.uniform(size=(G, M))
+            u = rng.uniform(size=(G, M))
+            U[1, :6] = [1e-300, 1e-17, 1 - 1e-16, .5, 1e-8, 1 - 1e-9]
+            std = probe.param_proposal_sd[sd_idx]
+            for trans in (False, True):
+                want = probe._mh_math(old, std, U, u, n1, n0, trans, None)
+                known = None
+                if want[3] is not None:
+                    # a cache that is right for half of the entries
+                    known = (old.copy(), fastdist.beta_logpdf(old, p, q))
+                    known[0][:, ::2] = np.float32(0.123)
+                for threads in (1, 3):
+                    got = _lib.mh_batch(table, old, n1, n0,
+                        probe.param_proposal_sd, TMIN, TMAX, FP, FN, p, q,
+                        probe.beta_prior_uniform, trans, known=known,
+                        want_prior=True, draws=(sd_idx, U, u),
+                        threads=threads)
+                    ok &= got[0] == 0 and np.array_equal(got[1], want[0]) \
+                        and np.array_equal(got[3], want[2].sum(axis=1))
+                    if trans:
+                        ok &= np.array_equal(got[2],
+                            np.cumsum(want[1], axis=1)[:, -1])
+                    if want[3] is not None:
+                        ok &= np.array_equal(got[4], want[3])
+            if not probe.beta_prior_uniform:
+                dens, total = _lib.beta_logpdf_f32(table, old, p, q,
+                    threads=2)
+                ref = fastdist.beta_logpdf(old, p, q)
+                ok &= np.array_equal(dens, ref) \
+                    and total == np.cumsum(ref.ravel())[-1]
+        return bool(ok)
+    except Exception:
+        return False
 
 
 class CRP:
@@ -393,13 +471,8 @@ class CRP:
         lprior = fastdist.gamma_logpdf(self.DP_a, shape, loc) \
             + np.cumsum(self.CRP_prior[sizes])[-1]
         if not self.beta_prior_uniform:
-            ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
-            theta = self.parameters[ids]
-            density = self._known_prior(ids, theta)     # rows kept by the MH
-            if density is None:
-                density = _rowwise(
-                    lambda t: fastdist.beta_logpdf(t, self.p, self.q), theta)
-            lprior += np.cumsum(density.ravel())[-1]
+            ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
+            lprior += self._prior_density_sum(ids, self.parameters[ids])
         return lprior
 
     # ---------------------------------------------------------------- Gibbs
@@ -619,65 +692,105 @@ class CRP:
     def update_parameters(self, step_no=None):
         """libs/CRP.py:302-311; the per-cluster sums over cells come from one
         column-count launch that is reused by get_ll_full / the error update,
-        and the K proposals are evaluated as one (K, M) array expression (the
-        draws stay in the reference's per-cluster order)."""
+        and the K proposals are evaluated as one batch (the draws stay in the
+        reference's per-cluster order)."""
         lab = self._label_counts()
         ids = lab['ids']
         old = self.parameters[ids]
         new, _, declined = self._mh_batch(old, (lab['n1'], lab['n0']), False,
-            old_prior=self._known_prior(ids, old), keep_prior=ids)
+            known=self._known_prior(ids), keep_prior=ids)
         self.parameters[ids] = new
         return declined.sum(), (self.muts_total - declined).sum()
 
-    # The Beta prior log-density of a profile that has not changed since the
-    # last update is the value computed then (an elementwise function of
-    # theta): every entry of the result is either the proposal's density
-    # (accepted) or the old one (declined).  Rows are verified against a copy
-    # of theta before they are trusted, so writes to `parameters` from anywhere
-    # (new clusters, split/merge, callers) simply miss.
+    # The Beta prior log-density of a profile entry that has not changed
+    # since the last update is the value computed then (an elementwise
+    # function of theta): every entry of the result is either the proposal's
+    # density (accepted) or the old one (declined).  The cache keeps a copy
+    # of theta beside the densities and an entry is only used where the bits
+    # of theta match, so writes to `parameters` from anywhere (new clusters,
+    # split/merge, callers) simply miss.
     _PRIOR_CACHE_ELEMS = 1 << 22
 
-    def _known_prior(self, ids, theta):
-        """(G, M) Beta log-density of `theta` = parameters[ids], rows taken
-        from the last update where theta is unchanged, or None (uniform
-        prior / nothing cached / too large to keep)."""
+    def _known_prior(self, ids):
+        """(theta copy, density) rows aligned with `ids`, or None (uniform
+        prior / nothing cached).  Rows of ids that are not in the cache hold
+        NaN parameters, which match nothing."""
         cache = getattr(self, '_prior_rows', None)
-        if self.beta_prior_uniform or not cache \
-                or theta.size > self._PRIOR_CACHE_ELEMS:
+        if self.beta_prior_uniform or not cache:
             return None
-        out = np.empty(theta.shape)
-        missing = []
-        for g, cl in enumerate(ids):
-            hit = cache.get(int(cl))
-            if hit is not None and np.array_equal(hit[0], theta[g]):
-                out[g] = hit[1]
-            else:
-                missing.append(g)
-        if missing:
-            out[missing] = fastdist.beta_logpdf(theta[missing], self.p, self.q)
-        return out
+        c_ids, c_theta, c_prior = cache
+        if c_ids.size == ids.size and np.array_equal(c_ids, ids):
+            return c_theta, c_prior
+        pos = {int(cl): g for g, cl in enumerate(c_ids)}
+        take = np.array([pos.get(int(cl), -1) for cl in ids], dtype=np.int64)
+        theta = c_theta[take]
+        theta[take < 0] = np.nan
+        return theta, c_prior[take]
 
     def _remember_prior(self, ids, theta, prior):
         if theta.size > self._PRIOR_CACHE_ELEMS:
             self._prior_rows = None
             return
-        self._prior_rows = {int(cl): (theta[g].copy(), prior[g])
-            for g, cl in enumerate(ids)}
+        self._prior_rows = (np.array(ids, dtype=np.int64), theta.copy(), prior)
 
-    def _mh_batch(self, old, counts, trans_prob, old_prior=None,
-                keep_prior=None):
+    def _prior_density_sum(self, ids, theta):
+        """Sum in index order of the Beta log-density of theta =
+        parameters[ids] (np.cumsum(...)[-1] of libs/CRP.py:249)."""
+        known = self._known_prior(ids)
+        table = _native_kernels()
+        if table is not None:
+            return _lib.beta_logpdf_f32(table, theta, self.p, self.q,
+                known=known)[1]
+        if known is not None:
+            density = np.where(known[0].view(np.int32) == theta.view(np.int32),
+                known[1], np.nan)
+            miss = np.isnan(density)
+            if miss.any():
+                density[miss] = fastdist.beta_logpdf(theta[miss], self.p,
+                    self.q)
+        else:
+            density = _rowwise(
+                lambda t: fastdist.beta_logpdf(t, self.p, self.q), theta)
+        return np.cumsum(density.ravel())[-1]
+
+    def _mh_batch(self, old, counts, trans_prob, known=None, keep_prior=None):
         """MH_cluster_params (libs/CRP.py:314-344) for G clusters at once.
 
         old: (G, M) float32; counts: (n1, n0) each (G, M).  RNG order per
         cluster, as in the reference: choice(sd, M) -> truncnorm.rvs (its M
         uniforms) -> random(M); the arithmetic in between does not draw, so
-        it is hoisted out of the loop and batched.  `old_prior`: the Beta
-        log-density of `old` if the caller has it; `keep_prior`: cluster ids
-        under which the log-density of the result is remembered."""
+        it is hoisted out of the loop and batched - natively on the host
+        thread team (bnpc_mh_batch) when the self-check allows, else as NumPy
+        / SciPy array expressions.  `known`: (theta, density) rows of the
+        prior cache; `keep_prior`: cluster ids under which the log-density of
+        the result is remembered."""
         G, M = old.shape
-        sd_idx, U, lu = _lib.mh_draws(G, M, self.param_proposal_sd.size)
-        std = self.param_proposal_sd[sd_idx]
         n1, n0 = counts
+        draws = None
+        table = _native_kernels()
+        if table is not None:
+            status, new, prob, declined, prior, draws = _lib.mh_batch(
+                table, old, n1, n0, self.param_proposal_sd, TMIN, TMAX,
+                self.FP, self.FN, self.p, self.q, self.beta_prior_uniform,
+                trans_prob, known=known, want_prior=keep_prior is not None)
+            if status == 0:
+                if keep_prior is not None and prior is not None:
+                    self._remember_prior(keep_prior, new, prior)
+                return new, prob, declined
+            # an element needs a branch the native batch leaves to SciPy:
+            # evaluate the whole batch here from the draws already taken
+        sd_idx, U, lu = draws if draws is not None \
+            else _lib.mh_draws(G, M, self.param_proposal_sd.size)
+        std = self.param_proposal_sd[sd_idx]
+        old_prior = None
+        if known is not None:
+            old_prior = np.where(
+                known[0].view(np.int32) == old.view(np.int32), known[1],
+                np.nan)
+            miss = np.isnan(old_prior)
+            if miss.any():
+                old_prior[miss] = fastdist.beta_logpdf(old[miss], self.p,
+                    self.q)
         pool, n_parts = None, _host_parts(G * M, G)
         if n_parts > 1:
             pool = _host_pool()

@@ -206,6 +206,86 @@ int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
 int bnpc_log_diff_pi(const double *log_p, const double *log_q, int64_t n,
                      double *out);
 
+/* ---- batched Metropolis-Hastings update of cluster parameters -------------
+ * CRP.MH_cluster_params (libs/CRP.py:314-344) with _get_log_A (:347-383) for
+ * G clusters in ONE call: the draws of every cluster in the reference's order
+ * on the caller's stream (choice(sd, M) -> the M uniforms of truncnorm.rvs ->
+ * random(M)), then the per-element arithmetic - truncated-normal proposal
+ * (ppf of the uniform), forward / reverse proposal log-density, the Beta prior
+ * log-density, the four element-table logs, the acceptance test - on a team of
+ * host threads, without the interpreter.
+ *
+ * The trajectory contract (identical assignments under a fixed seed) needs
+ * the proposal's float64 bits to equal SciPy's: a 1-ulp difference flips the
+ * float32 cast of a parameter with probability ~2e-9 per element.  So the
+ * transcendental kernels are NOT restated here: the caller hands over the
+ * addresses of the very functions SciPy and NumPy evaluate (scipy.special's
+ * C entry points as exported by scipy.special.cython_special.__pyx_capi__,
+ * NumPy's float64 inner loops of log / exp / log1p / expm1 as registered in
+ * the ufunc objects), and this library calls them in the order, association
+ * and dtypes of scipy.stats.truncnorm._ppf / _logpdf / _log_gauss_mass and
+ * beta._logpdf (scipy/stats/_continuous_distns.py) and of the reference's
+ * expressions.  The binding bit-compares the whole batch against the
+ * SciPy-level evaluation once per process and does not use it if anything
+ * differs. */
+typedef double (*bnpc_sf1)(double, int);            /* cython_special f(x)   */
+typedef double (*bnpc_sf2)(double, double, int);    /* cython_special f(x,y) */
+typedef void (*bnpc_uloop)(char **args, const intptr_t *dimensions,
+                           const intptr_t *steps, void *data);
+
+typedef struct bnpc_host_kernels {
+    bnpc_sf1 ndtr, log_ndtr, ndtri_exp, sc_log1p;   /* scipy.special */
+    bnpc_sf2 xlogy, xlog1py, betaln;
+    bnpc_uloop np_log, np_exp, np_log1p, np_expm1;  /* NumPy d->d loops */
+    void *np_log_data, *np_exp_data, *np_log1p_data, *np_expm1_data;
+    double norm_pdf_logC;   /* scipy.stats._continuous_distns._norm_pdf_logC */
+    int left_ok;            /* bnpc_log_diff_pi verified against SciPy */
+} bnpc_host_kernels;
+
+typedef struct bnpc_mh_args {
+    int64_t G, M;
+    const float *old_theta;     /* G x M current parameters (float32) */
+    const int32_t *n1, *n0;     /* G x M observed 1s / 0s of each cluster */
+    const double *sd;           /* n_sd proposal standard deviations */
+    int64_t n_sd;
+    double tmin, tmax;          /* truncation bounds, libs/CRP.py:13-14 */
+    double FP, FN;
+    double p, q;                /* Beta prior shapes */
+    int uniform_prior;          /* p == q == 1: prior terms are 0 */
+    int trans_prob;             /* libs/CRP.py:339-342: clip A, log(1-e^A) */
+    /* optional cache of the prior log-density: where known_theta[g,m] has
+     * the bits of old_theta[g,m], known_prior[g,m] is its density */
+    const float *known_theta;
+    const double *known_prior;
+    /* the draws, written first (G x M each) */
+    int32_t *sd_idx;
+    double *U, *u;
+    /* results */
+    float *new_theta;           /* G x M */
+    double *prior_out;          /* G x M density of new_theta, or NULL */
+    double *A;                  /* G x M log acceptance ratios (work/out) */
+    double *log_prob;           /* G: sum of A in index order (trans_prob) */
+    int64_t *declined;          /* G */
+    int threads;                /* <= 1: the calling thread only */
+} bnpc_mh_args;
+
+/* *status = 0: done.  *status = 1: the draws were taken (sd_idx, U, u are
+ * valid, the stream has advanced) but some element needs a branch this
+ * library leaves to SciPy (an interval right of zero, non-finite terms, a
+ * uniform that is exactly 0): the caller evaluates the batch from the draws.
+ * rng == NULL: the caller has filled sd_idx / U / u already. */
+int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
+                  const bnpc_mh_args *a, int *status);
+
+/* Beta(p, q) log-density of n float32 values (scipy.stats.beta._logpdf with
+ * the public wrapper's support handling), re-using known_prior[i] where
+ * known_theta[i] has the bits of x[i]; *seq_sum (optional) receives the sum
+ * in index order.  libs/CRP.py:249 (get_lprior_full), :371-376. */
+int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x, int64_t n,
+                         double p, double q, const float *known_theta,
+                         const double *known_prior, double *out,
+                         double *seq_sum, int threads);
+
 /* Checker hook: the cumulative sums np.cumsum(p) holds for the probability
  * vector p[top] = 1.0, p[a != top] = 1e-15-floor (a = 0..A) - the case in
  * which one cluster dominates _normalize_log_probs (libs/CRP.py:88-100).  The

@@ -481,16 +481,104 @@ def test_prior_density_cache_changes_nothing(monkeypatch):
 
     ref, _ = walk(0)
     got, m = walk(1 << 22)
-    assert m._prior_rows and set(m._prior_rows) == set(m.cells_per_cluster)
+    assert m._prior_rows is not None \
+        and set(m._prior_rows[0].tolist()) == set(m.cells_per_cluster)
     for r, g in zip(ref, got):
         assert np.array_equal(np.asarray(r), np.asarray(g))
-    # a cached row is only trusted while theta is unchanged
+    # a cached entry is only trusted while theta is unchanged
     ids = np.array(sorted(m.cells_per_cluster))
     theta = m.parameters[ids].copy()
     theta[0, 0] = np.float32(0.123)
     from bnpc_amd import fastdist
-    assert np.array_equal(m._known_prior(ids, theta),
-        fastdist.beta_logpdf(theta, m.p, m.q))
+    want = np.cumsum(fastdist.beta_logpdf(theta, m.p, m.q).ravel())[-1]
+    assert m._prior_density_sum(ids, theta) == want
+    monkeypatch.setenv('BNPC_NATIVE_MH', '0')
+    P._NATIVE.clear()
+    assert m._prior_density_sum(ids, theta) == want
+    P._NATIVE.clear()
+
+
+def _walk_moves(data, kind='learn', steps=10, seed=5):
+    np.random.seed(seed)
+    m = make(P, kind, data, pb=(.25, .25))
+    m.init()
+    out = []
+    for step in range(steps):
+        if step % 3 == 2:
+            out.append(repr(m.update_assignments_split_merge([.6, .4], 2)))
+        else:
+            m.update_assignments_Gibbs()
+        out.append(m.update_parameters())
+        out.append(m.parameters[sorted(m.cells_per_cluster)].copy())
+        out.append(m.get_lprior_full())
+        out.append(m.assignment.copy())
+    out.append(np.random.random())
+    return out
+
+
+def test_native_parameter_batch_is_in_use_and_changes_nothing(monkeypatch):
+    """The native batch of the MH parameter moves (bnpc_mh_batch on SciPy's /
+    NumPy's own scalar kernels) passes its start-up bit comparison here, and a
+    walk through Gibbs sweeps, split/merge moves and parameter updates is
+    bit-identical with it switched off (the SciPy-level array path), with one
+    thread and with several."""
+    data = synth(31, 80, 140, 4, 0.15)
+    walks = []
+    for native, threads in (('0', '1'), ('1', '1'), ('1', '4')):
+        monkeypatch.setenv('BNPC_NATIVE_MH', native)
+        monkeypatch.setenv('BNPC_HOST_THREADS', threads)
+        P._NATIVE.clear()
+        assert (P._native_kernels() is not None) == (native == '1')
+        walks.append(_walk_moves(data))
+    P._NATIVE.clear()
+    for other in walks[1:]:
+        for r, g in zip(walks[0], other):
+            assert np.array_equal(np.asarray(r), np.asarray(g))
+
+
+def test_native_batch_hands_exotic_elements_back(monkeypatch):
+    """A uniform that is exactly 0 (log raises in the reference) is not the
+    native batch's business: it reports status 1 with the draws taken, and the
+    SciPy-level path evaluates the batch from those draws."""
+    from bnpc_amd import _lib
+    table = P._native_kernels()
+    assert table is not None
+    rng = np.random.RandomState(3)
+    G, M = 2, 50
+    old = np.clip(rng.uniform(size=(G, M)), P.TMIN, P.TMAX).astype(np.float32)
+    n1 = rng.randint(0, 9, size=(G, M))
+    n0 = rng.randint(0, 9, size=(G, M))
+    sd = np.array([.1, .25, .5])
+    draws = [rng.randint(0, 3, size=(G, M)), rng.uniform(size=(G, M)),
+        rng.uniform(size=(G, M))]
+    args = (table, old, n1, n0, sd, P.TMIN, P.TMAX, 0.01, 0.2, .25, .25, False,
+        False)
+    assert _lib.mh_batch(*args, draws=draws)[0] == 0
+    draws[2][1, 7] = 0.0
+    assert _lib.mh_batch(*args, draws=draws)[0] == 1
+    draws[2][1, 7] = 0.5
+    draws[1][0, 3] = 0.0
+    assert _lib.mh_batch(*args, draws=draws)[0] == 1
+
+    # the model falls back to the array path on status 1, from the same draws
+    data = synth(4, 40, M, 3, 0.1)
+    res = []
+    for force in (False, True):
+        np.random.seed(9)
+        m = make(P, 'fixed', data, pb=(.25, .25))
+        m.init()
+        if force:
+            real = _lib.mh_batch
+
+            def exotic(*a, **k):
+                out = real(*a, **k)
+                return (1,) + out[1:]
+            monkeypatch.setattr(_lib, 'mh_batch', exotic)
+        res.append((m.update_parameters(),
+            m.parameters[sorted(m.cells_per_cluster)].copy(),
+            np.random.random()))
+    assert res[0][0] == res[1][0] and res[0][2] == res[1][2]
+    assert np.array_equal(res[0][1], res[1][1])
 
 
 def test_failed_tiled_sweep_leaves_no_tile_behind(monkeypatch):
