@@ -138,6 +138,16 @@ extern "C" int bnpc_dominated_cdf(int64_t A, int64_t top, double *cdf)
     return 0;
 }
 
+// -39 - log(A + 1): below this gap to the runner-up the tail sum of A
+// exponentials cannot reach 2^-55 (see the dominated case below)
+static double dominated_bound(int64_t A)
+{
+    static thread_local std::vector<double> bound;
+    while ((int64_t)bound.size() <= A)
+        bound.push_back(-39.0 - log((double)(bound.size() + 1)));
+    return bound[A];
+}
+
 extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                                 const int64_t *perm, const double *ll,
                                 const double *post_new,
@@ -155,6 +165,10 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     const int64_t N = st->n_cells, ld = st->ld;
     double *post = scratch;             // ld + 1
     double *cdf = scratch + ld + 1;     // ld + 1
+    // log prior of joining a column's cluster at its current size
+    static thread_local std::vector<double> cpr_store;
+    if ((int64_t)cpr_store.size() < ld) cpr_store.resize(ld);
+    double *cpr = cpr_store.data();
     st->new_cell = -1;
     if (st->pos_end > N || st->pos > st->pos_end ||
         (st->row_base >= 0 && st->row_base > st->pos)) {
@@ -162,6 +176,11 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                        (long long)st->pos, (long long)st->pos_end,
                        (long long)st->row_base);
         return 2;
+    }
+
+    for (int64_t c = 0; c < st->n_cols && c < ld; c++) {
+        const int64_t sz = col_size[c];
+        cpr[c] = (sz >= 0 && sz <= N + 1) ? crp_prior[sz] : 0.0;
     }
 
     while (st->pos < st->pos_end) {
@@ -204,38 +223,59 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             col_of_id[old_id] = -1;
         } else {
             col_size[old_col]--;
+            cpr[old_col] = crp_prior[col_size[old_col]];
         }
 
         // log posterior of joining each live cluster / a new one (:268-274)
         const int64_t A = st->n_active;
         const double *row = ll + (size_t)(st->row_base >= 0 ?
             st->pos - st->row_base : cell) * ld;
-        int64_t top = 0;
+        int64_t top = 0;                    // first maximum
+        double best = -INFINITY;
         double second = -INFINITY;          // largest entry that is not `top`
-        for (int64_t a = 0; a < A; a++) {
-            const int64_t c = order[a];
-            const double v = row[c] + crp_prior[col_size[c]];
-            post[a] = v;
-            if (v > post[top]) {
-                second = post[top];
-                top = a;
-            } else if (a != top && v > second) {
-                second = v;
+        if (A <= 64) {
+            // few clusters (the converged regime): where the maximum sits is
+            // data, so selects instead of branches
+            for (int64_t a = 0; a < A; a++) {
+                const int64_t c = order[a];
+                const double v = row[c] + cpr[c];
+                post[a] = v;
+                const bool gt = v > best;
+                const double runner = v > second ? v : second;
+                second = gt ? best : runner;
+                top = gt ? a : top;
+                best = gt ? v : best;
+            }
+        } else {
+            // many clusters: a new maximum is rare, branches predict well
+            // and there is no select chain from one entry to the next
+            for (int64_t a = 0; a < A; a++) {
+                const int64_t c = order[a];
+                const double v = row[c] + cpr[c];
+                post[a] = v;
+                if (v > best) {
+                    second = best;
+                    best = v;
+                    top = a;
+                } else if (v > second) {
+                    second = v;
+                }
             }
         }
-        post[A] = post_new[cell];
-        if (post[A] > post[top]) {
-            second = post[top];
-            top = A;
-        } else if (A != top && post[A] > second) {
-            second = post[A];
+        {
+            const double v = post_new[cell];
+            post[A] = v;
+            const bool gt = v > best;
+            const double runner = v > second ? v : second;
+            second = gt ? best : runner;
+            top = gt ? A : top;
+            best = gt ? v : best;
         }
-        if (A == 0) second = -INFINITY;
 
         // _normalize_log_probs (CRP.py:88-100) + choice(p=): cdf = cumsum(p);
         // cdf /= cdf[-1]; searchsorted(u, right).
-        const double ptop = post[top];
-        const double u_dominated = -39.0 - log((double)(A + 1));
+        const double ptop = best;
+        const double u_dominated = dominated_bound(A);
         int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
         if (FLOOR_STEP > 0 && second - ptop < u_dominated) {
             // One cluster dominates: the tail sum of exponentials is below
@@ -256,10 +296,17 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             };
             const double total = cdf_at(A);
             const double u = mt_double(rng);
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (cdf_at(mid) / total > u) hi = mid;
-                else lo = mid + 1;
+            // the answer is `top` unless u falls into one of the 1e-15
+            // slivers (the predicate cdf[a]/total > u is monotone in a)
+            if (cdf_at(top) / total > u
+                && (top == 0 || !(cdf_at(top - 1) / total > u))) {
+                lo = top;
+            } else {
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (cdf_at(mid) / total > u) hi = mid;
+                    else lo = mid + 1;
+                }
             }
         } else {
             // exp() is still skipped where its result is known exactly:
@@ -298,6 +345,7 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const int64_t c = order[pick];
         assignment[cell] = col_id[c];
         col_size[c]++;
+        cpr[c] = crp_prior[col_size[c]];
     }
     return 0;
 }

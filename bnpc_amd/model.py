@@ -263,6 +263,17 @@ class CRP:
             self._ctx = _lib.Context(data=self.data, device=device)
         return self._ctx
 
+    def _memo(self, key, compute):
+        """Scalar prior densities by argument value (a pure function of the
+        key; the same few arguments recur step after step)."""
+        memo = self.__dict__.setdefault('_scalar_memo', {})
+        hit = memo.get(key)
+        if hit is None:
+            if len(memo) > 64:
+                memo.clear()
+            hit = memo[key] = compute()
+        return hit
+
     def close(self):
         if self._ctx is not None:
             self._ctx.close()
@@ -468,7 +479,8 @@ class CRP:
         # Gamma(*DP_a_gamma): scipy reads the pair as (shape, loc), as in the
         # reference (libs/CRP.py:55)
         shape, loc = self.DP_a_gamma[0], self.DP_a_gamma[1]
-        lprior = fastdist.gamma_logpdf(self.DP_a, shape, loc) \
+        lprior = self._memo(('DP_a', self.DP_a), lambda:
+                fastdist.gamma_logpdf(self.DP_a, shape, loc)) \
             + np.cumsum(self.CRP_prior[sizes])[-1]
         if not self.beta_prior_uniform:
             ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
@@ -1288,10 +1300,12 @@ class CRP_errors_learning(CRP):
             + self._error_prior_logpdf('FN', self.FN)
 
     def _error_prior_logpdf(self, which, x):
-        """FP_prior.logpdf / FN_prior.logpdf without the frozen wrapper."""
+        """FP_prior.logpdf / FN_prior.logpdf without the frozen wrapper (the
+        current rates are asked for at every step: remembered by value)."""
         a, b, mean, sd = (self.FP_prior if which == 'FP'
             else self.FN_prior).args
-        return fastdist.tn_logpdf(x, a, b, mean, sd)
+        return self._memo((which, float(x)),
+            lambda: fastdist.tn_logpdf(x, a, b, mean, sd))
 
     def update_error_rates(self):
         """libs/CRP_learning_errors.py:52-55"""
