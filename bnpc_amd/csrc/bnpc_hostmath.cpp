@@ -19,13 +19,17 @@
 // _ppf / _logpdf, _norm_logpdf, beta_gen._logpdf, and scipy.special.logsumexp
 // for two real terms.
 
+#include <limits.h>
+#include <linux/futex.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <atomic>
-#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -39,10 +43,16 @@
 // ---------------------------------------------------------------------------
 namespace {
 
+// Workers park on a futex word that packs (job generation << 8 | ranks
+// wanted); after a job they spin for a short while first, so that the batches
+// of one sampler step (a few hundred microseconds apart) do not pay a kernel
+// wake-up each.  No mutex on the wake-up path: all workers start in parallel.
 class Team {
 public:
     explicit Team(int workers) : pid_(getpid())
     {
+        const char *e = getenv("BNPC_HOST_SPIN_US");
+        spin_ns_ = (e ? atol(e) : 50) * 1000L;
         for (int i = 0; i < workers; i++)
             threads_.emplace_back([this, i] { loop(i + 1); });
     }
@@ -53,53 +63,70 @@ public:
     void run(int n, const std::function<void(int)> &fn)
     {
         if (n > size()) n = size();
+        if (n > 255) n = 255;
         if (n <= 1) {
             fn(0);
             return;
         }
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            job_ = &fn;
-            want_ = n;
-            pending_ = n - 1;
-            generation_++;
-        }
-        start_.notify_all();
+        job_ = &fn;
+        pending_.store(n - 1, std::memory_order_relaxed);
+        gen_ = (gen_ + 1) & 0xffffff;
+        word_.store((gen_ << 8) | (uint32_t)n, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0)
+            syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAKE_PRIVATE, INT_MAX,
+                    nullptr, nullptr, 0);
         fn(0);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return pending_ == 0; });
+        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
         job_ = nullptr;
     }
 
 private:
+    static void cpu_relax()
+    {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    static long now_ns()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1000000000L + ts.tv_nsec;
+    }
     void loop(int rank)
     {
-        uint64_t seen = 0;
+        uint32_t seen = 0;      // the word before the first job (a worker
+                                // may start after that job was posted)
         for (;;) {
-            const std::function<void(int)> *job;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                start_.wait(lk, [&] { return generation_ != seen; });
-                seen = generation_;
-                if (rank >= want_) continue;
-                job = job_;
+            uint32_t w;
+            const long t0 = now_ns();
+            int polls = 0;
+            while ((w = word_.load(std::memory_order_acquire)) == seen) {
+                cpu_relax();
+                if ((++polls & 63) == 0 && now_ns() - t0 > spin_ns_) {
+                    sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                    // re-checked by the kernel: returns at once if the word
+                    // has moved on
+                    syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAIT_PRIVATE,
+                            seen, nullptr, nullptr, 0);
+                    sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                }
             }
-            (*job)(rank);
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                pending_--;
+            seen = w;
+            if (rank < (int)(w & 0xff)) {
+                (*job_)(rank);
+                pending_.fetch_sub(1, std::memory_order_release);
             }
-            done_.notify_one();
         }
     }
 
     pid_t pid_;
+    long spin_ns_ = 50000;
     std::vector<std::thread> threads_;
-    std::mutex mu_;
-    std::condition_variable start_, done_;
+    std::atomic<uint32_t> word_{0};
+    std::atomic<int> pending_{0}, sleepers_{0};
+    uint32_t gen_ = 0;
     const std::function<void(int)> *job_ = nullptr;
-    uint64_t generation_ = 0;
-    int want_ = 0, pending_ = 0;
 };
 
 // The team of this PROCESS.  A forked child inherits the object but not the
@@ -379,11 +406,9 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             for (int64_t g = 0; g < G; g++) {
                 int32_t *si = a->sd_idx + g * M;
                 double *Ug = a->U + g * M, *ug = a->u + g * M;
-                for (int64_t m = 0; m < M; m++)
-                    si[m] = (int32_t)mt_interval(rng, (uint64_t)(a->n_sd - 1));
-                for (int64_t m = 0; m < M; m++)
-                    Ug[m] = 0.0 + 1.0 * mt_double(rng);
-                for (int64_t m = 0; m < M; m++) ug[m] = mt_double(rng);
+                mt_fill_interval32(rng, (uint32_t)(a->n_sd - 1), si, M);
+                mt_fill_double(rng, Ug, M);     // uniform(0, 1) == sample
+                mt_fill_double(rng, ug, M);
                 rows_ready.store(g + 1, std::memory_order_release);
             }
         }
@@ -435,6 +460,14 @@ extern "C" int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x,
     const double bl = k->betaln(p, q, 0);
     const int64_t chunks = (n + 4 * BLK - 1) / (4 * BLK);
     if (threads > chunks) threads = (int)chunks;
+    // cache hits are a compare and a copy: not worth waking anybody
+    int64_t misses = 0;
+    if (known_theta)
+        for (int64_t i = 0; i < n; i++)
+            misses += memcmp(known_theta + i, x + i, sizeof(float)) != 0;
+    else
+        misses = n;
+    if (misses < 4096) threads = 1;
     std::atomic<int64_t> next(0);
     auto work = [&](int) {
         for (;;) {

@@ -62,10 +62,9 @@ extern "C" int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M,
     for (int64_t g = 0; g < G; g++) {
         int32_t *si = sd_idx + g * M;
         double *Ug = U + g * M, *ug = u + g * M;
-        for (int64_t m = 0; m < M; m++)
-            si[m] = (int32_t)mt_interval(rng, (uint64_t)(n_sd - 1));
-        for (int64_t m = 0; m < M; m++) Ug[m] = 0.0 + 1.0 * mt_double(rng);
-        for (int64_t m = 0; m < M; m++) ug[m] = mt_double(rng);
+        mt_fill_interval32(rng, (uint32_t)(n_sd - 1), si, M);
+        mt_fill_double(rng, Ug, M);     // uniform(0, 1): 0.0 + 1.0 * u == u
+        mt_fill_double(rng, ug, M);
     }
     return 0;
 }
