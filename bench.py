@@ -91,7 +91,9 @@ def step(chain, i, burn_in):
 
 class Ranks:
     """One process per GPU (torch.distributed.run contract).  No collective
-    in the data path: gloo carries the barrier and the max of the timings."""
+    in the data path: with more than one rank, gloo carries the barrier and
+    the max of the timings; a single rank needs no torch at all (the product
+    has no PyTorch dependency)."""
 
     def __init__(self):
         self.rank = int(os.environ.get('RANK', '0'))
@@ -99,30 +101,32 @@ class Ranks:
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.dist = None
         self.torch = None
+        self.ctx = None         # the chain's device context, once it exists
 
     def init(self):
-        import torch
-        self.torch = torch
         if self.world > 1:
+            import torch
             import torch.distributed as dist
+            self.torch = torch
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29577')
             dist.init_process_group('gloo', rank=self.rank,
                 world_size=self.world)
             self.dist = dist
-        self.device = 0
-        if torch.cuda.is_available():
-            # one rank per GPU; if there are more ranks than GPUs (a 2-rank
-            # smoke run on a 1-GPU box) ranks share devices round-robin
-            self.device = self.local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(self.device)
+        # one rank per GPU; if there are more ranks than GPUs (a 2-rank smoke
+        # run on a 1-GPU box) ranks share devices round-robin
+        from bnpc_amd import _lib
+        try:
+            self.device = self.local_rank % max(1, _lib.device_count())
+        except RuntimeError:        # no GPU: the CPU tests of this harness
+            self.device = 0
         return self
 
     def barrier_sync(self):
         if self.dist is not None:
             self.dist.barrier()
-        if self.torch is not None and self.torch.cuda.is_available():
-            self.torch.cuda.synchronize()
+        if self.ctx is not None:
+            self.ctx.sync()     # hipStreamSynchronize on the chain's stream
 
     def max_over_ranks(self, x):
         if self.dist is None:
@@ -206,6 +210,7 @@ def main():
         if i == 1:
             first_step_s = time.perf_counter() - t0
     K_warm = len(model.cells_per_cluster)
+    ranks.ctx = model._dev()
 
     # snapshot of the post-warm-up state for the CPU baseline
     snap = None

@@ -140,13 +140,29 @@ def as_i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 
 
+# Whether THIS process has made a HIP call: a process that has must not fork
+# workers that use the GPU (they would inherit a runtime they cannot use), so
+# the chain driver spawns them instead (bnpc_amd.handoff).
+_touched = {'pid': None}
+
+
+def mark_gpu_touched():
+    _touched['pid'] = os.getpid()
+
+
+def gpu_touched():
+    return _touched['pid'] == os.getpid()
+
+
 def device_count():
+    mark_gpu_touched()
     n = C.c_int(0)
     check(load().bnpc_device_count(C.byref(n)), 'device_count')
     return n.value
 
 
 def device_info(device=0):
+    mark_gpu_touched()
     name = C.create_string_buffer(64)
     cus = C.c_int(0)
     check(load().bnpc_device_info(device, name, 64, C.byref(cus)),
@@ -180,6 +196,7 @@ def codist(assignments, device=None):
     out = np.empty(N * (N - 1) // 2, dtype=np.int32)
     if device is None:
         device = int(os.environ.get('BNPC_DEVICE', '0'))
+    mark_gpu_touched()
     check(load().bnpc_codist(device, ptr(a, C.c_int32), S, N,
         ptr(out, C.c_int32)), 'codist')
     return out
@@ -343,6 +360,7 @@ class Context:
 
     def __init__(self, data=None, codes=None, device=0):
         lib = load()
+        mark_gpu_touched()
         handle = _ctx()
         if codes is not None:
             codes = np.ascontiguousarray(codes, dtype=np.int8)

@@ -56,20 +56,52 @@ def _node_has_simds(node):
     return False
 
 
+def _listed(name):
+    """Entries of a *_VISIBLE_DEVICES variable, or None if it is not set.
+    An empty value hides every device, as the runtime reads it."""
+    value = os.environ.get(name)
+    if value is None:
+        return None
+    return [e for e in value.replace(' ', '').split(',') if e != '']
+
+
 def _visible_gpus():
-    """GPUs to spread chains over, read from sysfs: no HIP call happens in
-    the parent, so the pool can still fork."""
+    """Number of GPUs chains may be spread over = the device ordinals
+    0..n-1 the HIP runtime will offer a worker.  No HIP call happens here
+    (the parent must stay fork-safe), so the count is read the way the
+    runtime reads it: BNPC_NUM_DEVICES if given; else the length of
+    HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES, its alias), which indexes
+    into what ROCR_VISIBLE_DEVICES leaves; else the length of
+    ROCR_VISIBLE_DEVICES; else the GPU nodes the kernel driver lists."""
     forced = os.environ.get('BNPC_NUM_DEVICES')
     if forced:
         return max(1, int(forced))
     try:
-        return max(1, sum(_node_has_simds(d) for d in os.listdir(KFD_NODES)))
+        physical = sum(_node_has_simds(d) for d in os.listdir(KFD_NODES))
     except OSError:
-        return 1
+        physical = 0
+    rocr = _listed('ROCR_VISIBLE_DEVICES')
+    if rocr is not None:
+        physical = len(rocr)
+    for name in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        hip = _listed(name)
+        if hip is not None:
+            # ordinals beyond what ROCR leaves visible are ignored by HIP
+            return max(1, min(len(hip), physical) if physical else len(hip))
+    return max(1, physical)
 
 
-def _bind_worker_to_gpu(chain_index):
-    os.environ.setdefault('BNPC_DEVICE', str(chain_index % _visible_gpus()))
+def device_for_chain(chain_index, n_devices=None):
+    """Chain i runs on device ordinal i mod #visible (one chain per GPU while
+    there are GPUs left, round-robin beyond)."""
+    return chain_index % (n_devices or _visible_gpus())
+
+
+def _bind_worker_to_gpu(chain_index, n_devices=None):
+    """Called in the worker before its model creates a device context.  The
+    assignment is explicit: a BNPC_DEVICE inherited from the parent's
+    environment does not pin every chain to one GPU."""
+    os.environ['BNPC_DEVICE'] = str(device_for_chain(chain_index, n_devices))
 
 
 # ------------------------------------------------------------------- traces
@@ -447,18 +479,15 @@ class MCMC:
 
     @staticmethod
     def _fan_out(fn, jobs, on_done):
-        """One forked worker per job; a failure in any of them is raised here
-        after all have finished."""
-        failures = []
-        pool = mp.get_context('fork').Pool(len(jobs))
-        for job in jobs:
-            pool.apply_async(fn, job, callback=on_done,
-                error_callback=failures.append)
-        pool.close()
-        pool.join()
+        """One worker PROCESS per job (the reference's pool has as many
+        workers as chains, MCMC.py:100-120).  Workers are forked, so the model
+        and the chains reach them without a pickle; results come back through
+        POSIX shared memory (bnpc_amd.handoff).  A worker that raises, or dies
+        without reporting, fails the run here after all have finished."""
+        from bnpc_amd import handoff
+        failures = handoff.run_jobs(fn, jobs, on_done)
         if failures:
-            raise RuntimeError(f'chain worker failed: {failures[0]!r}') \
-                from failures[0]
+            raise RuntimeError(f'chain worker failed: {failures[0]}')
 
     def run_chain(self, chain_type, run_var, assign, i, verbosity):
         """Worker body (MCMC.py:126-135): seed, private model copy, init, run."""

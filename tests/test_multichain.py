@@ -141,3 +141,132 @@ def test_runtime_mode_and_fixed_assignment(monkeypatch, tmp_path):
     np.testing.assert_allclose(p['ML'], o['ML'], rtol=1e-9)
     np.testing.assert_allclose(p['FN'], o['FN'], rtol=1e-9)
     assert np.array_equal(p['params'], o['params'])
+
+
+# ---- chain -> device placement (libs/MCMC.py:100-131 has no GPUs to place) ---
+def _report_device(i):
+    from bnpc_amd import mcmc
+    mcmc._bind_worker_to_gpu(i)
+    return i, int(os.environ['BNPC_DEVICE'])
+
+
+def _placements(n_chains):
+    from bnpc_amd import handoff
+    got = {}
+    fails = handoff.run_jobs(_report_device, [(i,) for i in range(n_chains)],
+        lambda r: got.__setitem__(*r))
+    assert not fails
+    return [got[i] for i in range(n_chains)]
+
+
+def test_eight_workers_get_eight_distinct_devices(monkeypatch):
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES',
+            'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv('BNPC_NUM_DEVICES', '8')
+    # a BNPC_DEVICE inherited from the parent must not pin every chain
+    monkeypatch.setenv('BNPC_DEVICE', '5')
+    assert _placements(8) == list(range(8))
+    assert _placements(10) == list(range(8)) + [0, 1]
+
+
+def test_placement_honours_the_visible_device_lists(monkeypatch):
+    from bnpc_amd import mcmc
+    monkeypatch.delenv('BNPC_NUM_DEVICES', raising=False)
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
+    monkeypatch.setattr(mcmc, 'KFD_NODES', '/nonexistent')
+    # a 4-entry list: ordinals 0..3, whatever the physical ids are
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '2,3,5,7')
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    assert mcmc._visible_gpus() == 4
+    assert _placements(8) == [0, 1, 2, 3, 0, 1, 2, 3]
+    # ROCR filters first, HIP indexes into what is left
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '0,1,2,3,4,5')
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,5')
+    assert mcmc._visible_gpus() == 2
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    assert mcmc._visible_gpus() == 6
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '3')
+    assert _placements(3) == [0, 0, 0]
+
+
+def test_placement_counts_kfd_gpu_nodes(monkeypatch, tmp_path):
+    from bnpc_amd import mcmc
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES',
+            'CUDA_VISIBLE_DEVICES', 'BNPC_NUM_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    for node, simds in enumerate((0, 0, 1024, 1024, 1024)):    # 2 CPUs, 3 GPUs
+        d = tmp_path / str(node)
+        d.mkdir()
+        (d / 'properties').write_text(f'cpu_cores_count 0\nsimd_count {simds}\n')
+    monkeypatch.setattr(mcmc, 'KFD_NODES', str(tmp_path))
+    assert mcmc._visible_gpus() == 3
+    assert [mcmc.device_for_chain(i) for i in range(4)] == [0, 1, 2, 0]
+
+
+# ---- hand-off through shared memory ---------------------------------------
+def _big_result(i, n):
+    rng = np.random.RandomState(i)
+    return {'no': i, 'labels': rng.randint(0, 9, size=(n, 50)),
+        'trace': rng.uniform(size=n), 'tag': 'x' * 10}
+
+
+def _dies_quietly(i):
+    if i == 1:
+        os._exit(3)
+    return i
+
+
+def test_results_return_through_shared_memory_and_it_is_released():
+    from bnpc_amd import handoff
+    before = set(os.listdir('/dev/shm'))
+    got = []
+    fails = handoff.run_jobs(_big_result, [(i, 40000) for i in range(3)],
+        got.append)
+    assert not fails and sorted(r['no'] for r in got) == [0, 1, 2]
+    for r in got:
+        want = _big_result(r['no'], 40000)
+        assert np.array_equal(r['labels'], want['labels'])
+        assert np.array_equal(r['trace'], want['trace'])
+        r['trace'][0] = 1.0             # arrays are private and writable
+    assert set(os.listdir('/dev/shm')) == before
+    # the in-band part is small: the arrays travelled out of band
+    data, name, sizes = handoff.pack(_big_result(0, 40000))
+    assert len(data) < 2000 and sum(sizes) > 40000 * 50 * 8
+    assert handoff.unpack((data, name, sizes))['tag'] == 'x' * 10
+
+
+def test_a_worker_that_dies_is_reported():
+    from bnpc_amd import handoff
+    got = []
+    fails = handoff.run_jobs(_dies_quietly, [(i,) for i in range(3)],
+        got.append)
+    assert sorted(got) == [0, 2]
+    assert len(fails) == 1 and 'exit code 3' in fails[0]
+
+
+def test_workers_are_spawned_once_the_parent_touched_the_gpu(monkeypatch):
+    from bnpc_amd import handoff
+    monkeypatch.setattr(_lib, '_touched', {'pid': os.getpid()})
+    got = []
+    # a spawned child re-imports this module: the job must be importable
+    fails = handoff.run_jobs(_big_result, [(4, 10)], got.append)
+    assert not fails and got[0]['no'] == 4
+
+
+def test_single_rank_bench_harness_needs_no_torch():
+    """bench.py --gpus 1 must run where torch is not installed (the product
+    has no PyTorch dependency): the import is blocked in a child process."""
+    import subprocess
+    code = ("import sys; sys.modules['torch'] = None; "
+        f"sys.path.insert(0, {ROOT!r}); import bench; "
+        "r = bench.Ranks().init(); "
+        "t = bench.timed_steps(r, lambda i: None, 1, 3); r.close(); "
+        "import bnpc_amd.model, bnpc_amd.mcmc, libs.CRP; "
+        "assert 'torch.distributed' not in sys.modules; print('ok', t >= 0)")
+    env = {k: v for k, v in os.environ.items()
+        if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True,
+        text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith('ok True')
