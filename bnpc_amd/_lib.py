@@ -58,6 +58,7 @@ SIGNATURES = {
     'bnpc_create_codes': (C.c_int, [C.c_int, _i64, _i64,
         C.POINTER(C.c_int8), C.POINTER(_ctx)]),
     'bnpc_destroy': (C.c_int, [_ctx]),
+    'bnpc_reload_options': (C.c_int, [_ctx]),
     'bnpc_shape': (C.c_int, [_ctx, _pi64, _pi64]),
     'bnpc_cell_counts': (C.c_int, [_ctx, _pi32, _pi32]),
     'bnpc_view_set': (C.c_int, [_ctx, C.c_int, _pi64, _i64]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     'bnpc_ll_rows_wait': (C.c_int, [_ctx, C.c_int, C.POINTER(_pd)]),
     'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
     'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
+    'bnpc_view_counts': (C.c_int, [_ctx, C.c_int, _pi64, _i64, _pi32, _pi32]),
     'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
         _pi32]),
     'bnpc_ll_total': (C.c_int, [_ctx, _pf, _i64, _pd, _pd, C.c_int, _pd]),
@@ -513,6 +515,20 @@ class Context:
             ptr(offs, C.c_int64), G, ptr(n1, C.c_int32), ptr(n0, C.c_int32)),
             'colcounts')
         return n1, n0
+
+    def view_counts(self, view, labels, G):
+        """(n1, n0) G x M int32 column counts of the view's slots grouped by
+        `labels` (one per slot; < 0: not counted)."""
+        labels = as_i64(labels)
+        assert labels.size == self.view_size(view)
+        n1 = np.empty((G, self.M), dtype=np.int32)
+        n0 = np.empty((G, self.M), dtype=np.int32)
+        check(self._lib.bnpc_view_counts(self._h, view, ptr(labels, C.c_int64),
+            G, ptr(n1, C.c_int32), ptr(n0, C.c_int32)), 'view_counts')
+        return n1, n0
+
+    def reload_options(self):
+        check(self._lib.bnpc_reload_options(self._h), 'reload_options')
 
     def colcounts_by_label(self, assignment, ids, fetch=True):
         assignment = as_i64(assignment)

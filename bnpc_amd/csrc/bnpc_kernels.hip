@@ -83,7 +83,49 @@ struct View {
     int64_t nblk = 0;
 };
 
+// Switches, read from the environment when a context is created and again
+// by bnpc_reload_options (A/B tools and tests); never on the launch path.
+struct Tunables {
+    int msplit = 1, msplit_waves = 4096, msplit_max = 64;
+    int xcd_remap = 1, ll_asm = 2, asm2_min_wgs = 448;
+    int tables_flat_max = 1 << 20, force_kw = 0;
+    int zero_copy = 1;              // small payloads are read / written in
+    int64_t zc_in_max = 256 << 10;  // place in pinned host memory
+    int64_t zc_out_max = 512 << 10;
+    int mask_counts_max = 64;       // segments for the mask-popcount counts
+    int seq_kernel = 1;             // k_ll_seq for caller-built tables
+    int fused_small = 1;            // one-launch small-K likelihood
+};
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static void read_tunables(Tunables &t)
+{
+    t.msplit = env_int("BNPC_MSPLIT", 1);
+    t.msplit_waves = env_int("BNPC_MSPLIT_WAVES", 4096);
+    t.msplit_max = env_int("BNPC_MSPLIT_MAX", 64);
+    t.xcd_remap = env_int("BNPC_XCD_REMAP", 1);
+    t.ll_asm = env_int("BNPC_LL_ASM", 2);       // 0 C++, 1 asm, 2 asm x2
+    t.asm2_min_wgs = env_int("BNPC_ASM2_MIN_WGS", 448);
+    t.tables_flat_max = env_int("BNPC_TABLES_FLAT_MAX", 1 << 20);
+    t.force_kw = env_int("BNPC_KW", 0);
+    if (t.force_kw != 1 && t.force_kw != 2 && t.force_kw != 4
+        && t.force_kw != 8)
+        t.force_kw = 0;
+    t.zero_copy = env_int("BNPC_ZERO_COPY", 1);
+    t.zc_in_max = (int64_t)env_int("BNPC_ZC_IN_KB", 256) << 10;
+    t.zc_out_max = (int64_t)env_int("BNPC_ZC_OUT_KB", 512) << 10;
+    t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
+    t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 1);
+    t.fused_small = env_int("BNPC_FUSED_SMALL", 1);
+}
+
 struct bnpc_ctx {
+    Tunables tun;
     int device = 0;
     int64_t N = 0, M = 0;
     int W = 0;          // 64-bit words per row
@@ -117,7 +159,16 @@ struct bnpc_ctx {
     // ~10 us apiece.  Reset at the start of every call that uses it; every
     // such call ends with a stream synchronisation.
     void *stage = nullptr;
+    char *stage_dev = nullptr;      // the arena as the device addresses it
     size_t stage_used = 0;
+    // small results written by kernels straight into pinned host memory
+    void *zc_out = nullptr;
+    char *zc_out_dev = nullptr;
+    // where the kernels of the current call read their inputs from: device
+    // scratch filled by a DMA copy, or the staging arena in place
+    const float *theta_src = nullptr;
+    const double *tab_src = nullptr;
+    const long long *cells_src = nullptr;
     // double-buffered pinned results of issued (asynchronous) tiles
     void *tile_pin[2] = {nullptr, nullptr};
     size_t tile_cap[2] = {0, 0};
@@ -129,6 +180,7 @@ struct bnpc_ctx {
     // configuration of the last k_ll launch (bnpc_bench_ll re-issues it)
     int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
+    double *last_out = nullptr;
 };
 
 static int ensure(DevBuf &b, size_t bytes)
@@ -144,6 +196,7 @@ static int ensure(DevBuf &b, size_t bytes)
 }
 
 #define STAGE_BYTES ((size_t)4 << 20)
+#define ZC_OUT_BYTES ((size_t)1 << 20)
 
 // a slot of the staging arena, or nullptr when the payload is too large
 static void *stage_slot(bnpc_ctx *c, size_t bytes)
@@ -154,11 +207,55 @@ static void *stage_slot(bnpc_ctx *c, size_t bytes)
             c->stage = nullptr;
             return nullptr;
         }
+        void *dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, c->stage, 0) == hipSuccess)
+            c->stage_dev = (char *)dev;
     }
     const size_t at = (c->stage_used + 255) & ~(size_t)255;
     if (at + bytes > STAGE_BYTES) return nullptr;
     c->stage_used = at + bytes;
     return (char *)c->stage + at;
+}
+
+// Zero-copy input: the payload is copied into the pinned arena and the
+// kernels of this call read it there, over the host link, instead of from a
+// device buffer filled by a DMA copy - for payloads of a few hundred KiB a
+// copy engine launch costs more than the bytes.  Returns the DEVICE address,
+// or nullptr (too large / switched off): then the caller copies.  Every call
+// that uses the arena ends with a stream synchronisation.
+static const void *stage_in_place(bnpc_ctx *c, const void *src, size_t bytes)
+{
+    if (!c->tun.zero_copy || (int64_t)bytes > c->tun.zc_in_max) return nullptr;
+    void *slot = stage_slot(c, bytes);
+    if (!slot || !c->stage_dev) return nullptr;
+    memcpy(slot, src, bytes);
+    return c->stage_dev + ((char *)slot - (char *)c->stage);
+}
+
+// Zero-copy output: `bytes` of pinned host memory the kernels of this call may
+// write their (small) result to; *dev receives the device address.  nullptr:
+// not available for this size.
+static void *zc_result(bnpc_ctx *c, size_t bytes, void **dev)
+{
+    if (!c->tun.zero_copy || (int64_t)bytes > c->tun.zc_out_max
+        || bytes > ZC_OUT_BYTES)
+        return nullptr;
+    if (!c->zc_out) {
+        if (hipHostMalloc(&c->zc_out, ZC_OUT_BYTES, hipHostMallocDefault)
+                != hipSuccess) {
+            c->zc_out = nullptr;
+            return nullptr;
+        }
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, c->zc_out, 0) != hipSuccess) {
+            (void)hipHostFree(c->zc_out);
+            c->zc_out = nullptr;
+            return nullptr;
+        }
+        c->zc_out_dev = (char *)d;
+    }
+    *dev = c->zc_out_dev;
+    return c->zc_out;
 }
 
 // host -> device on the context's stream; `src` may be released on return
@@ -710,6 +807,72 @@ __global__ __launch_bounds__(256) void k_colcounts(
 }
 
 // ---------------------------------------------------------------------------
+// K3b: column counts of G <= a few dozen segments of a VIEW, from its lane
+// masks: segment g is given as membership words member[g][blk] (bit s = slot
+// 64*blk + s belongs to g), and
+//   n1[g][m] = sum_blk popcount(masks[blk][m].ones  & member[g][blk])
+//   n0[g][m] = sum_blk popcount(masks[blk][m].zeros & member[g][blk])
+// Same integers as K3.  No cell lists, no atomics, no zero-fill: thread <->
+// mutation (coalesced 16-byte mask loads), the 4 waves of a workgroup take
+// every 4th block and add up through LDS, 8 segments per thread share each
+// loaded mask.  Results go to a device buffer (kept for K6) and, if given, to
+// pinned host memory in place.
+// ---------------------------------------------------------------------------
+#define CM_SEG 8
+
+__global__ __launch_bounds__(256) void k_counts_masks(
+    const ulonglong2 *__restrict__ masks, int Mpad, int M, long long nblk,
+    const unsigned long long *__restrict__ member, int G,
+    int *__restrict__ n1, int *__restrict__ n0, int *__restrict__ h1,
+    int *__restrict__ h0)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = blockIdx.x * 64 + lane;
+    const int g0 = blockIdx.y * CM_SEG;
+    int c1[CM_SEG], c0[CM_SEG];
+#pragma unroll
+    for (int j = 0; j < CM_SEG; j++) c1[j] = c0[j] = 0;
+    for (long long b = wave; b < nblk; b += 4) {
+        const ulonglong2 mk = masks[(size_t)b * Mpad + m];
+#pragma unroll
+        for (int j = 0; j < CM_SEG; j++) {
+            if (g0 + j < G) {
+                const unsigned long long mem =
+                    member[(size_t)(g0 + j) * nblk + b];
+                c1[j] += __popcll(mk.x & mem);
+                c0[j] += __popcll(mk.y & mem);
+            }
+        }
+    }
+    __shared__ int red[4][2 * CM_SEG][64];
+#pragma unroll
+    for (int j = 0; j < CM_SEG; j++) {
+        red[wave][2 * j][lane] = c1[j];
+        red[wave][2 * j + 1][lane] = c0[j];
+    }
+    __syncthreads();
+    // wave w finishes segments j = w, w + 4
+#pragma unroll
+    for (int i = 0; i < CM_SEG / 4; i++) {
+        const int j = wave + 4 * i;
+        if (g0 + j < G && m < M) {
+            const int s1 = red[0][2 * j][lane] + red[1][2 * j][lane]
+                + red[2][2 * j][lane] + red[3][2 * j][lane];
+            const int s0 = red[0][2 * j + 1][lane] + red[1][2 * j + 1][lane]
+                + red[2][2 * j + 1][lane] + red[3][2 * j + 1][lane];
+            const size_t at = (size_t)(g0 + j) * M + m;
+            n1[at] = s1;
+            n0[at] = s0;
+            if (h1) {
+                h1[at] = s1;
+                h0[at] = s0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K6: total log-likelihood from per-cluster counts, up to 4 trial error pairs
 //   out[e] = sum_{k,m} n1[k][m]*L1_e(theta[k][m]) + n0[k][m]*L0_e(theta[k][m])
 //   = CRP.get_ll_full (libs/CRP.py:237-238) and
@@ -810,6 +973,7 @@ static int create_impl(int device, int64_t N, int64_t M, GetCode code,
     *out = nullptr;
     HIPCHK(hipSetDevice(device));
     bnpc_ctx *c = new bnpc_ctx();
+    read_tunables(c->tun);
     c->device = device;
     c->N = N;
     c->M = M;
@@ -914,6 +1078,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     if (c->stage) (void)hipHostFree(c->stage);
+    if (c->zc_out) (void)hipHostFree(c->zc_out);
     for (int s = 0; s < 2; s++) {
         if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
         if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
@@ -924,6 +1089,13 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     delete c;
+    return 0;
+}
+
+extern "C" int bnpc_reload_options(bnpc_ctx *c)
+{
+    ARGCHK(c, "ctx is NULL");
+    read_tunables(c->tun);
     return 0;
 }
 
@@ -957,10 +1129,15 @@ extern "C" int bnpc_view_set(bnpc_ctx *c, int view, const int64_t *cells,
         c->views[view].nblk = 0;
         return 0;
     }
-    if (ensure(c->cells, n * sizeof(long long))) return 1;
     c->stage_used = 0;
-    if (h2d(c, c->cells.p, cells, n * sizeof(long long))) return 1;
-    if (build_view(c, view, (const long long *)c->cells.p, n)) return 1;
+    const long long *d_cells = (const long long *)stage_in_place(
+        c, cells, n * sizeof(long long));
+    if (!d_cells) {
+        if (ensure(c->cells, n * sizeof(long long))) return 1;
+        if (h2d(c, c->cells.p, cells, n * sizeof(long long))) return 1;
+        d_cells = (const long long *)c->cells.p;
+    }
+    if (build_view(c, view, d_cells, n)) return 1;
     // the caller's buffer is only borrowed: finish the copy before returning
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -972,12 +1149,6 @@ extern "C" int bnpc_view_size(const bnpc_ctx *c, int view, int64_t *n)
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
     *n = c->views[view].n;
     return 0;
-}
-
-static int env_flag(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
 }
 
 // clusters per wave: least padded work, weighted by the scalar-pipe overhead
@@ -999,15 +1170,15 @@ static int pick_kw(int64_t K)
 
 // mutation split of a small launch: enough waves to fill the chip, chunks of
 // at least 16 mutations, a multiple of 8 (stage sizes divide 8)
-static void pick_msplit(int64_t waves, int Mt, bool allowed, int *MS,
-                        int *m_chunk)
+static void pick_msplit(const Tunables &tun, int64_t waves, int Mt,
+                        bool allowed, int *MS, int *m_chunk)
 {
     *MS = 1;
     *m_chunk = Mt;
-    const int64_t target = env_flag("BNPC_MSPLIT_WAVES", 4096);
+    const int64_t target = tun.msplit_waves;
     if (!allowed || waves >= target) return;
     int64_t want = (target + waves - 1) / waves;
-    const int64_t cap = env_flag("BNPC_MSPLIT_MAX", 64);
+    const int64_t cap = tun.msplit_max;
     if (want > cap) want = cap;
     int chunk = (int)((Mt + want - 1) / want);
     chunk = (chunk + 7) / 8 * 8;
@@ -1028,8 +1199,8 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     const int64_t G = (K + KW - 1) / KW;
     const int64_t nwg = ((v.nblk + 3) / 4) * G * MS;
     ARGCHK(nwg < (1ll << 31), "launch too large");
-    const int xcd = env_flag("BNPC_XCD_REMAP", 1);
-    const int impl = env_flag("BNPC_LL_ASM", 2);    // 0 C++, 1 asm, 2 asm x2
+    const int xcd = c->tun.xcd_remap;
+    const int impl = c->tun.ll_asm;                 // 0 C++, 1 asm, 2 asm x2
     double *dst = d_out;
     if (MS > 1) {
         if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double))) return 1;
@@ -1049,7 +1220,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        (long long)v.n, (long long)v.nblk,                    \
                        (const double *)c->tabs.p, (int)K, (long long)ldo,    \
                        dst, xcd, MS, m_chunk)
-    if (KW == 8 && impl == 2 && wg2 >= env_flag("BNPC_ASM2_MIN_WGS", 448)) {
+    if (KW == 8 && impl == 2 && wg2 >= c->tun.asm2_min_wgs) {
         if (MS > 1) {
             if (MSq == 1) dst = d_out;  // the workgroup already holds the sum
             LAUNCH_ASM(2, true, split2);
@@ -1097,25 +1268,25 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         return 1;
     dim3 tgrid((unsigned)((c->Mt + 255) / 256), (unsigned)G);
     if (from_theta && G * KW * (int64_t)c->Mt
-            <= env_flag("BNPC_TABLES_FLAT_MAX", 1 << 20)) {
+            <= c->tun.tables_flat_max) {
         const int64_t threads = G * KW * (int64_t)c->Mt;
         hipLaunchKernelGGL(k_tables_theta_flat<KW>,
                            dim3((unsigned)((threads + 255) / 256)), dim3(256),
                            0, c->stream,
                            c->use_rows ? (const float *)c->theta_store.p
-                                       : (const float *)c->theta.p,
+                                       : c->theta_src,
                            c->use_rows, (int)K, (int)c->M, c->Mt, (int)G, FP,
                            FN, (double *)c->tabs.p);
     } else if (from_theta)
         hipLaunchKernelGGL(k_tables_theta<KW>, tgrid, dim3(256), 0, c->stream,
                            c->use_rows ? (const float *)c->theta_store.p
-                                       : (const float *)c->theta.p,
+                                       : c->theta_src,
                            c->use_rows, (int)K, (int)c->M, c->Mt, FP, FN,
                            (double *)c->tabs.p);
     else
         hipLaunchKernelGGL(k_tables_relayout<KW>, tgrid, dim3(256), 0,
-                           c->stream, (const double *)c->tab_in.p,
-                           (const double *)c->tab_in.p + (size_t)K * c->M,
+                           c->stream, c->tab_src,
+                           c->tab_src + (size_t)K * c->M,
                            (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
     HIPCHK(hipGetLastError());
     if (issue_ll<KW>(c, v, K, ldo, d_out, MS, m_chunk)) return 1;
@@ -1130,26 +1301,26 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     if (ldo == 0) ldo = K;
     ARGCHK(ldo >= K, "ldo smaller than K");
     const size_t out_bytes = (size_t)v.n * ldo * sizeof(double);
-    if (ensure(c->out, out_bytes)) return 1;
+    // a small result that the caller wants on the host is written by the
+    // kernels straight into pinned host memory (no copy-engine launch)
+    void *zc_dev = nullptr;
+    void *zc_host = out ? zc_result(c, out_bytes, &zc_dev) : nullptr;
+    if (!zc_host && ensure(c->out, out_bytes)) return 1;
     int kw = pick_kw(K);
     // A launch that will be split over the mutations runs the hand-placed
     // 8-cluster kernel whatever K is: its workgroups reduce 4 chunks through
     // LDS, which beats the narrower C++ tilings from K = 2 on (measured
     // K = 2..12: 11-17 us against 11-25 us; profiles/r01/small_launch_study.md)
-    if (K >= 2 && from_theta && env_flag("BNPC_MSPLIT", 1)
-        && v.nblk * ((K + 7) / 8) < env_flag("BNPC_MSPLIT_WAVES", 4096))
+    if (K >= 2 && from_theta && c->tun.msplit
+        && v.nblk * ((K + 7) / 8) < c->tun.msplit_waves)
         kw = 8;
-    const char *force = getenv("BNPC_KW");
-    if (force) {
-        int f = atoi(force);
-        if (f == 1 || f == 2 || f == 4 || f == 8) kw = f;
-    }
+    if (c->tun.force_kw) kw = c->tun.force_kw;
     // Sums over caller-built tables keep the strict mutation order (they are
     // the bit-exact path); device-built tables may split the mutations.
     int MS, m_chunk;
-    pick_msplit(v.nblk * ((K + kw - 1) / kw), c->Mt,
-                from_theta && env_flag("BNPC_MSPLIT", 1), &MS, &m_chunk);
-    double *d_out = (double *)c->out.p;
+    pick_msplit(c->tun, v.nblk * ((K + kw - 1) / kw), c->Mt,
+                from_theta && c->tun.msplit, &MS, &m_chunk);
+    double *d_out = zc_host ? (double *)zc_dev : (double *)c->out.p;
     int rc;
     switch (kw) {
     case 8: rc = launch_ll<8>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
@@ -1164,7 +1335,18 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     c->last_view = view;
     c->last_K = K;
     c->last_ldo = ldo;
-    if (out) {
+    c->last_out = d_out;
+    if (zc_host) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        // columns K..ldo of the caller's rows are not ours to touch
+        if (ldo == K) {
+            memcpy(out, zc_host, out_bytes);
+        } else {
+            for (int64_t r = 0; r < v.n; r++)
+                memcpy(out + r * ldo, (const double *)zc_host + r * ldo,
+                       (size_t)K * sizeof(double));
+        }
+    } else if (out) {
         HIPCHK(hipMemcpyAsync(out, c->out.p, out_bytes, hipMemcpyDeviceToHost,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1188,12 +1370,19 @@ static int ll_theta_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     if (K == 0) return 0;
     SideLane lane(c);
     const size_t bytes = (size_t)K * c->M * sizeof(float);
-    if (ensure(c->theta, bytes)) return 1;
     c->stage_used = 0;
-    void *slot = stage_slot(c, bytes);
-    if (slot) memcpy(slot, theta, bytes);
-    HIPCHK(hipMemcpyAsync(c->theta.p, slot ? slot : (const void *)theta, bytes,
-                          hipMemcpyHostToDevice, c->stream));
+    void *slot = nullptr;
+    c->theta_src = (const float *)stage_in_place(c, theta, bytes);
+    if (c->theta_src) {
+        slot = (void *)c->theta_src;    // staged: drain before returning
+    } else {
+        if (ensure(c->theta, bytes)) return 1;
+        slot = stage_slot(c, bytes);
+        if (slot) memcpy(slot, theta, bytes);
+        HIPCHK(hipMemcpyAsync(c->theta.p, slot ? slot : (const void *)theta,
+                              bytes, hipMemcpyHostToDevice, c->stream));
+        c->theta_src = (const float *)c->theta.p;
+    }
     int rc = ll_common(c, view, K, ldo, true, FP, FN, out);
     // staged parameters / the side lane: nothing may be in flight on return
     if (((slot && drain) || lane.on) && !out && rc == 0)
@@ -1388,10 +1577,24 @@ extern "C" int bnpc_ll_tables(bnpc_ctx *c, int view, const double *L1,
     HIPCHK(hipSetDevice(c->device));
     if (K == 0) return 0;
     const size_t bytes = (size_t)K * c->M * sizeof(double);
-    if (ensure(c->tab_in, 2 * bytes)) return 1;
     c->stage_used = 0;
-    if (h2d(c, c->tab_in.p, L1, bytes)) return 1;
-    if (h2d(c, (char *)c->tab_in.p + bytes, L0, bytes)) return 1;
+    c->tab_src = nullptr;
+    if (c->tun.zero_copy && (int64_t)(2 * bytes) <= c->tun.zc_in_max) {
+        // L1 then L0, contiguous in the arena
+        void *slot = stage_slot(c, 2 * bytes);
+        if (slot && c->stage_dev) {
+            memcpy(slot, L1, bytes);
+            memcpy((char *)slot + bytes, L0, bytes);
+            c->tab_src = (const double *)(c->stage_dev
+                + ((char *)slot - (char *)c->stage));
+        }
+    }
+    if (!c->tab_src) {
+        if (ensure(c->tab_in, 2 * bytes)) return 1;
+        if (h2d(c, c->tab_in.p, L1, bytes)) return 1;
+        if (h2d(c, (char *)c->tab_in.p + bytes, L0, bytes)) return 1;
+        c->tab_src = (const double *)c->tab_in.p;
+    }
     int rc = ll_common(c, view, K, ldo, false, 0.0, 0.0, out);
     if (!out && rc == 0) HIPCHK(hipStreamSynchronize(c->stream));
     return rc;
@@ -1435,6 +1638,107 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// Column counts of G segments of a view from its lane masks (K3b).
+// label_of(s) = segment of slot s, or < 0 for none.  The counts land in `cnt`
+// on the device ([n1: G x M][n0: G x M]) and in n1 / n0 on the host.
+template <typename LabelOf>
+static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
+                             int64_t G, DevBuf &cnt, int32_t *n1, int32_t *n0)
+{
+    const View &v = c->views[view];
+    const size_t half = (size_t)G * c->M * sizeof(int32_t);
+    if (ensure(cnt, 2 * half)) return 1;
+    c->stage_used = 0;
+    if (v.n == 0) {
+        HIPCHK(hipMemsetAsync(cnt.p, 0, 2 * half, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (n1) memset(n1, 0, half);
+        if (n0) memset(n0, 0, half);
+        return 0;
+    }
+    // membership words, built in the arena when they fit
+    const size_t mem_bytes = (size_t)G * v.nblk * sizeof(unsigned long long);
+    unsigned long long *mem = nullptr;
+    const unsigned long long *d_mem = nullptr;
+    std::vector<unsigned long long> heap;
+    if (c->tun.zero_copy && (int64_t)mem_bytes <= c->tun.zc_in_max) {
+        mem = (unsigned long long *)stage_slot(c, mem_bytes);
+        if (mem && c->stage_dev)
+            d_mem = (const unsigned long long *)(c->stage_dev
+                + ((char *)mem - (char *)c->stage));
+        else
+            mem = nullptr;
+    }
+    if (!mem) {
+        heap.resize((size_t)G * v.nblk);
+        mem = heap.data();
+    }
+    memset(mem, 0, mem_bytes);
+    for (int64_t s = 0; s < v.n; s++) {
+        const int64_t g = label_of(s);
+        if (g >= G) {
+            bnpc_set_error("bad argument: segment label out of range");
+            return 2;
+        }
+        if (g >= 0) mem[(size_t)g * v.nblk + (s >> 6)] |= 1ull << (s & 63);
+    }
+    if (!d_mem) {
+        if (ensure(c->chunks, mem_bytes)) return 1;
+        HIPCHK(hipMemcpyAsync(c->chunks.p, mem, mem_bytes,
+                              hipMemcpyHostToDevice, c->stream));
+        d_mem = (const unsigned long long *)c->chunks.p;
+    }
+    void *zc_dev = nullptr;
+    int *zc_host = (n1 && n0) ? (int *)zc_result(c, 2 * half, &zc_dev)
+                              : nullptr;
+    int *d1 = (int *)cnt.p, *d0 = d1 + (size_t)G * c->M;
+    int *h1 = zc_host ? (int *)zc_dev : nullptr;
+    int *h0 = h1 ? h1 + (size_t)G * c->M : nullptr;
+    dim3 grid((unsigned)(c->Mpad / 64), (unsigned)((G + CM_SEG - 1) / CM_SEG));
+    hipLaunchKernelGGL(k_counts_masks, grid, dim3(256), 0, c->stream,
+                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
+                       (long long)v.nblk, d_mem, (int)G, d1, d0, h1, h0);
+    HIPCHK(hipGetLastError());
+    if (zc_host) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(n1, zc_host, half);
+        memcpy(n0, zc_host + (size_t)G * c->M, half);
+    } else if (n1 && n0) {
+        // n1 and n0 are contiguous on the device: one copy when the arena
+        // can take it, else two into the caller's arrays
+        void *slot = stage_slot(c, 2 * half);
+        if (slot) {
+            HIPCHK(hipMemcpyAsync(slot, cnt.p, 2 * half,
+                                  hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            memcpy(n1, slot, half);
+            memcpy(n0, (char *)slot + half, half);
+        } else {
+            HIPCHK(hipMemcpyAsync(n1, d1, half, hipMemcpyDeviceToHost,
+                                  c->stream));
+            HIPCHK(hipMemcpyAsync(n0, d0, half, hipMemcpyDeviceToHost,
+                                  c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    } else {
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int bnpc_view_counts(bnpc_ctx *c, int view, const int64_t *labels,
+                                int64_t G, int32_t *n1, int32_t *n0)
+{
+    ARGCHK(c && n1 && n0, "NULL argument");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(G > 0 && G <= 4096, "G out of range");
+    ARGCHK(c->views[view].n == 0 || labels, "labels is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    SideLane lane(c);
+    return counts_from_masks(c, view,
+        [=](int64_t s) -> int64_t { return labels[s]; }, G, c->cnt, n1, n0);
 }
 
 extern "C" int bnpc_colcounts(bnpc_ctx *c, const int64_t *cells,
@@ -1488,6 +1792,15 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
                "assignment holds an id that is not in ids");
         offs[pos[a] + 1]++;
     }
+    if (K <= c->tun.mask_counts_max) {
+        // few clusters: popcounts over the lane masks of the identity view
+        const int64_t *pp = pos.data();
+        int rc = counts_from_masks(c, 0,
+            [=](int64_t s) -> int64_t { return pp[assignment[s]]; }, K,
+            c->lab_cnt, n1, n0);
+        if (rc == 0) c->lab_K = K;
+        return rc;
+    }
     for (int64_t g = 0; g < K; g++) offs[g + 1] += offs[g];
     std::vector<int64_t> cells(c->N), fill(offs.begin(), offs.end() - 1);
     for (int64_t i = 0; i < c->N; i++)
@@ -1521,13 +1834,31 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
                "error rates must lie in (0, 1)");
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = (size_t)K * c->M * sizeof(float);
-    if (ensure(c->theta, bytes)) return 1;
-    if (ensure(c->partial, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
-    if (!c->pin_small)
-        HIPCHK(hipHostMalloc(&c->pin_small, TOTAL_BLOCKS * 4 * sizeof(double),
-                             hipHostMallocDefault));
     c->stage_used = 0;
-    if (h2d(c, c->theta.p, theta, bytes)) return 1;
+    const float *d_theta = (const float *)stage_in_place(c, theta, bytes);
+    if (!d_theta) {
+        if (ensure(c->theta, bytes)) return 1;
+        if (h2d(c, c->theta.p, theta, bytes)) return 1;
+        d_theta = (const float *)c->theta.p;
+    }
+    // a fixed number of blocks per problem size (the sum order must not
+    // depend on anything else): ~1024 elements per block, at most 256 blocks
+    const long long KM = (long long)K * c->M;
+    int blocks = (int)((KM + 1023) / 1024);
+    if (blocks > TOTAL_BLOCKS) blocks = TOTAL_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const size_t part_bytes = (size_t)blocks * 4 * sizeof(double);
+    void *zc_dev = nullptr;
+    const double *p = (const double *)zc_result(c, part_bytes, &zc_dev);
+    double *d_part = (double *)zc_dev;
+    if (!p) {
+        if (ensure(c->partial, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
+        if (!c->pin_small)
+            HIPCHK(hipHostMalloc(&c->pin_small,
+                                 TOTAL_BLOCKS * 4 * sizeof(double),
+                                 hipHostMallocDefault));
+        d_part = (double *)c->partial.p;
+    }
     double fp[4] = {0.5, 0.5, 0.5, 0.5}, fn[4] = {0.5, 0.5, 0.5, 0.5};
     for (int e = 0; e < E; e++) {
         fp[e] = FP[e];
@@ -1535,20 +1866,20 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
     }
     const int *n1 = (const int *)c->lab_cnt.p;
     const int *n0 = n1 + (size_t)K * c->M;
-    hipLaunchKernelGGL(k_ll_total, dim3(TOTAL_BLOCKS), dim3(256), 0, c->stream,
-                       (const float *)c->theta.p, n1, n0,
-                       (long long)(K * c->M), E, fp[0], fn[0], fp[1], fn[1],
-                       fp[2], fn[2], fp[3], fn[3], (double *)c->partial.p);
+    hipLaunchKernelGGL(k_ll_total, dim3(blocks), dim3(256), 0, c->stream,
+                       d_theta, n1, n0, KM, E, fp[0], fn[0], fp[1], fn[1],
+                       fp[2], fn[2], fp[3], fn[3], d_part);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->pin_small, c->partial.p,
-                          TOTAL_BLOCKS * 4 * sizeof(double),
-                          hipMemcpyDeviceToHost, c->stream));
+    if (!p) {
+        HIPCHK(hipMemcpyAsync(c->pin_small, c->partial.p, part_bytes,
+                              hipMemcpyDeviceToHost, c->stream));
+        p = (const double *)c->pin_small;
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
-    const double *p = (const double *)c->pin_small;
     for (int e = 0; e < E; e++) {
-        double s = 0.0;
-        for (int b = 0; b < TOTAL_BLOCKS; b++) s += p[b * 4 + e];
-        out[e] = s;
+        double sum = 0.0;
+        for (int b = 0; b < blocks; b++) sum += p[b * 4 + e];
+        out[e] = sum;
     }
     return 0;
 }
@@ -1563,7 +1894,7 @@ extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; r++) {
         int rc;
-        double *o = (double *)c->out.p;
+        double *o = c->last_out;
         switch (c->last_kw) {
         case 8: rc = issue_ll<8>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;
         case 4: rc = issue_ll<4>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;

@@ -229,6 +229,7 @@ class CRP:
         state['_newcl'] = None
         state['_lab'] = None
         state['_prior_rows'] = None
+        state['_rg_view'] = None
         data = state.pop('data')
         state['_data_codes'] = np.where(np.isnan(data), 3, data) \
             .astype(np.int8)
@@ -994,10 +995,7 @@ class CRP:
         """libs/CRP.py:527-544.  The non-anchor cells of the move are gathered
         ONCE into a device slot view and re-used by every scan; the counts of
         the merged cluster are those of the two halves added."""
-        self._rg_S = cells[1:-1]
-        self._rg_counts = None
-        if self._rg_S.size:
-            self._dev().view_set(VIEW_MOVE, self._rg_S)
+        self._rg_open(cells)
         self._rg_init_split(cells)
         self.rg_params_merge = self._beta_draw(*self._rg_all_counts(cells))
         for _ in range(scan_no):
@@ -1005,6 +1003,17 @@ class CRP:
         if move == 'split':
             return self._do_rg_split_MH(cells, size_data)
         return self._do_rg_merge_MH(cells, size_data)
+
+    def _rg_open(self, cells):
+        """Device view of a move's cells [i, S..., j] (anchors first and
+        last): the scans use rows 1..n-2, the column counts of the two launch
+        clusters all of them."""
+        self._rg_S = cells[1:-1]
+        self._rg_counts = None
+        self._rg_view = None
+        if self._rg_S.size:
+            self._dev().view_set(VIEW_MOVE, cells)
+            self._rg_view = np.array(cells, dtype=np.int64)
 
     def _rg_members(self, cells, which):
         S = cells[1:-1]
@@ -1016,11 +1025,22 @@ class CRP:
         rg_assignment: one launch, cached until the assignment changes."""
         key = np.asarray(self.rg_assignment, dtype=np.int64).tobytes()
         if self._rg_counts is None or self._rg_counts[0] != key:
-            members = [self._rg_members(cells, 0), self._rg_members(cells, 1)]
+            view = getattr(self, '_rg_view', None)
             if cells.size <= 4:
-                cnt = [self._counts_of(m) for m in members]
+                cnt = [self._counts_of(self._rg_members(cells, g))
+                    for g in range(2)]
             else:
-                n1, n0 = self._dev().colcounts(members)
+                if view is not None and view.size == cells.size \
+                        and np.array_equal(view, cells):
+                    # the two launch clusters are two segments of the move's
+                    # own view: anchors fixed, the rest by rg_assignment
+                    labels = np.empty(cells.size, dtype=np.int64)
+                    labels[0], labels[-1] = 0, 1
+                    labels[1:-1] = self.rg_assignment
+                    n1, n0 = self._dev().view_counts(VIEW_MOVE, labels, 2)
+                else:
+                    n1, n0 = self._dev().colcounts(
+                        [self._rg_members(cells, g) for g in range(2)])
                 cnt = [(n1[g].astype(np.float64), n0[g].astype(np.float64))
                     for g in range(2)]
             self._rg_counts = (key, cnt)
@@ -1045,7 +1065,7 @@ class CRP:
             fill = self._beta_mix_const[0]
             anchors = np.nan_to_num(self.data[[i, j]], nan=fill)
             L1, L0 = self._tables(anchors)
-            ll = self._dev().ll_tables(VIEW_MOVE, L1, L0)
+            ll = self._dev().ll_tables(VIEW_MOVE, L1, L0)[1:-1]
             self.rg_assignment = np.where(ll[:, 1] > ll[:, 0], 1, 0) \
                 .astype(np.int64)
         self._rg_counts = None
@@ -1131,10 +1151,14 @@ class CRP:
         """libs/CRP.py:635-638: (|cells| x 2) in one launch on the move's
         slot view (cells must be the move's non-anchor cells)."""
         theta = np.stack([params[0], params[1]]).astype(np.float32)
-        if not (self._rg_S.size == len(cells)
-                and np.array_equal(self._rg_S, cells)):
-            self._rg_S = np.asarray(cells)
-            self._dev().view_set(VIEW_MOVE, self._rg_S)
+        view = getattr(self, '_rg_view', None)
+        if view is not None and view.size == len(cells) + 2 \
+                and np.array_equal(view[1:-1], cells):
+            return self._dev().ll_theta(VIEW_MOVE, theta, self.FP,
+                self.FN)[1:-1]
+        # not the current move's cells: a view of their own
+        self._rg_view = None
+        self._dev().view_set(VIEW_MOVE, np.asarray(cells))
         return self._dev().ll_theta(VIEW_MOVE, theta, self.FP, self.FN)
 
     def _do_rg_split_MH(self, cells, size_data):

@@ -60,6 +60,9 @@ int bnpc_create(int device, int64_t N, int64_t M, const double *data_nan,
 int bnpc_create_codes(int device, int64_t N, int64_t M, const int8_t *codes,
                       bnpc_ctx **out);
 int bnpc_destroy(bnpc_ctx *ctx);
+/* Kernel-selection switches (BNPC_* environment variables, README) are read
+ * when a context is created; this reads them again (A/B tools, tests). */
+int bnpc_reload_options(bnpc_ctx *ctx);
 int bnpc_shape(const bnpc_ctx *ctx, int64_t *N, int64_t *M);
 
 /* per-cell counts of observed 1s and 0s (row sums of the planes).  With them
@@ -140,6 +143,14 @@ int bnpc_ll_tables(bnpc_ctx *ctx, int view, const double *L1, const double *L0,
 int bnpc_colcounts(bnpc_ctx *ctx, const int64_t *cells,
                    const int64_t *seg_offsets, int64_t G,
                    int32_t *n1, int32_t *n0);
+
+/* Column counts of G segments of a slot view, from its lane masks:
+ * labels[s] = segment (0..G-1) of slot s, or < 0 for none.  Same integers as
+ * bnpc_colcounts on the corresponding cell lists, without cell lists, atomics
+ * or zero-fill: the restricted-Gibbs launch clusters of a split/merge move
+ * are the two segments of the move's own view (libs/CRP.py:590-606). */
+int bnpc_view_counts(bnpc_ctx *ctx, int view, const int64_t *labels,
+                     int64_t G, int32_t *n1, int32_t *n0);
 
 /* Per-cluster column counts for the K cluster ids `ids` (segment g = cells
  * with assignment == ids[g]).  The counts also stay resident on the device

@@ -116,6 +116,18 @@ class FakeContext:
             n0[g] = (sub == 0).sum(axis=0)
         return n1, n0
 
+    def view_counts(self, view, labels, G):
+        self._count('view_counts')
+        labels = np.asarray(labels)
+        cells = self.views[view]
+        assert labels.size == cells.size
+        n1, n0 = self.colcounts([cells[labels == g] for g in range(G)])
+        self.calls['colcounts'] -= 1
+        return n1, n0
+
+    def reload_options(self):
+        pass
+
     def colcounts_by_label(self, assignment, ids, fetch=True):
         self._count('colcounts_by_label')
         assignment = np.asarray(assignment)

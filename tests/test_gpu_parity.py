@@ -106,12 +106,15 @@ def test_every_cluster_tiling_gives_identical_bits(kw, monkeypatch):
     ctx = _lib.Context(data=data)
     monkeypatch.delenv('BNPC_KW', raising=False)
     monkeypatch.setenv('BNPC_MSPLIT', '0')      # strict mutation order
+    ctx.reload_options()
     ref = ctx.ll_theta(0, theta, 0.01, 0.2)
     monkeypatch.setenv('BNPC_KW', kw)
+    ctx.reload_options()
     assert np.array_equal(ctx.ll_theta(0, theta, 0.01, 0.2), ref)
     # small launches split the mutations over waves: partial sums combined in
     # index order - deterministic, equal to ~1 ulp of the sum
     monkeypatch.setenv('BNPC_MSPLIT', '1')
+    ctx.reload_options()
     split = ctx.ll_theta(0, theta, 0.01, 0.2)
     np.testing.assert_allclose(split, ref, rtol=1e-14)
     assert np.array_equal(split, ctx.ll_theta(0, theta, 0.01, 0.2))
@@ -264,6 +267,53 @@ def test_colcounts_segments_and_labels():
     ctx.close()
 
 
+@pytest.mark.parametrize('N,M', [(1000, 333), (63, 64), (4100, 1003)])
+def test_counts_from_lane_masks_equal_the_cell_list_counts(N, M, monkeypatch):
+    """Few segments: popcounts over the view's lane masks (k_counts_masks) -
+    by label on the identity view, by slot label on a gathered view - give
+    the integers of the cell-list kernel and of NumPy; every input / output
+    route (in-place pinned memory or copies)."""
+    rng = np.random.RandomState(N + M)
+    data = (rng.random_sample((N, M)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    ctx = _lib.Context(data=data)
+    for zero_copy in ('1', '0'):
+        monkeypatch.setenv('BNPC_ZERO_COPY', zero_copy)
+        for G in (1, 2, 7, 8, 9, 40, 64):
+            assign = rng.randint(0, G, N) * 2
+            ids = rng.permutation(np.unique(assign))
+            monkeypatch.setenv('BNPC_MASK_COUNTS_MAX', '64')
+            ctx.reload_options()
+            n1, n0 = ctx.colcounts_by_label(assign, ids)
+            monkeypatch.setenv('BNPC_MASK_COUNTS_MAX', '0')
+            ctx.reload_options()
+            o1, o0 = ctx.colcounts_by_label(assign, ids)
+            assert np.array_equal(n1, o1) and np.array_equal(n0, o0)
+            g = int(rng.randint(ids.size))
+            assert np.array_equal(n1[g],
+                (data[assign == ids[g]] == 1).sum(axis=0))
+            # the resident copy feeds ll_total: same total either way
+            theta = np.clip(rng.uniform(size=(ids.size, M)), 1e-5, 1 - 1e-5) \
+                .astype(np.float32)
+            a = ctx.ll_total(theta, [.01], [.2])
+            monkeypatch.setenv('BNPC_MASK_COUNTS_MAX', '64')
+            ctx.reload_options()
+            ctx.colcounts_by_label(assign, ids)
+            assert np.array_equal(a, ctx.ll_total(theta, [.01], [.2]))
+        # a gathered view with repeats, slots of no segment, 3 segments
+        cells = rng.randint(0, N, size=min(N, 777))
+        ctx.view_set(1, cells)
+        labels = rng.randint(-1, 3, size=cells.size)
+        n1, n0 = ctx.view_counts(1, labels, 3)
+        for g in range(3):
+            sub = data[cells[labels == g]]
+            assert np.array_equal(n1[g], (sub == 1).sum(axis=0))
+            assert np.array_equal(n0[g], (sub == 0).sum(axis=0))
+    with pytest.raises(RuntimeError, match='out of range'):
+        ctx.view_counts(1, np.full(cells.size, 3), 3)
+    ctx.close()
+
+
 def test_ll_total_trials_match_oracle(golden_dir):
     g = np.load(os.path.join(golden_dir, 'state_functions.npz'))
     data = decode(g['data'])
@@ -315,9 +365,7 @@ def test_state_functions_match_reference_golden(golden_dir):
                 np.testing.assert_allclose(A, g[pre + f'logA{j}_A{clip}'],
                     rtol=1e-9, atol=1e-9)
         cells = g[pre + 'rg_cells']
-        m._rg_S = cells[1:-1]
-        m._rg_counts = None
-        m._dev().view_set(P.VIEW_MOVE, m._rg_S)
+        m._rg_open(cells)
         m.rg_assignment = g[pre + 'rg_assignment_init'].astype(np.int64)
         m.rg_params_split = g[pre + 'rg_params_split'].copy()
         m.rg_params_merge = g[pre + 'rg_params_merge'].copy()

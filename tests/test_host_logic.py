@@ -250,9 +250,8 @@ def test_rg_init_split_is_bit_identical_to_oracle():
         rng.shuffle(cells)
         for m in (o, p):
             np.random.seed(trial)
-            m._rg_S = cells[1:-1].copy()
             if m is p:
-                m._dev().view_set(P.VIEW_MOVE, m._rg_S)
+                m._rg_open(cells.copy())
             m._rg_init_split(cells.copy())
         assert np.array_equal(o.rg_assignment, p.rg_assignment)
         assert np.array_equal(o.rg_params_split, p.rg_params_split)

@@ -32,6 +32,7 @@ times = {k: [] for k in variants}
 for rnd in range(5):
     for name, env in variants.items():
         os.environ.update(env)
+        ctx.reload_options()
         out = ctx.ll_theta(0, theta, 0.01, 0.2)
         if ref is None:
             ref = out

@@ -16,6 +16,7 @@ for n, K in ((500, 2), (5000, 10), (5000, 18), (5000, 64)):
     theta = np.clip(rng.uniform(size=(K, 1000)), 1e-5, 1 - 1e-5).astype(np.float32)
     for waves, cap in ((1, 1), (1024, 16), (2048, 32), (4096, 64), (8192, 64), (8192, 128), (16384, 128)):
         os.environ['BNPC_MSPLIT_WAVES'] = str(waves); os.environ['BNPC_MSPLIT_MAX'] = str(cap)
+        ctx.reload_options()
         ctx.ll_theta(view, theta, 0.01, 0.2, fetch=False); ctx.sync(); ctx.bench_ll(3)
         t = min(ctx.bench_ll(10) for _ in range(3))
         print(f'n={n:5d} K={K:3d} target_waves={waves:6d} cap={cap:4d}: {t*1e3:7.1f} us')

@@ -18,6 +18,7 @@ for N, M, K in ((1000, 200, 632), (50000, 5000, 50), (10000, 2000, 200), (5000, 
         for k in ('BNPC_MSPLIT', 'BNPC_ASM2_MIN_WGS', 'BNPC_KW'):
             os.environ.pop(k, None)
         os.environ.update(env)
+        ctx.reload_options()
         ctx.ll_theta(0, theta, 0.01, 0.2, fetch=False); ctx.sync(); ctx.bench_ll(2)
         t = min(ctx.bench_ll(5) for _ in range(3))
         print(f'N={N} M={M} K={K} {name:22s}: {t*1e3:8.1f} us  {N*K*M/(t*1e-3)/19.65e12*100:5.1f}% of peak')
