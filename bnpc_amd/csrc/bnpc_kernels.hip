@@ -758,6 +758,92 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
 }
 
 // ---------------------------------------------------------------------------
+// K2s: the same sums over CALLER-BUILT tables in strict mutation order - the
+// bit-exact path of CRP._rg_init_split (libs/CRP.py:547-561, whose
+// `ll_j > ll_i` is the one discrete decision on the path) and of the
+// new-cluster term (libs/CRP.py:230-234); K is 1 or 2 there and the launch
+// has a handful of waves, so what matters is the latency of ONE wave's chain
+// of M dependent adds, not throughput:
+//   wave <-> (block of 64 slots, ONE cluster); workgroup <-> 4 blocks of the
+//   same cluster, whose table {L1, L0}[m] is staged once into LDS straight
+//   from the caller's layout (no re-layout launch);
+//   the lane masks of 64 mutations arrive with ONE coalesced vector load
+//   (lane j holds mutation m0 + j), the next 64 are in flight meanwhile;
+//   mutation m0 + j: v_readlane the mask pair into SGPRs -> EXEC, the table
+//   pair by a broadcast LDS read, two exec-masked v_add_f64.
+// No scalar-memory round trip inside the loop (k_ll<KW> waits ~0.3 us for one
+// every stage when nothing else runs on the CU).  Same order, same bits.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long readlane_u64(
+    unsigned long long v, int lane)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v,
+                                                            lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(
+        (int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void k_ll_seq(
+    const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
+    long long nblk, const double *__restrict__ L1,
+    const double *__restrict__ L0, long long ldo, double *__restrict__ out)
+{
+    extern __shared__ double2 seq_tab[];    // [Mpad + 8] {L1, L0} of cluster k
+    const int k = blockIdx.y;
+    for (int m = threadIdx.x; m < Mpad + 8; m += 256)
+        seq_tab[m] = (m < M)
+            ? make_double2(L1[(size_t)k * M + m], L0[(size_t)k * M + m])
+            : make_double2(0.0, 0.0);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long long blk = (long long)blockIdx.x * 4 + wave;
+    if (blk >= nblk) return;            // whole wave, after the barrier
+    const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
+    double acc = 0.0;
+    ulonglong2 cur = mk[lane];
+    // table pairs of 8 mutations at a time, ping-pong: the LDS reads of the
+    // next 8 are in flight while the masked adds of these 8 issue (the asm
+    // blocks keep program order, so the prefetch is spelled out)
+    double2 ta[8], tb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) ta[u] = seq_tab[u];
+#define SEQ_STEP(T, J)                                                        \
+    {                                                                         \
+        const unsigned long long ones = readlane_u64(cur.x, (J));             \
+        const unsigned long long zeros = readlane_u64(cur.y, (J));            \
+        asm volatile(                                                         \
+            "s_mov_b64 exec, %1\n\t"                                          \
+            "v_add_f64 %0, %0, %3\n\t"                                        \
+            "s_mov_b64 exec, %2\n\t"                                          \
+            "v_add_f64 %0, %0, %4\n\t"                                        \
+            "s_mov_b64 exec, -1"                                              \
+            : "+v"(acc)                                                       \
+            : "s"(ones), "s"(zeros), "v"((T).x), "v"((T).y));                 \
+    }
+    for (int m0 = 0; m0 < Mpad; m0 += 64) {
+        ulonglong2 nxt = make_ulonglong2(0ull, 0ull);
+        if (m0 + 64 < Mpad) nxt = mk[m0 + 64 + lane];
+#pragma unroll
+        for (int sb = 0; sb < 8; sb += 2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) tb[u] = seq_tab[m0 + 8 * (sb + 1) + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) SEQ_STEP(ta[u], 8 * sb + u)
+#pragma unroll
+            for (int u = 0; u < 8; u++) ta[u] = seq_tab[m0 + 8 * (sb + 2) + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) SEQ_STEP(tb[u], 8 * (sb + 1) + u)
+        }
+        cur = nxt;
+    }
+#undef SEQ_STEP
+    const long long slot = blk * 64 + lane;
+    if (slot < n) out[(size_t)slot * ldo + k] = acc;
+}
+
+// ---------------------------------------------------------------------------
 // K3: column counts of 1s and 0s over chunks of cell segments
 //   n1[g][m] = #{c in segment g : x_cm = 1},  n0 likewise
 //   = the sums over a cell subset inside CRP._get_log_A (libs/CRP.py:359-368),
@@ -830,22 +916,33 @@ __global__ __launch_bounds__(256) void k_counts_masks(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int m = blockIdx.x * 64 + lane;
     const int g0 = blockIdx.y * CM_SEG;
+    // The membership words of this workgroup's segments, fetched ONCE with
+    // coalesced loads (they may sit in host memory: a dependent load per
+    // loop iteration would pay the link's latency every time) into LDS,
+    // [blk][CM_SEG]; segments past G read as empty.
+    extern __shared__ unsigned long long mem_lds[];
+    for (long long i = threadIdx.x; i < nblk * CM_SEG; i += 256) {
+        const long long b = i / CM_SEG;
+        const int j = (int)(i - b * CM_SEG);
+        mem_lds[i] = (g0 + j < G) ? member[(size_t)(g0 + j) * nblk + b] : 0ull;
+    }
+    __syncthreads();
     int c1[CM_SEG], c0[CM_SEG];
 #pragma unroll
     for (int j = 0; j < CM_SEG; j++) c1[j] = c0[j] = 0;
     for (long long b = wave; b < nblk; b += 4) {
         const ulonglong2 mk = masks[(size_t)b * Mpad + m];
+        const unsigned long long *mem = mem_lds + b * CM_SEG;
 #pragma unroll
         for (int j = 0; j < CM_SEG; j++) {
-            if (g0 + j < G) {
-                const unsigned long long mem =
-                    member[(size_t)(g0 + j) * nblk + b];
-                c1[j] += __popcll(mk.x & mem);
-                c0[j] += __popcll(mk.y & mem);
-            }
+            c1[j] += __popcll(mk.x & mem[j]);
+            c0[j] += __popcll(mk.y & mem[j]);
         }
     }
-    __shared__ int red[4][2 * CM_SEG][64];
+    // the membership words are done with: the same LDS takes the partial
+    // counts of the 4 waves (the launch reserves at least that much)
+    __syncthreads();
+    int (*red)[2 * CM_SEG][64] = (int (*)[2 * CM_SEG][64])mem_lds;
 #pragma unroll
     for (int j = 0; j < CM_SEG; j++) {
         red[wave][2 * j][lane] = c1[j];
@@ -1293,6 +1390,29 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     return 0;
 }
 
+#define SEQ_LDS_MAX ((size_t)144 << 10)
+
+// K2s on the caller's tables (c->tab_src: L1 [K][M] then L0 [K][M])
+static int issue_seq(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
+                     double *d_out)
+{
+    static bool lds_raised = false;
+    const size_t lds = (size_t)(c->Mpad + 8) * sizeof(double2);
+    if (lds > 48 * 1024 && !lds_raised) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SEQ_LDS_MAX));
+        lds_raised = true;
+    }
+    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)K);
+    hipLaunchKernelGGL(k_ll_seq, grid, dim3(256), lds, c->stream,
+                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
+                       (long long)v.n, (long long)v.nblk, c->tab_src,
+                       c->tab_src + (size_t)K * c->M, (long long)ldo, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
                      bool from_theta, double FP, double FN, double *out)
 {
@@ -1322,6 +1442,13 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
                 from_theta && c->tun.msplit, &MS, &m_chunk);
     double *d_out = zc_host ? (double *)zc_dev : (double *)c->out.p;
     int rc;
+    const size_t seq_lds = (size_t)(c->Mpad + 8) * sizeof(double2);
+    if (!from_theta && c->tun.seq_kernel && !c->tun.force_kw
+        && seq_lds <= SEQ_LDS_MAX && K <= 65535) {
+        rc = issue_seq(c, v, K, ldo, d_out);
+        kw = -1;
+        MS = 1;
+    } else
     switch (kw) {
     case 8: rc = launch_ll<8>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
     case 4: rc = launch_ll<4>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
@@ -1697,7 +1824,15 @@ static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
     int *h1 = zc_host ? (int *)zc_dev : nullptr;
     int *h0 = h1 ? h1 + (size_t)G * c->M : nullptr;
     dim3 grid((unsigned)(c->Mpad / 64), (unsigned)((G + CM_SEG - 1) / CM_SEG));
-    hipLaunchKernelGGL(k_counts_masks, grid, dim3(256), 0, c->stream,
+    // dynamic LDS: nblk x CM_SEG membership words (50 KB at 50000 cells)
+    size_t lds = (size_t)v.nblk * CM_SEG * sizeof(unsigned long long);
+    const size_t red_bytes = 4 * 2 * CM_SEG * 64 * sizeof(int);
+    if (lds < red_bytes) lds = red_bytes;
+    if (lds > 56 * 1024) {
+        bnpc_set_error("view too large for the mask-count kernel");
+        return 1;
+    }
+    hipLaunchKernelGGL(k_counts_masks, grid, dim3(256), lds, c->stream,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.nblk, d_mem, (int)G, d1, d0, h1, h0);
     HIPCHK(hipGetLastError());
@@ -1792,7 +1927,8 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
                "assignment holds an id that is not in ids");
         offs[pos[a] + 1]++;
     }
-    if (K <= c->tun.mask_counts_max) {
+    if (K <= c->tun.mask_counts_max
+        && (size_t)c->views[0].nblk * CM_SEG * 8 <= 56 * 1024) {
         // few clusters: popcounts over the lane masks of the identity view
         const int64_t *pp = pos.data();
         int rc = counts_from_masks(c, 0,
@@ -1888,13 +2024,16 @@ extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
 {
     ARGCHK(c && ms_per_launch, "NULL argument");
     ARGCHK(reps >= 1, "reps must be positive");
-    ARGCHK(c->last_kw > 0, "no previous bnpc_ll_theta / bnpc_ll_tables call");
+    ARGCHK(c->last_kw != 0, "no previous bnpc_ll_theta / bnpc_ll_tables call");
     HIPCHK(hipSetDevice(c->device));
     const View &v = c->views[c->last_view];
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; r++) {
         int rc;
         double *o = c->last_out;
+        if (c->last_kw == -1)
+            rc = issue_seq(c, v, c->last_K, c->last_ldo, o);
+        else
         switch (c->last_kw) {
         case 8: rc = issue_ll<8>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;
         case 4: rc = issue_ll<4>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;

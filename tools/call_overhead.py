@@ -39,5 +39,17 @@ t('ll_total 1 trial', lambda: ctx.ll_total(theta, [.01], [.2]))
 t('ll_total 2 trials', lambda: ctx.ll_total(theta, [.01, .02], [.2, .2]))
 t('view_set 500 cells', lambda: ctx.view_set(1, cells))
 t('ll_theta view 500 x 2', lambda: ctx.ll_theta(1, theta[:2], .01, .2))
+t64 = theta[:2].astype(np.float64)
+L1, L0 = np.log(t64 * .8 + (1 - t64) * .01), np.log(t64 * .2 + (1 - t64) * .99)
+t('ll_tables view 500 x 2 (bit-exact)', lambda: ctx.ll_tables(1, L1, L0))
+t('ll_tables N x 1 (bit-exact)', lambda: ctx.ll_tables(0, L1[:1], L0[:1]))
+lab = rng.randint(0, 2, 500)
+t('view_counts 500 cells, 2 segments', lambda: ctx.view_counts(1, lab, 2))
+ctx.ll_tables(1, L1, L0)
+t('  kernel only: k_ll_seq 500 x 2', lambda: ctx.bench_ll(20), reps=20)
+ctx.ll_theta(1, theta[:2], .01, .2)
+t('  kernels only: ll_theta 500 x 2', lambda: ctx.bench_ll(20), reps=20)
+ctx.ll_theta(0, theta, .01, .2)
+t('  kernels only: ll_theta N x 12', lambda: ctx.bench_ll(20), reps=20)
 t('sync only', ctx.sync)
 ctx.close()

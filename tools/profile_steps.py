@@ -57,5 +57,7 @@ for n, (t, c) in acc.items():
     if c:
         print(f'  {n:34s} calls {c:4d}  total {1e3 * t:8.1f} ms  '
             f'per call {1e3 * t / c:7.2f} ms  per step {1e3 * t / steps:6.2f}')
+if len(sys.argv) > 3:
+    pr.dump_stats(sys.argv[3])
 st = pstats.Stats(pr)
 st.sort_stats('tottime').print_stats(28)
