@@ -18,6 +18,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -177,6 +178,11 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         return 2;
     }
 
+    static const int64_t ahead_by = [] {
+        const char *e = getenv("BNPC_SWEEP_PREFETCH");
+        const long v = e ? atol(e) : 8;
+        return (int64_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
     for (int64_t c = 0; c < st->n_cols && c < ld; c++) {
         const int64_t sz = col_size[c];
         cpr[c] = (sz >= 0 && sz <= N + 1) ? crp_prior[sz] : 0.0;
@@ -186,15 +192,17 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
         // per-cell scalars) of a cell a few positions ahead into the cache
-        if (st->pos + 6 < st->pos_end) {
-            const int64_t ahead = perm[st->pos + 6];
+        if (st->pos + ahead_by < st->pos_end) {
+            const int64_t ahead = perm[st->pos + ahead_by];
             if (ahead >= 0 && ahead < N) {
                 const char *r = (const char *)(ll + (size_t)(
-                    st->row_base >= 0 ? st->pos + 6 - st->row_base : ahead)
-                    * ld);
+                    st->row_base >= 0 ? st->pos + ahead_by - st->row_base
+                                      : ahead) * ld);
                 const size_t bytes = (size_t)st->n_cols * sizeof(double);
-                for (size_t off = 0; off < bytes && off < 512; off += 64)
-                    __builtin_prefetch(r + off, 0, 1);
+                const char *end = r + (bytes < 512 ? bytes : 512);
+                for (const char *q = (const char *)((uintptr_t)r & ~(uintptr_t)63);
+                     q < end; q += 64)
+                    __builtin_prefetch(q, 0, 1);
                 __builtin_prefetch(&assignment[ahead], 1, 1);
                 __builtin_prefetch(&post_new[ahead], 0, 1);
             }

@@ -45,11 +45,20 @@ t('ll_tables view 500 x 2 (bit-exact)', lambda: ctx.ll_tables(1, L1, L0))
 t('ll_tables N x 1 (bit-exact)', lambda: ctx.ll_tables(0, L1[:1], L0[:1]))
 lab = rng.randint(0, 2, 500)
 t('view_counts 500 cells, 2 segments', lambda: ctx.view_counts(1, lab, 2))
+def kern(name):
+    ctx.bench_ll(5)
+    print(f'  device time, HIP events: {name:24s} '
+        f'{1e3 * min(ctx.bench_ll(20) for _ in range(5)):8.1f} us',
+        flush=True)
+
+
 ctx.ll_tables(1, L1, L0)
-t('  kernel only: k_ll_seq 500 x 2', lambda: ctx.bench_ll(20), reps=20)
+kern('k_ll_seq 500 x 2')
+ctx.ll_tables(0, L1[:1], L0[:1])
+kern('k_ll_seq N x 1')
 ctx.ll_theta(1, theta[:2], .01, .2)
-t('  kernels only: ll_theta 500 x 2', lambda: ctx.bench_ll(20), reps=20)
+kern('ll_theta 500 x 2')
 ctx.ll_theta(0, theta, .01, .2)
-t('  kernels only: ll_theta N x 12', lambda: ctx.bench_ll(20), reps=20)
+kern('ll_theta N x 12')
 t('sync only', ctx.sync)
 ctx.close()
