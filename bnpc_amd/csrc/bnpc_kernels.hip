@@ -1042,6 +1042,13 @@ extern "C" int bnpc_device_info(int device, char *name, int len, int *cus)
     return 0;
 }
 
+extern "C" int bnpc_device_pci_bus_id(int device, char *bus_id, int len)
+{
+    ARGCHK(bus_id && len >= 16, "bus_id buffer too small");
+    HIPCHK(hipDeviceGetPCIBusId(bus_id, len, device));
+    return 0;
+}
+
 static int build_view(bnpc_ctx *c, int view, const long long *d_cells,
                       int64_t n)
 {

@@ -140,12 +140,12 @@ extern "C" int bnpc_dominated_cdf(int64_t A, int64_t top, double *cdf)
 
 // -39 - log(A + 1): below this gap to the runner-up the tail sum of A
 // exponentials cannot reach 2^-55 (see the dominated case below)
-static double dominated_bound(int64_t A)
+static const double *dominated_bounds(int64_t A)
 {
     static thread_local std::vector<double> bound;
     while ((int64_t)bound.size() <= A)
         bound.push_back(-39.0 - log((double)(bound.size() + 1)));
-    return bound[A];
+    return bound.data();
 }
 
 extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
@@ -178,9 +178,13 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         return 2;
     }
 
+    // both tables are thread-local and grow on demand: fetched once, for the
+    // largest cluster count this call can see (at most ld live columns)
+    const double *fs = floor_sums(ld + 1);
+    const double *dom_bound = dominated_bounds(ld + 1);
     static const int64_t ahead_by = [] {
         const char *e = getenv("BNPC_SWEEP_PREFETCH");
-        const long v = e ? atol(e) : 8;
+        const long v = e ? atol(e) : 16;
         return (int64_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     for (int64_t c = 0; c < st->n_cols && c < ld; c++) {
@@ -282,7 +286,7 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // _normalize_log_probs (CRP.py:88-100) + choice(p=): cdf = cumsum(p);
         // cdf /= cdf[-1]; searchsorted(u, right).
         const double ptop = best;
-        const double u_dominated = dominated_bound(A);
+        const double u_dominated = dom_bound[A];
         int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
         if (FLOOR_STEP > 0 && second - ptop < u_dominated) {
             // One cluster dominates: the tail sum of exponentials is below
@@ -295,7 +299,6 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // walking them: `top` copies of the floor added one by one
             // (floor_sums), then + 1.0, then every further floor moves the
             // sum, which now lies in [1, 2), by exactly FLOOR_STEP ulps.
-            const double *fs = floor_sums(top);
             const double at_top = fs[top] + 1.0;
             auto cdf_at = [&](int64_t a) {
                 return a < top ? fs[a + 1]

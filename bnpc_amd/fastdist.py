@@ -234,6 +234,20 @@ def selfcheck():
             aa, bb = (0 - lo) / sc_, (1 - lo) / sc_
             ok &= bool(_tn_logpdf_public(x, aa, bb, lo, sc_)
                 == _tn_logpdf_direct(x, aa, bb, lo, sc_))
+        # a scalar draw (error-rate proposals, CRP_learning_errors.py:81-84):
+        # truncnorm.rvs with size=None = ppf of ONE uniform of the stream
+        for lo, sc_ in ((0.01, 0.005), (0.2, 0.15), (0.0007, 0.00075)):
+            aa, bb = (0 - lo) / sc_, (1 - lo) / sc_
+            state = np.random.get_state()
+            np.random.seed(4242)
+            ref = _truncnorm.rvs(aa, bb, loc=lo, scale=sc_)
+            after_ref = np.random.random()
+            np.random.seed(4242)
+            got = _tn_ppf_direct(np.random.uniform(), aa, bb, lo, sc_)
+            after_got = np.random.random()
+            np.random.set_state(state)
+            ok &= bool(ref == got) and after_ref == after_got \
+                and np.ndim(got) == 0
         for x, aa, lo in ((70.7, 70.71, 1), (3.2, 2.5, 0.5), (31.0, 31.6, 1)):
             ok &= bool(_gamma.logpdf(x, aa, loc=lo, scale=1)
                 == _gamma_logpdf_direct(x, aa, lo, 1))
@@ -262,6 +276,15 @@ def tn_rvs_from_uniform(U, a, b, loc, scale):
     if selfcheck():
         return _tn_ppf_direct(U, a, b, loc, scale)
     return _truncnorm._ppf(U, a, b) * scale + loc
+
+
+def tn_rvs_scalar(a, b, loc, scale):
+    """truncnorm.rvs(a, b, loc=loc, scale=scale) for scalar arguments: one
+    uniform from the global stream, then the ppf kernel - without the public
+    wrapper's argument machinery when the self-check allows."""
+    if selfcheck():
+        return np.float64(_tn_ppf_direct(np.random.uniform(), a, b, loc, scale))
+    return _truncnorm.rvs(a, b, loc=loc, scale=scale)
 
 
 def tn_logpdf(x, a, b, loc, scale):

@@ -1353,7 +1353,7 @@ class CRP_errors_learning(CRP):
         a = (0 - old) / std
         b = (1 - old) / std
         try:
-            new = truncnorm.rvs(a, b, loc=old, scale=std)
+            new = fastdist.tn_rvs_scalar(a, b, old, std)
         except FloatingPointError:
             new = truncnorm.rvs(a, np.inf, loc=old, scale=std)
 

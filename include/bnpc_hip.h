@@ -50,6 +50,11 @@ int bnpc_device_count(int *count);
 /* name[len] receives the gfx arch name, *cus the CU count */
 int bnpc_device_info(int device, char *name, int len, int *cus);
 
+/* PCI address "dddd:bb:dd.f" of a device: the binding reads the device's NUMA
+ * node from sysfs with it and keeps the chain's host threads on that node
+ * (the sweep walks a matrix the GPU has just written to host memory there). */
+int bnpc_device_pci_bus_id(int device, char *bus_id, int len);
+
 /* ---- context: data of one chain ------------------------------------------
  * Replaces the float64 N x M `self.data` (NaN = missing) of libs/CRP.py:30-31
  * by two bit planes resident in HBM.  data_nan holds 0 | 1 | NaN. */

@@ -270,3 +270,39 @@ def test_single_rank_bench_harness_needs_no_torch():
         text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().endswith('ok True')
+
+
+def test_host_threads_are_kept_on_the_devices_numa_node(monkeypatch, tmp_path):
+    """bind_near_device: PCI address -> numa_node -> cpulist -> affinity."""
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 2:
+        pytest.skip('needs two CPUs')
+    pci = tmp_path / 'pci' / '0000:0d:00.0'
+    pci.mkdir(parents=True)
+    (pci / 'numa_node').write_text('1\n')
+    half = have[:len(have) // 2]
+    for node, cpus in ((0, have[len(have) // 2:]), (1, half)):
+        d = tmp_path / 'node' / f'node{node}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(','.join(str(c) for c in cpus) + '\n')
+
+    class Lib:
+        @staticmethod
+        def bnpc_device_pci_bus_id(device, buf, n):
+            buf.value = b'0000:0D:00.0'
+            return 0
+    monkeypatch.setattr(_lib, 'load', lambda: Lib)
+    try:
+        monkeypatch.setenv('BNPC_NUMA_BIND', '0')
+        assert _lib.bind_near_device(0, str(tmp_path / 'pci'),
+            str(tmp_path / 'node')) is None
+        assert sorted(os.sched_getaffinity(0)) == have
+        monkeypatch.setenv('BNPC_NUMA_BIND', '1')
+        assert _lib.bind_near_device(0, str(tmp_path / 'pci'),
+            str(tmp_path / 'node')) == 1
+        assert sorted(os.sched_getaffinity(0)) == half
+        # no sysfs entry for the device: nothing changes
+        assert _lib.bind_near_device(0, str(tmp_path / 'nope'),
+            str(tmp_path / 'node')) is None
+    finally:
+        os.sched_setaffinity(0, have)
