@@ -15,10 +15,11 @@ MAX_VIEWS = 5
 MAX_TRIALS = 4
 
 _i64 = C.c_int64
-_pd = C.POINTER(C.c_double)
-_pf = C.POINTER(C.c_float)
-_pi64 = C.POINTER(C.c_int64)
-_pi32 = C.POINTER(C.c_int32)
+# array arguments travel as plain addresses (building a typed ctypes pointer
+# per argument costs more than some of the calls)
+_pd = _pf = _pi64 = _pi32 = C.c_void_p
+_host_pd = C.POINTER(C.c_double)            # double* results (pinned buffers)
+_ppd = C.POINTER(_host_pd)
 _ctx = C.c_void_p
 
 
@@ -57,7 +58,7 @@ SIGNATURES = {
     'bnpc_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'bnpc_create': (C.c_int, [C.c_int, _i64, _i64, _pd, C.POINTER(_ctx)]),
     'bnpc_create_codes': (C.c_int, [C.c_int, _i64, _i64,
-        C.POINTER(C.c_int8), C.POINTER(_ctx)]),
+        C.c_void_p, C.POINTER(_ctx)]),
     'bnpc_destroy': (C.c_int, [_ctx]),
     'bnpc_reload_options': (C.c_int, [_ctx]),
     'bnpc_shape': (C.c_int, [_ctx, _pi64, _pi64]),
@@ -67,13 +68,13 @@ SIGNATURES = {
     'bnpc_ll_theta': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
         C.c_double, _pd, _i64]),
     'bnpc_ll_theta_pinned': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
-        C.c_double, _i64, C.POINTER(_pd)]),
+        C.c_double, _i64, _ppd]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
-        C.c_double, _i64, C.POINTER(_pd)]),
+        C.c_double, _i64, _ppd]),
     'bnpc_ll_rows_issue': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, C.c_int]),
-    'bnpc_ll_rows_wait': (C.c_int, [_ctx, C.c_int, C.POINTER(_pd)]),
+    'bnpc_ll_rows_wait': (C.c_int, [_ctx, C.c_int, _ppd]),
     'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
     'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
     'bnpc_view_counts': (C.c_int, [_ctx, C.c_int, _pi64, _i64, _pi32, _pi32]),
@@ -98,7 +99,7 @@ SIGNATURES = {
     'bnpc_gibbs_sweep': (C.c_int, [C.POINTER(GibbsState), C.POINTER(MT19937),
         _pi64, _pd, _pd, _pd, _pi64, _pi64, _pi64, _pi64, _pi64, _pd]),
     'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,
-        C.POINTER(C.c_int8), _pi64, _pi64]),
+        C.c_void_p, _pi64, _pi64]),
     'bnpc_codist': (C.c_int, [C.c_int, _pi32, _i64, _i64, _pi32]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
@@ -135,8 +136,9 @@ def check(rc, what=''):
         raise RuntimeError(f'libbnpc_hip {what} failed (code {rc}): {msg}')
 
 
-def ptr(arr, ctype):
-    return arr.ctypes.data_as(C.POINTER(ctype))
+def ptr(arr, ctype=None):
+    """Address of a C-contiguous array (the ctype is documentation)."""
+    return arr.ctypes.data
 
 
 def as_i64(a):
@@ -485,7 +487,7 @@ class Context:
         theta = np.ascontiguousarray(theta, dtype=np.float32)
         K = theta.shape[0]
         n = self.view_size(view)
-        host = _pd()
+        host = _host_pd()
         check(self._lib.bnpc_ll_theta_pinned(self._h, view,
             ptr(theta, C.c_float), K, float(FP), float(FN), ld,
             C.byref(host)), 'll_theta_pinned')
@@ -507,7 +509,7 @@ class Context:
         resident store (rows = cluster ids)."""
         rows = as_i64(rows)
         n = self.view_size(view)
-        host = _pd()
+        host = _host_pd()
         check(self._lib.bnpc_ll_rows_pinned(self._h, view,
             ptr(rows, C.c_int64), rows.size, float(FP), float(FN), ld,
             C.byref(host)), 'll_rows_pinned')
@@ -524,7 +526,7 @@ class Context:
 
     def ll_rows_wait(self, slot, n_rows, ld):
         """The (n_rows, ld) result of the tile issued on `slot`."""
-        host = _pd()
+        host = _host_pd()
         check(self._lib.bnpc_ll_rows_wait(self._h, slot, C.byref(host)),
             'll_rows_wait')
         return np.ctypeslib.as_array(host, shape=(n_rows, ld))

@@ -624,6 +624,60 @@ def test_full_size_properties_50000x5000():
     ctx.close()
 
 
+def test_config5_moves_chain_matches_oracle():
+    """Config 5's move schedule (-smp 0.5 -sms 5, learned error rates) at a
+    size the CPU oracle walks in seconds (2000 x 500, 20 % missing): 40 steps
+    from the random start - ~20 split/merge moves with 5 restricted scans
+    each - with identical assignments and traces to 1e-9."""
+    data = H.synth(5, 2000, 500, 12, 0.20)
+    kw = dict(sm_prob=.5, sm_steps=5, eup=.25)
+    ro = H.run_chain(H.make(O, 'learn', data), 40, 42, **kw)
+    rp = H.run_chain(H.make(P, 'learn', data), 40, 42, **kw)
+    assert np.array_equal(ro['assignments'], rp['assignments'])
+    for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
+        np.testing.assert_allclose(rp[key], ro[key], rtol=1e-9)
+    assert np.array_equal(ro['params'], rp['params'])
+
+
+def test_first_sweep_at_config5_size_does_not_depend_on_the_tiling(
+        monkeypatch):
+    """The first sweep of config 5 at FULL size (50000 x 5000 from K0 ~ 31600
+    clusters: a 12.6 GB matrix, never materialised) with the real 64 MiB
+    tiles (~190 tiles of ~265 cells, side-lane columns for clusters reborn in
+    between) against the same sweep in 2 GiB tiles (6 tiles, other tile
+    boundaries, other launch shapes): same assignment, same clusters in the
+    same order, same parameter rows, same position of the random stream.
+    Oracle identity of the tiled sweep itself is shown at forced-small tiles
+    (test_tiled_sweep_on_device); this is its self-consistency at scale."""
+    import bench
+    import libs.CRP_learning_errors as dev
+    N, M, C_, miss, learned = bench.CONFIGS['c5']
+    data = H.synth(0, N, M, C_, miss)
+    outs = []
+    for tile_bytes in (None, 2 << 30):
+        if tile_bytes is None:
+            monkeypatch.delenv('BNPC_TILE_BYTES', raising=False)
+            monkeypatch.delenv('BNPC_SWEEP_BYTES', raising=False)
+        else:
+            monkeypatch.setenv('BNPC_TILE_BYTES', str(tile_bytes))
+            monkeypatch.setenv('BNPC_SWEEP_BYTES', str(tile_bytes))
+        np.random.seed(42)
+        m = bench.make_model(dev, dev, data, learned)
+        m.init()
+        K0 = len(m.cells_per_cluster)
+        assert 8 * N * K0 > (8 << 30)          # far beyond either budget
+        m.update_assignments_Gibbs()
+        ids = list(m.cells_per_cluster)
+        outs.append((m.assignment.copy(), list(m.cells_per_cluster.items()),
+            m.parameters[ids].copy(), np.random.random()))
+        m.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    assert a[1] == b[1] and a[3] == b[3]
+    assert np.array_equal(a[2], b[2])
+    assert len(a[1]) < 200                      # the sweep collapsed K0
+
+
 def test_pinned_result_buffer():
     rng = np.random.RandomState(4)
     data = (rng.random_sample((500, 90)) < 0.3).astype(float)
