@@ -30,7 +30,7 @@ class MT19937(C.Structure):
 class GibbsState(C.Structure):
     _fields_ = [('n_cells', _i64), ('ld', _i64), ('n_cols', _i64),
         ('n_active', _i64), ('pos', _i64), ('new_cell', _i64),
-        ('pos_end', _i64), ('row_base', _i64)]
+        ('pos_end', _i64), ('row_base', _i64), ('threads', _i64)]
 
 
 class MHArgs(C.Structure):

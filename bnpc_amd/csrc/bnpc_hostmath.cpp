@@ -146,6 +146,27 @@ Team *team_for(int threads)
     return g_team;
 }
 
+}  // namespace
+
+// ranks a team of `threads` would really have (the team is capped)
+int bnpc_team_ranks(int threads)
+{
+    if (threads > 255) threads = 255;
+    return threads < 1 ? 1 : threads;
+}
+
+void bnpc_team_run(int threads, const std::function<void(int)> &fn)
+{
+    threads = bnpc_team_ranks(threads);
+    if (threads <= 1) {
+        fn(0);
+        return;
+    }
+    team_for(threads)->run(threads, fn);
+}
+
+namespace {
+
 inline void uloop(bnpc_uloop f, void *data, const double *in, double *out,
                   intptr_t n)
 {

@@ -9,6 +9,15 @@
 
 void bnpc_set_error(const char *fmt, ...);
 
+#ifdef __cplusplus
+#include <functional>
+// fn(rank) for every rank 0..n-1, n = bnpc_team_ranks(threads), on this
+// process's host thread team (the caller is rank 0; the team grows to n if it
+// is smaller); returns when all ranks are done.
+int bnpc_team_ranks(int threads);
+void bnpc_team_run(int threads, const std::function<void(int)> &fn);
+#endif
+
 // ---------------------------------------------------------------------------
 // MT19937 (Matsumoto & Nishimura), state layout of np.random.get_state()
 // ---------------------------------------------------------------------------

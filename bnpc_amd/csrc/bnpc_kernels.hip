@@ -49,7 +49,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 1; }
+extern "C" int bnpc_abi_version(void) { return 2; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <vector>
 
 #include "bnpc_hip.h"
@@ -148,27 +149,123 @@ static const double *dominated_bounds(int64_t A)
     return bound.data();
 }
 
-extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
-                                const int64_t *perm, const double *ll,
-                                const double *post_new,
-                                const double *crp_prior, int64_t *assignment,
-                                int64_t *col_of_id, int64_t *col_id,
-                                int64_t *col_size, int64_t *order,
-                                double *scratch)
+// ---- the per-cell scan over many live clusters, on a team -------------------
+// In the first sweep of a large data set a cell is scored against tens of
+// thousands of clusters.  Rank 0 walks the cells (draws, state updates: the
+// sequential part, unchanged); for a cell with many live clusters it posts the
+// scan to the other ranks, which spin on a phase word for the duration of the
+// window: every rank scores a contiguous range of the live list and reports
+// (maximum, first position of it, runner-up); the ranges are combined in order,
+// so `top` is the first maximum and `second` the largest other entry exactly as
+// in the one-thread scan.  Exponentials of the non-dominated case are taken in
+// parallel, their SUMS stay sequential in index order (same bits).
+namespace {
+
+inline void spin_pause()
 {
-    if (!st || !rng || !perm || !ll || !post_new || !crp_prior ||
-        !assignment || !col_of_id || !col_id || !col_size || !order ||
-        !scratch) {
-        bnpc_set_error("bad argument: NULL");
-        return 2;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+
+struct ParScan {
+    enum { SCAN = 1, EXP_TAIL = 2, EXP_PROB = 3, EXIT = 4, MAXT = 64 };
+    int T = 1;
+    alignas(64) std::atomic<uint32_t> phase{0};
+    alignas(64) std::atomic<int> done{0};
+    int mode = 0;
+    const double *row = nullptr, *cpr = nullptr;
+    const int64_t *order = nullptr;
+    double *post = nullptr, *buf = nullptr;
+    int64_t A = 0, top = 0;
+    double ptop = 0.0, lnorm = 0.0;
+    struct alignas(64) Part {
+        double best, second;
+        int64_t top;
+    } part[MAXT];
+
+    void work(int rank)
+    {
+        const int64_t lo = A * rank / T, hi = A * (rank + 1) / T;
+        if (mode == SCAN) {
+            double best = -INFINITY, second = -INFINITY;
+            int64_t t = lo;
+            for (int64_t a = lo; a < hi; a++) {
+                const int64_t c = order[a];
+                const double v = row[c] + cpr[c];
+                post[a] = v;
+                if (v > best) {
+                    second = best;
+                    best = v;
+                    t = a;
+                } else if (v > second) {
+                    second = v;
+                }
+            }
+            part[rank].best = best;
+            part[rank].second = second;
+            part[rank].top = t;
+        } else if (mode == EXP_TAIL) {
+            // entries 0..A of post (the new-cluster entry included: ranges
+            // over A + 1 here)
+            const int64_t n = A + 1;
+            const int64_t l2 = n * rank / T, h2 = n * (rank + 1) / T;
+            for (int64_t a = l2; a < h2; a++) {
+                const double d = post[a] - ptop;
+                buf[a] = (a != top && d > -746.0) ? exp(d) : 0.0;
+            }
+        } else if (mode == EXP_PROB) {
+            const int64_t n = A + 1;
+            const int64_t l2 = n * rank / T, h2 = n * (rank + 1) / T;
+            for (int64_t a = l2; a < h2; a++) {
+                const double v = post[a] - ptop - lnorm;
+                buf[a] = (v <= LOG_EPS) ? EXP_LOG_EPS : exp(v > 0.0 ? 0.0 : v);
+            }
+        }
     }
+    // rank 0: run one phase on all ranks
+    void run(int m)
+    {
+        mode = m;
+        done.store(0, std::memory_order_relaxed);
+        phase.fetch_add(1, std::memory_order_release);
+        work(0);
+        while (done.load(std::memory_order_acquire) != T - 1) spin_pause();
+    }
+    void finish()
+    {
+        mode = EXIT;
+        phase.fetch_add(1, std::memory_order_release);
+    }
+    // ranks 1..T-1
+    void serve(int rank)
+    {
+        uint32_t seen = 0;
+        for (;;) {
+            uint32_t p;
+            while ((p = phase.load(std::memory_order_acquire)) == seen)
+                spin_pause();
+            seen = p;
+            if (mode == EXIT) return;
+            work(rank);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+};
+
+}  // namespace
+
+static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
+                        const int64_t *perm, const double *ll,
+                        const double *post_new, const double *crp_prior,
+                        int64_t *assignment, int64_t *col_of_id,
+                        int64_t *col_id, int64_t *col_size, int64_t *order,
+                        double *scratch, double *cpr, ParScan *par,
+                        int64_t par_min)
+{
     const int64_t N = st->n_cells, ld = st->ld;
     double *post = scratch;             // ld + 1
     double *cdf = scratch + ld + 1;     // ld + 1
-    // log prior of joining a column's cluster at its current size
-    static thread_local std::vector<double> cpr_store;
-    if ((int64_t)cpr_store.size() < ld) cpr_store.resize(ld);
-    double *cpr = cpr_store.data();
     st->new_cell = -1;
     if (st->pos_end > N || st->pos > st->pos_end ||
         (st->row_base >= 0 && st->row_base > st->pos)) {
@@ -225,8 +322,19 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             return 3;
         }
         if (col_size[old_col] == 1) {
-            int64_t a = 0;
-            while (a < st->n_active && order[a] != old_col) a++;
+            // the live list is ascending in column index (columns are handed
+            // out in increasing order and deletions keep the order): bisect,
+            // and fall back to a walk should that ever not hold
+            int64_t a = 0, b = st->n_active;
+            while (a < b) {
+                const int64_t mid = (a + b) >> 1;
+                if (order[mid] < old_col) a = mid + 1;
+                else b = mid;
+            }
+            if (a >= st->n_active || order[a] != old_col) {
+                a = 0;
+                while (a < st->n_active && order[a] != old_col) a++;
+            }
             memmove(order + a, order + a + 1,
                     (size_t)(st->n_active - a - 1) * sizeof(int64_t));
             st->n_active--;
@@ -244,7 +352,21 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         int64_t top = 0;                    // first maximum
         double best = -INFINITY;
         double second = -INFINITY;          // largest entry that is not `top`
-        if (A <= 64) {
+        if (par && A >= par_min) {
+            par->row = row;
+            par->A = A;
+            par->run(ParScan::SCAN);
+            for (int r = 0; r < par->T; r++) {
+                const ParScan::Part &q = par->part[r];
+                if (q.best > best) {
+                    second = best > q.second ? best : q.second;
+                    best = q.best;
+                    top = q.top;
+                } else if (q.best > second) {
+                    second = q.best;
+                }
+            }
+        } else if (A <= 64) {
             // few clusters (the converged regime): where the maximum sits is
             // data, so selects instead of branches
             for (int64_t a = 0; a < A; a++) {
@@ -324,17 +446,32 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // every entry clipped at log(1e-15) contributes exp(LOG_EPS).
             double run = 0.0;
             double tail = 0.0;
-            for (int64_t a = 0; a <= A; a++) {
-                if (a == top) continue;
-                const double d = post[a] - ptop;
-                if (d > -746.0) tail += exp(d);
-            }
-            const double lnorm = log1p(tail);
-            for (int64_t a = 0; a <= A; a++) {
-                const double v = post[a] - ptop - lnorm;
-                if (v <= LOG_EPS) run += EXP_LOG_EPS;
-                else run += exp(v > 0.0 ? 0.0 : v);
-                cdf[a] = run;
+            if (par && A >= par_min) {
+                // the exponentials on the team, the sums here in index order
+                par->top = top;
+                par->ptop = ptop;
+                par->run(ParScan::EXP_TAIL);
+                for (int64_t a = 0; a <= A; a++) tail += cdf[a];
+                const double lnorm = log1p(tail);
+                par->lnorm = lnorm;
+                par->run(ParScan::EXP_PROB);
+                for (int64_t a = 0; a <= A; a++) {
+                    run += cdf[a];
+                    cdf[a] = run;
+                }
+            } else {
+                for (int64_t a = 0; a <= A; a++) {
+                    if (a == top) continue;
+                    const double d = post[a] - ptop;
+                    if (d > -746.0) tail += exp(d);
+                }
+                const double lnorm = log1p(tail);
+                for (int64_t a = 0; a <= A; a++) {
+                    const double v = post[a] - ptop - lnorm;
+                    if (v <= LOG_EPS) run += EXP_LOG_EPS;
+                    else run += exp(v > 0.0 ? 0.0 : v);
+                    cdf[a] = run;
+                }
             }
             const double total = cdf[A];
             const double u = mt_double(rng);
@@ -358,6 +495,58 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         cpr[c] = crp_prior[col_size[c]];
     }
     return 0;
+}
+
+extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
+                                const int64_t *perm, const double *ll,
+                                const double *post_new,
+                                const double *crp_prior, int64_t *assignment,
+                                int64_t *col_of_id, int64_t *col_id,
+                                int64_t *col_size, int64_t *order,
+                                double *scratch)
+{
+    if (!st || !rng || !perm || !ll || !post_new || !crp_prior ||
+        !assignment || !col_of_id || !col_id || !col_size || !order ||
+        !scratch) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    // log prior of joining a column's cluster at its current size
+    static thread_local std::vector<double> cpr_store;
+    if ((int64_t)cpr_store.size() < st->ld) cpr_store.resize(st->ld);
+    double *cpr = cpr_store.data();
+
+    // live clusters from which the scan of a cell goes to the team (read per
+    // window, not per cell: the tests lower it)
+    const char *pm = getenv("BNPC_SWEEP_PAR_MIN");
+    int64_t par_min = pm ? atol(pm) : 2048;
+    if (par_min < 2) par_min = 2;
+    int T = (int)st->threads;
+    if (T > ParScan::MAXT) T = ParScan::MAXT;
+    if (T < 2 || st->n_active < par_min)
+        return sweep_window(st, rng, perm, ll, post_new, crp_prior,
+                            assignment, col_of_id, col_id, col_size, order,
+                            scratch, cpr, nullptr, par_min);
+
+    ParScan par;
+    par.T = T;
+    par.cpr = cpr;
+    par.order = order;
+    par.post = scratch;
+    par.buf = scratch + st->ld + 1;
+    int rc = 0;
+    // the error text is thread-local: rank 0 is the calling thread
+    bnpc_team_run(T, [&](int rank) {
+        if (rank == 0) {
+            rc = sweep_window(st, rng, perm, ll, post_new, crp_prior,
+                              assignment, col_of_id, col_id, col_size, order,
+                              scratch, cpr, &par, par_min);
+            par.finish();
+        } else {
+            par.serve(rank);
+        }
+    });
+    return rc;
 }
 
 // ---------------------------------------------------------------------------

@@ -639,7 +639,7 @@ class CRP:
         scratch = np.empty(2 * (ld + 1), dtype=np.float64)
 
         st = _lib.GibbsState(N, ld, n_cols, K, pos, -1, pos_end,
-            -1 if whole else pos)
+            -1 if whole else pos, _lib.host_threads())
         i64, f64 = C.c_int64, C.c_double
         born = []
         while True:

@@ -339,6 +339,9 @@ typedef struct bnpc_gibbs_state {
     int64_t row_base;   /* -1: row of ll = cell id (whole matrix resident);
                            >= 0: row of ll = position in perm - row_base (the
                            matrix of one permutation-ordered tile of cells) */
+    int64_t threads;    /* host threads for the scan of a cell over thousands
+                           of live clusters (first sweeps); <= 1: none.  The
+                           result does not depend on it. */
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

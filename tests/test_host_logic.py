@@ -610,3 +610,34 @@ def test_failed_tiled_sweep_leaves_no_tile_behind(monkeypatch):
     np.random.seed(2)
     p.update_assignments_Gibbs()
     assert not p._ctx.tiles and p._ctx.calls['ll_rows_issue'] >= 4
+
+
+@pytest.mark.parametrize('tiled', [False, True])
+def test_team_scan_of_many_clusters_changes_nothing(tiled, monkeypatch):
+    """The scan of a cell over many live clusters on the host thread team
+    (first sweeps; bnpc_gibbs_sweep with threads > 1): same sweeps as the
+    oracle, whole-matrix and tiled, dominated and non-dominated cells, with
+    the team threshold lowered so that a small case reaches it."""
+    monkeypatch.setenv('BNPC_SWEEP_PAR_MIN', '6')
+    monkeypatch.setenv('BNPC_HOST_THREADS', '5')
+    if tiled:
+        monkeypatch.setenv('BNPC_SWEEP_BYTES', '40000')
+    # few mutations: neighbouring clusters are close, many cells take the
+    # full normalisation; many mutations: one cluster dominates
+    for M, seed in ((6, 3), (70, 4)):
+        data = synth(seed, 220, M, 4, 0.15)
+        o = make(O, 'fixed', data)
+        p = make(P, 'fixed', data)
+        for m in (o, p):
+            np.random.seed(21)
+            m.init()
+        assert len(p.cells_per_cluster) > 100
+        for sweep in range(2):
+            for m in (o, p):
+                np.random.seed(300 + sweep)
+                m.update_assignments_Gibbs()
+                m._tail = np.random.random(2)
+            assert np.array_equal(o.assignment, p.assignment), (M, sweep)
+            assert list(o.cells_per_cluster.items()) == \
+                list(p.cells_per_cluster.items())
+            assert np.array_equal(o._tail, p._tail)
