@@ -59,6 +59,12 @@ SIGNATURES = {
     'bnpc_create': (C.c_int, [C.c_int, _i64, _i64, _pd, C.POINTER(_ctx)]),
     'bnpc_create_codes': (C.c_int, [C.c_int, _i64, _i64,
         C.c_void_p, C.POINTER(_ctx)]),
+    'bnpc_create_planes': (C.c_int, [C.c_int, _i64, _i64, C.c_void_p,
+        C.POINTER(_ctx)]),
+    'bnpc_pack_codes': (C.c_int, [C.c_void_p, _i64, _i64, _i64, _i64,
+        C.c_void_p]),
+    'bnpc_unpack_codes': (C.c_int, [C.c_void_p, _i64, _i64, C.c_void_p, _i64,
+        C.c_void_p]),
     'bnpc_destroy': (C.c_int, [_ctx]),
     'bnpc_reload_options': (C.c_int, [_ctx]),
     'bnpc_shape': (C.c_int, [_ctx, _pi64, _pi64]),
@@ -407,7 +413,14 @@ class Context:
         lib = load()
         mark_gpu_touched()
         handle = _ctx()
-        if codes is not None:
+        planes = getattr(data, 'planes', None)
+        if planes is not None:      # bnpc_amd.bitplanes.BitPlanes
+            N, M = data.shape
+            self._keep = planes = np.ascontiguousarray(planes, dtype='<u8')
+            check(lib.bnpc_create_planes(device, N, M, planes.ctypes.data,
+                C.byref(handle)), 'create_planes')
+            del self._keep
+        elif codes is not None:
             codes = np.ascontiguousarray(codes, dtype=np.int8)
             N, M = codes.shape
             check(lib.bnpc_create_codes(device, N, M, ptr(codes, C.c_int8),

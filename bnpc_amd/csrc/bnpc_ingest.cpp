@@ -140,3 +140,98 @@ extern "C" int bnpc_parse_matrix(const char *path, char sep, int skip_rows,
     *cols = width;
     return 0;
 }
+
+// ---- bit planes <-> codes (host) -------------------------------------------
+// The packed form of the data matrix, on disk (bnpc_amd/bitplanes.py) and in
+// HBM alike: per cell W = ceil(M / 64) pairs of 64-bit words {ones, zeros},
+// bit b of word w = mutation 64 w + b; an entry with neither bit is missing.
+extern "C" int bnpc_pack_codes(const int8_t *codes, int64_t N, int64_t M,
+                               int64_t row_stride, int64_t col_stride,
+                               uint64_t *planes)
+{
+    if (!codes || !planes || N < 0 || M < 1) {
+        bnpc_set_error("bad argument: pack_codes");
+        return 2;
+    }
+    const int64_t W = (M + 63) / 64;
+    if (row_stride == 1 && col_stride != 1) {
+        // a transposed view (the file is mutations x cells): walk it in
+        // 64 x 64 tiles along ITS rows, so that every cache line of the
+        // source is used whole
+        for (int64_t i0 = 0; i0 < N; i0 += 64) {
+            const int64_t ni = i0 + 64 < N ? 64 : N - i0;
+            for (int64_t w = 0; w < W; w++) {
+                uint64_t o[64] = {0}, z[64] = {0};
+                const int64_t m0 = w * 64, m1 = m0 + 64 < M ? m0 + 64 : M;
+                for (int64_t m = m0; m < m1; m++) {
+                    const int8_t *src = codes + m * col_stride + i0;
+                    const uint64_t bit = 1ull << (m - m0);
+                    for (int64_t j = 0; j < ni; j++) {
+                        const int v = src[j];
+                        if (v == 1 || v == 2) o[j] |= bit;
+                        else if (v == 0) z[j] |= bit;
+                        else if (v != 3) {
+                            bnpc_set_error(
+                                "codes[%lld,%lld] = %d is not 0|1|2|3",
+                                (long long)(i0 + j), (long long)m, v);
+                            return 2;
+                        }
+                    }
+                }
+                for (int64_t j = 0; j < ni; j++) {
+                    uint64_t *out = planes + ((size_t)(i0 + j) * W + w) * 2;
+                    out[0] = o[j];
+                    out[1] = z[j];
+                }
+            }
+        }
+        return 0;
+    }
+    for (int64_t i = 0; i < N; i++) {
+        const int8_t *row = codes + i * row_stride;
+        uint64_t *out = planes + (size_t)i * W * 2;
+        for (int64_t w = 0; w < W; w++) {
+            uint64_t o = 0, z = 0;
+            const int64_t m0 = w * 64, m1 = m0 + 64 < M ? m0 + 64 : M;
+            for (int64_t m = m0; m < m1; m++) {
+                const int v = row[m * col_stride];
+                if (v == 1 || v == 2) o |= 1ull << (m - m0);    // 2 -> 1
+                else if (v == 0) z |= 1ull << (m - m0);
+                else if (v != 3) {
+                    bnpc_set_error("codes[%lld,%lld] = %d is not 0|1|2|3",
+                                   (long long)i, (long long)m, v);
+                    return 2;
+                }
+            }
+            out[2 * w] = o;
+            out[2 * w + 1] = z;
+        }
+    }
+    return 0;
+}
+
+// rows `cells[0..n)` of the planes as int8 codes 0 | 1 | 3 (n x M)
+extern "C" int bnpc_unpack_codes(const uint64_t *planes, int64_t N, int64_t M,
+                                 const int64_t *cells, int64_t n, int8_t *codes)
+{
+    if (!planes || !codes || (n > 0 && !cells && n != N)) {
+        bnpc_set_error("bad argument: unpack_codes");
+        return 2;
+    }
+    const int64_t W = (M + 63) / 64;
+    for (int64_t r = 0; r < n; r++) {
+        const int64_t i = cells ? cells[r] : r;
+        if (i < 0 || i >= N) {
+            bnpc_set_error("cell index out of range");
+            return 2;
+        }
+        const uint64_t *in = planes + (size_t)i * W * 2;
+        int8_t *out = codes + (size_t)r * M;
+        for (int64_t m = 0; m < M; m++) {
+            const uint64_t bit = 1ull << (m & 63);
+            const uint64_t o = in[2 * (m >> 6)], z = in[2 * (m >> 6) + 1];
+            out[m] = (o & bit) ? 1 : ((z & bit) ? 0 : 3);
+        }
+    }
+    return 0;
+}

@@ -1067,14 +1067,11 @@ static int build_view(bnpc_ctx *c, int view, const long long *d_cells,
     return 0;
 }
 
-template <typename GetCode>
-static int create_impl(int device, int64_t N, int64_t M, GetCode code,
-                       bnpc_ctx **out)
+// Context from ready bit planes: rows[N][W] of {ones, zeros} words (bits past
+// M clear, no bit set in both planes - checked).
+static int create_from_planes(int device, int64_t N, int64_t M,
+                              const ulonglong2 *rows, bnpc_ctx **out)
 {
-    ARGCHK(out, "out is NULL");
-    ARGCHK(N > 0 && M > 0, "N and M must be positive");
-    ARGCHK(M < (1ll << 30) && N < (1ll << 40), "matrix too large");
-    *out = nullptr;
     HIPCHK(hipSetDevice(device));
     bnpc_ctx *c = new bnpc_ctx();
     read_tunables(c->tun);
@@ -1084,31 +1081,24 @@ static int create_impl(int device, int64_t N, int64_t M, GetCode code,
     c->W = (int)((M + 63) / 64);
     c->Mpad = c->W * 64;
     c->Mt = (int)((M + 7) / 8 * 8);
-
-    // pack on the host: 2 bits per entry
-    std::vector<ulonglong2> rows((size_t)N * c->W);
     c->cell_n1.assign(N, 0);
     c->cell_n0.assign(N, 0);
+    const int tail_bits = (int)(M - (int64_t)(c->W - 1) * 64);  // 1..64
+    const unsigned long long tail_mask =
+        tail_bits == 64 ? ~0ull : ((1ull << tail_bits) - 1);
     for (int64_t i = 0; i < N; i++) {
         int32_t s1 = 0, s0 = 0;
+        const ulonglong2 *r = rows + (size_t)i * c->W;
         for (int w = 0; w < c->W; w++) {
-            unsigned long long o = 0, z = 0;
-            const int64_t m0 = (int64_t)w * 64;
-            const int64_t m1 = std::min<int64_t>(M, m0 + 64);
-            for (int64_t m = m0; m < m1; m++) {
-                const int v = code(i, m);
-                if (v == 1) o |= 1ull << (m - m0);
-                else if (v == 0) z |= 1ull << (m - m0);
-                else if (v != 3) {
-                    delete c;
-                    bnpc_set_error("data[%lld,%lld] is not 0, 1 or missing",
-                                   (long long)i, (long long)m);
-                    return 2;
-                }
+            const unsigned long long ok = (w == c->W - 1) ? tail_mask : ~0ull;
+            if ((r[w].x & r[w].y) || ((r[w].x | r[w].y) & ~ok)) {
+                delete c;
+                bnpc_set_error("bit planes of row %lld are inconsistent",
+                               (long long)i);
+                return 2;
             }
-            rows[(size_t)i * c->W + w] = make_ulonglong2(o, z);
-            s1 += __builtin_popcountll(o);
-            s0 += __builtin_popcountll(z);
+            s1 += __builtin_popcountll(r[w].x);
+            s0 += __builtin_popcountll(r[w].y);
         }
         c->cell_n1[i] = s1;
         c->cell_n0[i] = s0;
@@ -1123,13 +1113,13 @@ static int create_impl(int device, int64_t N, int64_t M, GetCode code,
             return 1;                                                        \
         }                                                                    \
     } while (0)
+    const size_t bytes = (size_t)N * c->W * sizeof(ulonglong2);
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRCHK(hipEventCreate(&c->ev0));
     CRCHK(hipEventCreate(&c->ev1));
-    CRCHK(hipMalloc((void **)&c->rows, rows.size() * sizeof(ulonglong2)));
-    CRCHK(hipMemcpyAsync(c->rows, rows.data(),
-                         rows.size() * sizeof(ulonglong2),
-                         hipMemcpyHostToDevice, c->stream));
+    CRCHK(hipMalloc((void **)&c->rows, bytes));
+    CRCHK(hipMemcpyAsync(c->rows, rows, bytes, hipMemcpyHostToDevice,
+                         c->stream));
     if (build_view(c, 0, nullptr, N)) {
         bnpc_destroy(c);
         return 1;
@@ -1138,6 +1128,48 @@ static int create_impl(int device, int64_t N, int64_t M, GetCode code,
 #undef CRCHK
     *out = c;
     return 0;
+}
+
+template <typename GetCode>
+static int create_impl(int device, int64_t N, int64_t M, GetCode code,
+                       bnpc_ctx **out)
+{
+    ARGCHK(out, "out is NULL");
+    ARGCHK(N > 0 && M > 0, "N and M must be positive");
+    ARGCHK(M < (1ll << 30) && N < (1ll << 40), "matrix too large");
+    *out = nullptr;
+    const int W = (int)((M + 63) / 64);
+    // pack on the host: 2 bits per entry
+    std::vector<ulonglong2> rows((size_t)N * W);
+    for (int64_t i = 0; i < N; i++) {
+        for (int w = 0; w < W; w++) {
+            unsigned long long o = 0, z = 0;
+            const int64_t m0 = (int64_t)w * 64;
+            const int64_t m1 = std::min<int64_t>(M, m0 + 64);
+            for (int64_t m = m0; m < m1; m++) {
+                const int v = code(i, m);
+                if (v == 1) o |= 1ull << (m - m0);
+                else if (v == 0) z |= 1ull << (m - m0);
+                else if (v != 3) {
+                    bnpc_set_error("data[%lld,%lld] is not 0, 1 or missing",
+                                   (long long)i, (long long)m);
+                    return 2;
+                }
+            }
+            rows[(size_t)i * W + w] = make_ulonglong2(o, z);
+        }
+    }
+    return create_from_planes(device, N, M, rows.data(), out);
+}
+
+extern "C" int bnpc_create_planes(int device, int64_t N, int64_t M,
+                                  const uint64_t *planes, bnpc_ctx **out)
+{
+    ARGCHK(out && planes, "NULL argument");
+    ARGCHK(N > 0 && M > 0, "N and M must be positive");
+    ARGCHK(M < (1ll << 30) && N < (1ll << 40), "matrix too large");
+    *out = nullptr;
+    return create_from_planes(device, N, M, (const ulonglong2 *)planes, out);
 }
 
 extern "C" int bnpc_create(int device, int64_t N, int64_t M,

@@ -231,8 +231,11 @@ class CRP:
         state['_prior_rows'] = None
         state['_rg_view'] = None
         data = state.pop('data')
-        state['_data_codes'] = np.where(np.isnan(data), 3, data) \
-            .astype(np.int8)
+        if hasattr(data, 'planes'):     # bit planes travel as they are
+            state['_data_planes'] = (np.asarray(data.planes), data.shape[1])
+        else:
+            state['_data_codes'] = np.where(np.isnan(data), 3, data) \
+                .astype(np.int8)
         theta = state.get('parameters')
         if isinstance(theta, np.ndarray) and theta.ndim == 2 \
                 and self.cells_per_cluster is not None \
@@ -246,8 +249,12 @@ class CRP:
 
     def __setstate__(self, state):
         codes = state.pop('_data_codes', None)
+        planes = state.pop('_data_planes', None)
         rows = state.pop('_theta_rows', None)
         self.__dict__.update(state)
+        if planes is not None:
+            from bnpc_amd.bitplanes import BitPlanes
+            self.data = BitPlanes(*planes)
         if codes is not None:
             data = codes.astype(np.float64)
             data[codes == 3] = np.nan
@@ -387,10 +394,11 @@ class CRP:
         N, M = self.data.shape
         params = np.full((N, M), np.float32(TMIN), dtype=np.float32)
         if mode == 'separate':
+            data = np.asarray(self.data)        # (bit planes: materialised)
             draw = np.random.beta(
-                np.nan_to_num(self.p + self.data * fkt,
+                np.nan_to_num(self.p + data * fkt,
                     nan=self._beta_mix_const[0]),
-                np.nan_to_num(self.q + (1 - self.data) * fkt,
+                np.nan_to_num(self.q + (1 - data) * fkt,
                     nan=self._beta_mix_const[1]))
             params = np.clip(draw, TMIN, TMAX).astype(np.float32)
         elif mode == 'together':

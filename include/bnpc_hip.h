@@ -64,6 +64,19 @@ int bnpc_create(int device, int64_t N, int64_t M, const double *data_nan,
  * libs/dpmmIO.py:27-98 maps 3 -> NaN, 2 -> 1) */
 int bnpc_create_codes(int device, int64_t N, int64_t M, const int8_t *codes,
                       bnpc_ctx **out);
+/* same, from the packed form itself (libs/dpmmIO.py:27-98 parsed once, kept
+ * as a bit-plane file: bnpc_amd/bitplanes.py): planes[N][W][2] 64-bit words
+ * {ones, zeros}, W = ceil(M / 64), bit b of word w = mutation 64 w + b.  No
+ * float64 or int8 matrix is ever materialised. */
+int bnpc_create_planes(int device, int64_t N, int64_t M,
+                       const uint64_t *planes, bnpc_ctx **out);
+/* host-side packing / unpacking of that form: codes 0 | 1 | 2 (-> 1) | 3 with
+ * arbitrary element strides (a transposed view packs without a copy);
+ * unpack gathers rows `cells` (NULL: all N rows, n == N). */
+int bnpc_pack_codes(const int8_t *codes, int64_t N, int64_t M,
+                    int64_t row_stride, int64_t col_stride, uint64_t *planes);
+int bnpc_unpack_codes(const uint64_t *planes, int64_t N, int64_t M,
+                      const int64_t *cells, int64_t n, int8_t *codes);
 int bnpc_destroy(bnpc_ctx *ctx);
 /* Kernel-selection switches (BNPC_* environment variables, README) are read
  * when a context is created; this reads them again (A/B tools, tests). */

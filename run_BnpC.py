@@ -187,9 +187,12 @@ def main(args):
     from libs.MCMC import MCMC
 
     if os.path.getsize(args.input) > (4 << 20):
-        # large matrices: native byte scanner (no row / column names)
-        data = bio.codes_to_data(
-            bio.load_codes_native(args.input, transpose=args.transpose))
+        # large matrices (no row / column names): the packed bit planes, read
+        # from the file next to the input when it is current, else scanned
+        # natively and written there for the next run; the model and the
+        # device take them as they are (no float64 matrix)
+        from bnpc_amd import bitplanes
+        data = bitplanes.load_matrix(args.input, transpose=args.transpose)
     else:
         data, _ = bio.load_data(args.input, transpose=args.transpose,
             get_names=True)
@@ -235,6 +238,8 @@ def main(args):
         bio.show_MCMC_summary(args.time[0], args.time[1], results)
         print(f'Lugsail PSRF:\t\t{args.PSRF:.5f}')
         print(f'\nWriting output to: {out_dir}\n')
+    if hasattr(data, 'planes'):
+        data = data.codes()     # 0 | 1 | 3: all the estimators compare with
     save_outputs(args, results, data, out_dir)
     return results
 

@@ -165,3 +165,97 @@ def test_native_parser_throughput(tmp_path):
     t_nat = time.perf_counter() - t0
     assert np.array_equal(bio.data_to_codes(py), nat)
     assert t_nat * 3 < t_py, (t_nat, t_py)
+
+
+# ---- bit-plane file -------------------------
+@pytest.mark.parametrize('sep', [' ', '\t', ','])
+@pytest.mark.parametrize('header,index', [(False, False), (True, True),
+    (True, False)])
+def test_bitplane_file_round_trip_equals_load_data(tmp_path, sep, header,
+            index):
+    """Text -> native scan -> packed planes -> file -> memory map gives the
+    matrix of the reference's loader (dpmmIO.load_data) on every layout, in
+    both orientations, for sizes that are not multiples of 64."""
+    from bnpc_amd import bitplanes as B
+    rng = np.random.RandomState(4)
+    mat = rng.choice([0, 1, 2, 3], size=(70, 131), p=[.5, .3, .05, .15])
+    f = tmp_path / 'm.txt'
+    _write(f, mat, sep, header, index)
+    for transpose in (True, False):
+        want = bio.load_data(str(f), transpose=transpose)
+        side = str(f) + B.SUFFIX
+        if os.path.exists(side):
+            os.remove(side)
+        first = B.load_matrix(str(f), transpose=transpose)
+        assert os.path.exists(side) and not isinstance(first.planes, np.memmap)
+        again = B.load_matrix(str(f), transpose=transpose)
+        assert isinstance(again.planes, np.memmap)      # read, not re-parsed
+        for got in (first, again):
+            assert got.shape == want.shape
+            assert np.array_equal(np.asarray(got), want, equal_nan=True)
+            rows = [3, 0, want.shape[0] - 1, 3]
+            assert np.array_equal(got[rows], want[rows], equal_nan=True)
+            assert np.array_equal(got[5], want[5], equal_nan=True)
+            assert np.array_equal(got.codes(), bio.data_to_codes(want))
+        # the other orientation does not accept this file: rebuilt
+        other = B.load_matrix(str(f), transpose=not transpose)
+        assert other.shape == want.shape[::-1]
+        os.remove(side)
+
+
+def test_bitplane_cache_is_tied_to_its_source(tmp_path, monkeypatch):
+    from bnpc_amd import bitplanes as B
+    f = tmp_path / 'm.txt'
+    f.write_text('0 1 3\n1 1 0\n')
+    a = B.load_matrix(str(f), transpose=False)
+    assert np.asarray(a).tolist()[0][:2] == [0.0, 1.0]
+    side = str(f) + B.SUFFIX
+    # the text changes (same size, later mtime): the cache is not trusted
+    f.write_text('1 0 3\n1 1 0\n')
+    st = os.stat(str(f))
+    os.utime(str(f), ns=(st.st_atime_ns, st.st_mtime_ns + 10 ** 9))
+    b = B.load_matrix(str(f), transpose=False)
+    assert np.asarray(b).tolist()[0][:2] == [1.0, 0.0]
+    assert isinstance(B.load_matrix(str(f), transpose=False).planes, np.memmap)
+    # garbage in place of the cache is ignored and replaced
+    with open(side, 'wb') as g:
+        g.write(b'nonsense')
+    assert np.array_equal(np.asarray(B.load_matrix(str(f), transpose=False)), np.asarray(b),
+        equal_nan=True)
+    with pytest.raises(ValueError):
+        B.load(str(f))
+    # switched off: nothing is written
+    os.remove(side)
+    monkeypatch.setenv('BNPC_BITPLANE_CACHE', '0')
+    B.load_matrix(str(f), transpose=False)
+    assert not os.path.exists(side)
+    # inconsistent planes are refused by the packer's counterpart
+    with pytest.raises(RuntimeError, match='not 0\\|1\\|2\\|3'):
+        B.BitPlanes.from_codes(np.array([[0, 5]], dtype=np.int8))
+
+
+def test_model_on_bit_planes_walks_the_same_chain(monkeypatch):
+    """A model given BitPlanes instead of the float64 matrix: same chain
+    (row gathers come from the planes), picklable, deep-copyable."""
+    import copy
+    import pickle
+    from bnpc_amd import _lib, bitplanes as B, model as P
+    from fake_device import FakeContext
+    import test_host_logic as H
+    monkeypatch.setattr(_lib, 'Context', FakeContext)
+    data = H.synth(12, 60, 70, 3, 0.2)
+    planes = B.BitPlanes.from_data(data)
+    assert np.array_equal(np.asarray(planes), data, equal_nan=True)
+    res = []
+    for d in (data, planes):
+        res.append(H.run_chain(H.make(P, 'learn', d), 25, 7, sm_prob=.4,
+            eup=.25))
+    assert np.array_equal(res[0]['assignments'], res[1]['assignments'])
+    assert np.array_equal(res[0]['ML'], res[1]['ML'])
+    m = H.make(P, 'fixed', planes)
+    np.random.seed(1)
+    m.init()
+    for clone in (pickle.loads(pickle.dumps(m)), copy.deepcopy(m)):
+        assert isinstance(clone.data, B.BitPlanes)
+        assert np.array_equal(clone.data.planes, planes.planes)
+        assert np.array_equal(clone.parameters, m.parameters)

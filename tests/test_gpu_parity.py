@@ -765,3 +765,35 @@ def test_issued_tiles_overlap_other_calls():
     with pytest.raises(RuntimeError, match='slot'):
         ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 2)
     ctx.close()
+
+
+def test_context_from_bit_planes_equals_context_from_matrix(tmp_path):
+    """bnpc_create_planes (memory-mapped bit-plane file straight to HBM)
+    against bnpc_create (float64 matrix): same per-cell counts, same sums bit
+    for bit; inconsistent planes are refused."""
+    from bnpc_amd import bitplanes as B
+    rng = np.random.RandomState(8)
+    N, M = 333, 257
+    data = (rng.random_sample((N, M)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    path = str(tmp_path / 'x' + B.SUFFIX)
+    B.BitPlanes.from_data(data).save(path)
+    planes = B.load(path)
+    assert isinstance(planes.planes, np.memmap)
+    theta = np.clip(rng.uniform(size=(9, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    a = _lib.Context(data=data)
+    b = _lib.Context(data=planes)
+    assert all(np.array_equal(x, y)
+        for x, y in zip(a.cell_counts(), b.cell_counts()))
+    assert np.array_equal(a.ll_theta(0, theta, .01, .2),
+        b.ll_theta(0, theta, .01, .2))
+    L1, L0 = host_tables(theta[:2], .01, .2)
+    assert np.array_equal(b.ll_tables(0, L1, L0), table_sums(data, L1, L0))
+    a.close()
+    b.close()
+    bad = np.array(planes.planes)
+    bad[0, 0, 1] |= bad[0, 0, 0] | 1       # a bit set in both planes
+    bad[0, 0, 0] |= 1
+    with pytest.raises(RuntimeError, match='inconsistent'):
+        _lib.Context(data=B.BitPlanes(bad, M))
