@@ -776,7 +776,7 @@ def test_context_from_bit_planes_equals_context_from_matrix(tmp_path):
     N, M = 333, 257
     data = (rng.random_sample((N, M)) < 0.3).astype(float)
     data[rng.random_sample(data.shape) < 0.2] = np.nan
-    path = str(tmp_path / 'x' + B.SUFFIX)
+    path = str(tmp_path / ('x' + B.SUFFIX))
     B.BitPlanes.from_data(data).save(path)
     planes = B.load(path)
     assert isinstance(planes.planes, np.memmap)
