@@ -153,19 +153,65 @@ def timed_steps(ranks, step_fn, first, last):
 
 def load_pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or
-    None.  The counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, 'profiles', 'r01', 'pmc_v11_final.json')
-    try:
-        with open(path) as f:
-            pmc = json.load(f)
-        for name, ctr in pmc.items():
-            if kernel_substr in name:
-                kib = ctr['FETCH_SIZE']['mean'] + ctr['WRITE_SIZE']['mean']
-                return int(kib * 1024), os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        pass
+    PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units; the
+    fetch counter was calibrated on this kernel's scalar-load streams, see
+    profiles/r01/fetch_calibration.md), or None.  The counters cannot be read
+    from inside this process."""
+    for rel in (('profiles', 'r02', 'pmc_final.json'),
+            ('profiles', 'r01', 'pmc_v11_final.json')):
+        path = os.path.join(ROOT, *rel)
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+            for name, ctr in pmc.items():
+                if kernel_substr in name:
+                    kib = ctr['FETCH_SIZE']['mean'] + ctr['WRITE_SIZE']['mean']
+                    return int(kib * 1024), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
     return None, None
+
+
+def ll_roofline(ctx, rng, N, M, K, reps, traffic=None, traffic_src=None):
+    """One cells x clusters x mutations evaluation for K clusters, timed live
+    with HIP events on the library's stream: the sums kernel alone
+    (`launch_ms`, what the rocprof stats average) and the whole device-side
+    evaluation (`eval_ms`: element tables + sums + combine)."""
+    theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    ctx.ll_theta(0, theta, 0.01, 0.2, fetch=False)
+    ctx.sync()
+    kernel, _, chunks = ctx.last_launch()
+    ctx.bench_ll(2)
+    ms = ctx.bench_ll(reps)
+    ctx.ll_theta(0, theta, 0.01, 0.2, fetch=False)
+    ctx.sync()
+    ctx.bench_ll_full(2)
+    ms_full = ctx.bench_ll_full(reps)
+    alg_bytes = N * M / 4 + 4 * K * M + 8 * N * K
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    evals = N * K / (ms * 1e-3)
+    return {
+        'kernel': kernel, 'bound': 'hbm',
+        'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
+        'traffic_source': traffic_src,
+        'note': 'arithmetic intensity ~4K FP64 adds/byte: for K >= 2 the '
+            'kernel is FP64-VALU-bound, not HBM-bound (SURVEY.md 8(d)); '
+            'the binding roof is in `valu`',
+        'shape': {'N': N, 'M': M, 'K': K, 'mutation_chunks': chunks},
+        'launch_ms': round(ms, 5),
+        'eval_ms': round(ms_full, 5),
+        'algorithmic_bytes': int(alg_bytes),
+        # the exec-mask formulation issues 2 masked v_add_f64 per cell x
+        # cluster x mutation; BASELINE.md section 3 prices 1 add per element
+        'valu': {
+            'achieved_elem_evals_per_s': evals * M,
+            'peak_elem_evals_per_s': FP64_ADDS_PEAK / 2,
+            'frac': round(evals * M / (FP64_ADDS_PEAK / 2), 4),
+            'frac_1add': round(evals * M / FP64_ADDS_PEAK, 4),
+        },
+    }, evals
 
 
 def main():
@@ -230,52 +276,31 @@ def main():
     ml_end = float(chain.results['ML'][total])
 
     # ---- roofline of the dominant kernel, measured live -------------------
-    roofline = None
+    roofline = roofline_converged = None
     extra = {}
     if rank == 0:
         ctx = model._dev()
         rng = np.random.RandomState(1)
-
-        def time_ll(K):
-            theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
-                .astype(np.float32)
-            ctx.ll_theta(0, theta, 0.01, 0.2, fetch=False)
-            ctx.sync()
-            ctx.bench_ll(2)
-            ms = ctx.bench_ll(args.kernel_reps)
-            alg_bytes = N * M / 4 + 4 * K * M + 8 * N * K
-            return ms, alg_bytes
-
-        ms, alg_bytes = time_ll(K0)
-        gbs = alg_bytes / (ms * 1e-3) / 1e9
-        evals = N * K0 / (ms * 1e-3)
-        # the committed PMC passes were taken on config 3's first-sweep shape
-        traffic, traffic_src = load_pmc_traffic('k_ll8_asm<2, false>') \
-            if args.config == 'c3' else (None, None)
-        roofline = {
-            'kernel': 'k_ll8_asm<2, false>', 'bound': 'hbm',
-            'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'traffic_source': traffic_src,
-            'note': 'arithmetic intensity ~4K FP64 adds/byte: for K >= 2 the '
-                'kernel is FP64-VALU-bound, not HBM-bound (SURVEY.md 8(d)); '
-                'the binding roof is in `valu`',
-            'shape': {'N': N, 'M': M, 'K': K0},
-            'launch_ms': round(ms, 4),
-            'algorithmic_bytes': int(alg_bytes),
-            # the kernel is FP64-VALU-bound for K >~ 2 (2 exec-masked
-            # v_add_f64 per cell x cluster x mutation)
-            'valu': {
-                'achieved_elem_evals_per_s': evals * M,
-                'peak_elem_evals_per_s': FP64_ADDS_PEAK / 2,
-                'frac': round(evals * M / (FP64_ADDS_PEAK / 2), 4),
-            },
-        }
+        # the first-sweep shape: the launch that dominates the device time of
+        # a chain (not inside the timed region, which is the converged regime)
+        roofline, evals = ll_roofline(ctx, rng, N, M, K0, args.kernel_reps)
+        if args.config == 'c3':
+            # the committed PMC passes were taken on config 3's K0 shape
+            roofline['traffic'], roofline['traffic_source'] = \
+                load_pmc_traffic(roofline['kernel'])
         extra['ll_evals_per_s_K0'] = evals
+        # the launch that IS inside the timed region: K_end clusters
+        roofline_converged, _ = ll_roofline(ctx, rng, N, M, K_end,
+            max(20, args.kernel_reps))
+        roofline_converged['note'] = (
+            'the evaluation inside the timed region (K = K_end): a few '
+            'microseconds of work, latency-bound; eval_ms = element tables + '
+            'sums + combine')
         for Kc in sorted({10, 64, K_end}):
-            ms_c, b_c = time_ll(Kc)
-            extra[f'll_evals_per_s_K{Kc}'] = N * Kc / (ms_c * 1e-3)
-            extra[f'll_launch_us_K{Kc}'] = round(ms_c * 1e3, 2)
+            r, ev = ll_roofline(ctx, rng, N, M, Kc, max(20, args.kernel_reps))
+            extra[f'll_evals_per_s_K{Kc}'] = ev
+            extra[f'll_launch_us_K{Kc}'] = round(r['launch_ms'] * 1e3, 2)
+            extra[f'll_eval_us_K{Kc}'] = round(r['eval_ms'] * 1e3, 2)
 
     # ---- CPU baseline: the oracle from the same state, 1 core -------------
     cpu = None
@@ -314,6 +339,13 @@ def main():
         }
 
     if rank == 0:
+        from bnpc_amd import _lib, model as pmodel
+        host_info = {
+            'threads': _lib.host_threads(),
+            'native_mh_batch': pmodel._native_kernels() is not None,
+            'numa_node': getattr(model._dev(), 'numa_node', None),
+            'cpus': len(os.sched_getaffinity(0)),
+        }
         value = world * args.steps / elapsed
         line = {
             'metric': ('MCMC steps/s, 5k cells x 1k muts' if args.config == 'c3'
@@ -335,10 +367,12 @@ def main():
                 'chains': world, 'data_seed': 0, 'mcmc_seed': args.seed,
                 'K0': K0, 'K_after_warmup': K_warm, 'K_end': K_end,
             },
+            'host': host_info,
             'first_step_s': None if first_step_s is None
                 else round(first_step_s, 4),
             'ML_end': ml_end,
             'roofline': roofline,
+            'roofline_converged': roofline_converged,
             'cpu_baseline': cpu,
         }
         line.update(extra)

@@ -88,6 +88,9 @@ SIGNATURES = {
         _pi32]),
     'bnpc_ll_total': (C.c_int, [_ctx, _pf, _i64, _pd, _pd, C.c_int, _pd]),
     'bnpc_bench_ll': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
+    'bnpc_bench_ll_full': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
+    'bnpc_last_launch': (C.c_int, [_ctx, C.c_char_p, C.c_int,
+        C.POINTER(_i64), C.POINTER(C.c_int)]),
     'bnpc_timer_start': (C.c_int, [_ctx]),
     'bnpc_timer_stop': (C.c_int, [_ctx, C.POINTER(C.c_float)]),
     'bnpc_sync': (C.c_int, [_ctx]),
@@ -620,6 +623,22 @@ class Context:
         ms = C.c_float(0)
         check(self._lib.bnpc_bench_ll(self._h, reps, C.byref(ms)), 'bench_ll')
         return ms.value
+
+    def bench_ll_full(self, reps=10):
+        """Average device time (ms) of the whole last ll evaluation (tables +
+        sums + combine), re-issued; call right after ll_theta / ll_tables."""
+        ms = C.c_float(0)
+        check(self._lib.bnpc_bench_ll_full(self._h, reps, C.byref(ms)),
+            'bench_ll_full')
+        return ms.value
+
+    def last_launch(self):
+        """(kernel name(s), clusters, mutation chunks) of the last ll call."""
+        name = C.create_string_buffer(96)
+        K, ms = _i64(0), C.c_int(0)
+        check(self._lib.bnpc_last_launch(self._h, name, 96, C.byref(K),
+            C.byref(ms)), 'last_launch')
+        return name.value.decode(), K.value, ms.value
 
     def timer_start(self):
         check(self._lib.bnpc_timer_start(self._h), 'timer_start')

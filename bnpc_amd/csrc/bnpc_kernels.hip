@@ -181,6 +181,9 @@ struct bnpc_ctx {
     int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
     double *last_out = nullptr;
+    bool last_from_theta = false;
+    double last_FP = 0.0, last_FN = 0.0;
+    char last_name[96] = "";
 };
 
 static int ensure(DevBuf &b, size_t bytes)
@@ -1356,30 +1359,44 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        (long long)v.n, (long long)v.nblk,                    \
                        (const double *)c->tabs.p, (int)K, (long long)ldo,    \
                        dst, xcd, MS, m_chunk)
+    const char *combine = "";
     if (KW == 8 && impl == 2 && wg2 >= c->tun.asm2_min_wgs) {
         if (MS > 1) {
             if (MSq == 1) dst = d_out;  // the workgroup already holds the sum
             LAUNCH_ASM(2, true, split2);
             planes = MSq;
+            combine = MSq > 1 ? " + k_ll_combine" : "";
+            snprintf(c->last_name, sizeof(c->last_name),
+                     "k_ll8_asm<2, true>%s", combine);
         } else {
             LAUNCH_ASM(2, false, wg2);
+            snprintf(c->last_name, sizeof(c->last_name),
+                     "k_ll8_asm<2, false>");
         }
     } else if (KW == 8 && impl >= 1) {
         if (MS > 1) {
             if (MSq == 1) dst = d_out;
             LAUNCH_ASM(1, true, split1);
             planes = MSq;
+            combine = MSq > 1 ? " + k_ll_combine" : "";
+            snprintf(c->last_name, sizeof(c->last_name),
+                     "k_ll8_asm<1, true>%s", combine);
         } else {
             LAUNCH_ASM(1, false, nwg);
+            snprintf(c->last_name, sizeof(c->last_name),
+                     "k_ll8_asm<1, false>");
         }
     }
 #undef LAUNCH_ASM
-    else
+    else {
+        snprintf(c->last_name, sizeof(c->last_name), "k_ll<%d>%s", KW,
+                 MS > 1 ? " + k_ll_combine" : "");
         hipLaunchKernelGGL(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
                            dst, xcd, MS, m_chunk);
+    }
     if (MS > 1 && planes > 1) {
         HIPCHK(hipGetLastError());
         const long long total = (long long)v.n * K;
@@ -1444,6 +1461,7 @@ static int issue_seq(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         lds_raised = true;
     }
     dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)K);
+    snprintf(c->last_name, sizeof(c->last_name), "k_ll_seq");
     hipLaunchKernelGGL(k_ll_seq, grid, dim3(256), lds, c->stream,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.n, (long long)v.nblk, c->tab_src,
@@ -1497,6 +1515,9 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     if (rc) return rc;
     c->last_ms = MS;
     c->last_mchunk = m_chunk;
+    c->last_from_theta = from_theta;
+    c->last_FP = FP;
+    c->last_FN = FN;
     c->last_kw = kw;
     c->last_view = view;
     c->last_K = K;
@@ -2056,6 +2077,54 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
         for (int b = 0; b < blocks; b++) sum += p[b * 4 + e];
         out[e] = sum;
     }
+    return 0;
+}
+
+extern "C" int bnpc_last_launch(const bnpc_ctx *c, char *name, int len,
+                                int64_t *K, int *mutation_chunks)
+{
+    ARGCHK(c && name && len > 0, "NULL argument");
+    ARGCHK(c->last_kw != 0, "no previous bnpc_ll_theta / bnpc_ll_tables call");
+    strncpy(name, c->last_name, len - 1);
+    name[len - 1] = 0;
+    if (K) *K = c->last_K;
+    if (mutation_chunks) *mutation_chunks = c->last_ms;
+    return 0;
+}
+
+// the whole evaluation of the last call again - element tables, sums, combine -
+// `reps` times between two HIP events
+extern "C" int bnpc_bench_ll_full(bnpc_ctx *c, int reps, float *ms_per_call)
+{
+    ARGCHK(c && ms_per_call, "NULL argument");
+    ARGCHK(reps >= 1, "reps must be positive");
+    ARGCHK(c->last_kw != 0, "no previous bnpc_ll_theta / bnpc_ll_tables call");
+    HIPCHK(hipSetDevice(c->device));
+    const View &v = c->views[c->last_view];
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) {
+        int rc;
+        double *o = c->last_out;
+        const int64_t K = c->last_K, ldo = c->last_ldo;
+        const bool ft = c->last_from_theta;
+        const double FP = c->last_FP, FN = c->last_FN;
+        const int MS = c->last_ms, mc = c->last_mchunk;
+        if (c->last_kw == -1)
+            rc = issue_seq(c, v, K, ldo, o);
+        else
+        switch (c->last_kw) {
+        case 8: rc = launch_ll<8>(c, v, K, ldo, ft, FP, FN, o, MS, mc); break;
+        case 4: rc = launch_ll<4>(c, v, K, ldo, ft, FP, FN, o, MS, mc); break;
+        case 2: rc = launch_ll<2>(c, v, K, ldo, ft, FP, FN, o, MS, mc); break;
+        default: rc = launch_ll<1>(c, v, K, ldo, ft, FP, FN, o, MS, mc); break;
+        }
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_per_call = ms / reps;
     return 0;
 }
 

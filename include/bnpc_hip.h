@@ -193,6 +193,14 @@ int bnpc_ll_total(bnpc_ctx *ctx, const float *theta, int64_t K,
  * events on the context's stream; *ms_per_launch = average kernel duration.
  * Measurement only (bench.py roofline). */
 int bnpc_bench_ll(bnpc_ctx *ctx, int reps, float *ms_per_launch);
+/* the same for the WHOLE evaluation of that call (element tables, sums and,
+ * for mutation-split launches, the combine): what a converged-K call costs on
+ * the device.  Valid right after the call (its inputs are still staged). */
+int bnpc_bench_ll_full(bnpc_ctx *ctx, int reps, float *ms_per_call);
+/* which kernel(s) that call launched ("k_ll8_asm<2, true> + k_ll_combine"),
+ * for how many clusters, in how many mutation chunks */
+int bnpc_last_launch(const bnpc_ctx *ctx, char *name, int len, int64_t *K,
+                     int *mutation_chunks);
 int bnpc_timer_start(bnpc_ctx *ctx);
 int bnpc_timer_stop(bnpc_ctx *ctx, float *ms);
 int bnpc_sync(bnpc_ctx *ctx);
