@@ -2038,9 +2038,11 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
         d_theta = (const float *)c->theta.p;
     }
     // a fixed number of blocks per problem size (the sum order must not
-    // depend on anything else): ~1024 elements per block, at most 256 blocks
+    // depend on anything else): one element per thread up to 256 blocks -
+    // the parameters may be read in place from host memory, and every
+    // further trip of a thread's loop would pay that latency again
     const long long KM = (long long)K * c->M;
-    int blocks = (int)((KM + 1023) / 1024);
+    int blocks = (int)((KM + 255) / 256);
     if (blocks > TOTAL_BLOCKS) blocks = TOTAL_BLOCKS;
     if (blocks < 1) blocks = 1;
     const size_t part_bytes = (size_t)blocks * 4 * sizeof(double);
