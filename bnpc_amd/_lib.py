@@ -27,10 +27,17 @@ class MT19937(C.Structure):
     _fields_ = [('key', C.c_uint32 * 624), ('pos', C.c_int32)]
 
 
+# bnpc_top2 (include/bnpc_hip.h) as a NumPy record
+TOP2 = np.dtype([('best', np.float64), ('second', np.float64),
+    ('col', np.int64)])
+
+
 class GibbsState(C.Structure):
     _fields_ = [('n_cells', _i64), ('ld', _i64), ('n_cols', _i64),
         ('n_active', _i64), ('pos', _i64), ('new_cell', _i64),
-        ('pos_end', _i64), ('row_base', _i64), ('threads', _i64)]
+        ('pos_end', _i64), ('row_base', _i64), ('threads', _i64),
+        ('hint', C.c_void_p), ('hint_prior', C.c_void_p), ('hint_cols', _i64),
+        ('hint_used', _i64)]
 
 
 class MHArgs(C.Structure):
@@ -75,6 +82,8 @@ SIGNATURES = {
         C.c_double, _pd, _i64]),
     'bnpc_ll_theta_pinned': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
         C.c_double, _i64, _ppd]),
+    'bnpc_ll_theta_pinned_top2': (C.c_int, [_ctx, C.c_int, _pf, _i64,
+        C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, _ppd]),
@@ -101,6 +110,9 @@ SIGNATURES = {
     'bnpc_log_diff_pi': (C.c_int, [_pd, _pd, _i64, _pd]),
     'bnpc_mh_batch': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
         C.POINTER(MHArgs),
+        C.POINTER(C.c_int)]),
+    'bnpc_tn_logpdf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
+        C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
         C.POINTER(C.c_int)]),
     'bnpc_beta_logpdf_f32': (C.c_int, [C.c_void_p, _pf, _i64, C.c_double,
         C.c_double, C.c_void_p, C.c_void_p, _pd, _pd, C.c_int]),
@@ -378,6 +390,15 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
     return status.value, new, log_prob, declined, prior, (sd_idx, U, u)
 
 
+def tn_logpdf_scalar(kernels, x, a, b, loc, scale):
+    """truncnorm.logpdf for scalars on the kernel table, or None when the
+    library leaves the interval to SciPy."""
+    out, status = C.c_double(0.0), C.c_int(0)
+    check(load().bnpc_tn_logpdf_scalar(C.addressof(kernels), x, a, b, loc,
+        scale, C.byref(out), C.byref(status)), 'tn_logpdf_scalar')
+    return None if status.value else np.float64(out.value)
+
+
 def beta_logpdf_f32(kernels, x, p, q, known=None, threads=None):
     """(density array shaped like x, its sum in index order)"""
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -510,6 +531,31 @@ class Context:
         if n == 0:
             return np.empty((0, ld))
         return np.ctypeslib.as_array(host, shape=(n, ld))
+
+    def ll_theta_pinned_top2(self, view, theta, FP, FN, ld, col_prior):
+        """ll_theta_pinned plus the sweep's hint: (matrix view, hint) where
+        hint is a structured NumPy VIEW (fields best, second, col; one entry
+        per slot) of pinned memory, or None (more than 64 columns)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        K = theta.shape[0]
+        if K > 64:
+            return self.ll_theta_pinned(view, theta, FP, FN, ld), None
+        col_prior = np.ascontiguousarray(col_prior, dtype=np.float64)
+        assert col_prior.size == K
+        n = self.view_size(view)
+        host = _host_pd()
+        hint = C.c_void_p()
+        check(self._lib.bnpc_ll_theta_pinned_top2(self._h, view,
+            ptr(theta, C.c_float), K, float(FP), float(FN), ld,
+            ptr(col_prior), C.byref(host), C.byref(hint)),
+            'll_theta_pinned_top2')
+        if n == 0:
+            return np.empty((0, ld)), None
+        mat = np.ctypeslib.as_array(host, shape=(n, ld))
+        if not hint.value:
+            return mat, None
+        raw = (C.c_char * (n * TOP2.itemsize)).from_address(hint.value)
+        return mat, np.frombuffer(raw, dtype=TOP2, count=n)
 
     def theta_put(self, row0, theta):
         """Store parameter rows on the device (row index = cluster id)."""

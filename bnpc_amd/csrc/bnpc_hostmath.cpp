@@ -518,3 +518,40 @@ extern "C" int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x,
     }
     return 0;
 }
+
+// truncnorm.logpdf(x, a, b, loc, scale) for scalars (the error-rate moves,
+// libs/CRP_learning_errors.py:85-91, and their priors :47-49): SciPy's
+// _norm_logpdf((x - loc) / scale) - _log_gauss_mass(a, b) - log(scale) with
+// the support mask of the public wrapper.  *status = 1: an interval this
+// library leaves to SciPy.
+extern "C" int bnpc_tn_logpdf_scalar(const bnpc_host_kernels *k, double x,
+                                     double a, double b, double loc,
+                                     double scale, double *out, int *status)
+{
+    if (check_kernels(k)) return 2;
+    if (!out || !status) {
+        bnpc_set_error("bad argument: tn_logpdf_scalar");
+        return 2;
+    }
+    *status = 0;
+    double mass;
+    if (a > 0.0 && k->left_ok) {
+        // case_right: the mirrored interval left of zero
+        mass = bnpc_log_diff_pi1(k->log_ndtr(-a, 0), k->log_ndtr(-b, 0));
+    } else if (!gauss_mass(k, a, b, &mass)) {
+        *status = 1;
+        return 0;
+    }
+    if (!(scale > 0.0) || !isfinite(mass)) {
+        *status = 1;
+        return 0;
+    }
+    const double xs = (x - loc) / scale;
+    double log_scale;
+    uloop(k->np_log, k->np_log_data, &scale, &log_scale, 1);
+    double v = -(xs * xs) / 2.0 - k->norm_pdf_logC;
+    v = v - mass;
+    v = v - log_scale;
+    *out = ((a <= xs) && (xs <= b)) ? v : -INFINITY;
+    return 0;
+}

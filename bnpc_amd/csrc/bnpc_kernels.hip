@@ -92,6 +92,7 @@ struct Tunables {
     int zero_copy = 1;              // small payloads are read / written in
     int64_t zc_in_max = 256 << 10;  // place in pinned host memory
     int64_t zc_out_max = 512 << 10;
+    int64_t zc_sweep_max = 0;       // the sweep's matrix (pinned) in place
     int mask_counts_max = 64;       // segments for the mask-popcount counts
     int seq_kernel = 1;             // k_ll_seq for caller-built tables
     int fused_small = 1;            // one-launch small-K likelihood
@@ -119,6 +120,7 @@ static void read_tunables(Tunables &t)
     t.zero_copy = env_int("BNPC_ZERO_COPY", 1);
     t.zc_in_max = (int64_t)env_int("BNPC_ZC_IN_KB", 256) << 10;
     t.zc_out_max = (int64_t)env_int("BNPC_ZC_OUT_KB", 512) << 10;
+    t.zc_sweep_max = (int64_t)env_int("BNPC_ZC_SWEEP_KB", 0) << 10;
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 1);
     t.fused_small = env_int("BNPC_FUSED_SMALL", 1);
@@ -181,6 +183,7 @@ struct bnpc_ctx {
     int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
     double *last_out = nullptr;
+    double *dst_override = nullptr; // device-addressable result buffer
     bool last_from_theta = false;
     double last_FP = 0.0, last_FN = 0.0;
     char last_name[96] = "";
@@ -847,6 +850,42 @@ __global__ __launch_bounds__(256) void k_ll_seq(
 }
 
 // ---------------------------------------------------------------------------
+// K2t: per slot the two largest entries of out[s][k] + prior[k], k < K <= 64,
+// and the column of the largest (first on ties): the sweep's hint.  The
+// priors travel as kernel arguments (no memory to fetch them from); the matrix
+// was just written and is read from L2.
+// ---------------------------------------------------------------------------
+struct Top2Prior {
+    double v[64];
+};
+
+__global__ __launch_bounds__(256) void k_row_top2(
+    const double *__restrict__ ll, long long n, long long ldo, int K,
+    Top2Prior prior, bnpc_top2 *__restrict__ out)
+{
+    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n) return;
+    const double *__restrict__ r = ll + (size_t)slot * ldo;
+    double best = -INFINITY, second = -INFINITY;
+    long long col = 0;
+    for (int k = 0; k < K; k++) {
+        const double v = r[k] + prior.v[k];
+        if (v > best) {
+            second = best;
+            best = v;
+            col = k;
+        } else if (v > second) {
+            second = v;
+        }
+    }
+    bnpc_top2 t;
+    t.best = best;
+    t.second = second;
+    t.col = col;
+    out[slot] = t;
+}
+
+// ---------------------------------------------------------------------------
 // K3: column counts of 1s and 0s over chunks of cell segments
 //   n1[g][m] = #{c in segment g : x_cm = 1},  n0 likewise
 //   = the sums over a cell subset inside CRP._get_log_A (libs/CRP.py:359-368),
@@ -1498,6 +1537,7 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     pick_msplit(c->tun, v.nblk * ((K + kw - 1) / kw), c->Mt,
                 from_theta && c->tun.msplit, &MS, &m_chunk);
     double *d_out = zc_host ? (double *)zc_dev : (double *)c->out.p;
+    if (c->dst_override) d_out = c->dst_override;
     int rc;
     const size_t seq_lds = (size_t)(c->Mpad + 8) * sizeof(double2);
     if (!from_theta && c->tun.seq_kernel && !c->tun.force_kw
@@ -1599,18 +1639,74 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     *host = nullptr;
     ARGCHK(!c->tile_pending[0] && !c->tile_pending[1],
            "not available while an issued tile is in flight");
-    int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
-    if (rc) return rc;
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
+    if (bytes && ensure_pin(c, bytes)) return 1;
+    // up to BNPC_ZC_SWEEP_KB the kernels write the matrix straight into the
+    // pinned buffer (no copy-engine launch behind them)
+    void *pin_dev = nullptr;
+    if (bytes && c->tun.zero_copy && (int64_t)bytes <= c->tun.zc_sweep_max
+        && hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
+        c->dst_override = (double *)pin_dev;
+    int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
+    const bool in_place = c->dst_override != nullptr;
+    c->dst_override = nullptr;
+    if (rc) return rc;
     if (bytes == 0) {
         HIPCHK(hipStreamSynchronize(c->stream));
         return 0;
     }
-    if (ensure_pin(c, bytes)) return 1;
+    if (!in_place)
+        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *host = (double *)c->pin;
+    return 0;
+}
+
+extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
+                                         const float *theta, int64_t K,
+                                         double FP, double FN, int64_t ldo,
+                                         const double *col_prior,
+                                         double **host, bnpc_top2 **top2)
+{
+    ARGCHK(c && host && top2 && col_prior, "NULL argument");
+    ARGCHK(K > 0 && K <= 64, "K out of range for the top-2 hint");
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    *top2 = nullptr;
+    if (ldo == 0) ldo = K;
+    const int64_t n = c->views[view].n;
+    void *zc_dev = nullptr;
+    // the hints of all slots, written in place into pinned host memory
+    bnpc_top2 *hint = n ? (bnpc_top2 *)zc_result(
+        c, (size_t)n * sizeof(bnpc_top2), &zc_dev) : nullptr;
+    // the matrix itself as bnpc_ll_theta_pinned, minus its final wait
+    ARGCHK(theta, "theta is NULL");
+    ARGCHK(ldo >= K, "ldo smaller than K");
+    *host = nullptr;
+    ARGCHK(!c->tile_pending[0] && !c->tile_pending[1],
+           "not available while an issued tile is in flight");
+    const size_t bytes = (size_t)n * ldo * sizeof(double);
+    if (bytes && ensure_pin(c, bytes)) return 1;
+    int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
+    if (rc) return rc;
+    if (bytes == 0) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    if (hint) {
+        Top2Prior pr;
+        for (int k = 0; k < 64; k++) pr.v[k] = k < K ? col_prior[k] : 0.0;
+        hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
+                           dim3(256), 0, c->stream, (const double *)c->out.p,
+                           (long long)n, (long long)ldo, (int)K, pr,
+                           (bnpc_top2 *)zc_dev);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
                           c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *host = (double *)c->pin;
+    *top2 = hint;
     return 0;
 }
 

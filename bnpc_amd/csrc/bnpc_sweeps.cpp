@@ -289,6 +289,39 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         cpr[c] = (sz >= 0 && sz <= N + 1) ? crp_prior[sz] : 0.0;
     }
 
+    // The hint (include/bnpc_hip.h: bnpc_top2): the two largest entries of
+    // every row under the priors at launch.  `drift` bounds how far any
+    // column's prior has moved since; with it the hint decides a cell without
+    // scanning it when best - drift beats everything else + drift (and the
+    // new-cluster entry, and the columns born since, which are looked at) by
+    // more than the dominance margin.  Whole-matrix sweeps with few clusters.
+    const bnpc_top2 *hint = (st->row_base < 0 && st->hint && st->hint_prior
+                             && st->hint_cols > 0 && st->hint_cols <= 64
+                             && st->hint_cols <= st->n_cols && FLOOR_STEP > 0)
+        ? st->hint : nullptr;
+    const int64_t hint_cols = hint ? st->hint_cols : 0;
+    const double *cpr0 = st->hint_prior;
+    double drift = 0.0;
+    int64_t pos_of_col[64];
+    auto index_live = [&]() {
+        for (int64_t c = 0; c < hint_cols; c++) pos_of_col[c] = -1;
+        for (int64_t a = 0; a < st->n_active; a++)
+            if (order[a] < hint_cols) pos_of_col[order[a]] = a;
+    };
+    if (hint) {
+        for (int64_t c = 0; c < hint_cols; c++)
+            if (col_size[c] > 0) {
+                const double d = fabs(cpr[c] - cpr0[c]);
+                if (d > drift) drift = d;
+            }
+        index_live();
+    }
+#define NOTE_PRIOR(c_)                                                        \
+    if ((c_) < hint_cols) {                                                   \
+        const double d_ = fabs(cpr[c_] - cpr0[c_]);                           \
+        if (d_ > drift) drift = d_;                                           \
+    }
+
     while (st->pos < st->pos_end) {
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
@@ -340,9 +373,11 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             st->n_active--;
             col_size[old_col] = 0;
             col_of_id[old_id] = -1;
+            if (hint) index_live();
         } else {
             col_size[old_col]--;
             cpr[old_col] = crp_prior[col_size[old_col]];
+            NOTE_PRIOR(old_col)
         }
 
         // log posterior of joining each live cluster / a new one (:268-274)
@@ -352,7 +387,29 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         int64_t top = 0;                    // first maximum
         double best = -INFINITY;
         double second = -INFINITY;          // largest entry that is not `top`
-        if (par && A >= par_min) {
+        bool hinted = false;
+        if (hint && A <= 64) {
+            const bnpc_top2 &h = hint[cell];
+            const int64_t hc = h.col;
+            if (hc >= 0 && hc < hint_cols && col_size[hc] > 0
+                && pos_of_col[hc] >= 0) {
+                double other = h.second + drift;
+                const double pn = post_new[cell];
+                if (pn > other) other = pn;
+                for (int64_t a = A - 1; a >= 0 && order[a] >= hint_cols; a--) {
+                    const double v = row[order[a]] + cpr[order[a]];
+                    if (v > other) other = v;
+                }
+                if (other - (h.best - drift) < dom_bound[A]) {
+                    top = pos_of_col[hc];
+                    hinted = true;
+                    st->hint_used++;
+                }
+            }
+        }
+        if (hinted) {
+            // `top` is known and dominates: nothing else is needed below
+        } else if (par && A >= par_min) {
             par->row = row;
             par->A = A;
             par->run(ParScan::SCAN);
@@ -395,7 +452,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
-        {
+        if (!hinted) {
             const double v = post_new[cell];
             post[A] = v;
             const bool gt = v > best;
@@ -410,7 +467,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const double ptop = best;
         const double u_dominated = dom_bound[A];
         int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
-        if (FLOOR_STEP > 0 && second - ptop < u_dominated) {
+        if (hinted || (FLOOR_STEP > 0 && second - ptop < u_dominated)) {
             // One cluster dominates: the tail sum of exponentials is below
             // 2^-55, so log1p(tail) == tail < half an ulp of 1: the winner's
             // probability is exp(-tail) == 1.0 exactly and every other entry
@@ -493,8 +550,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         assignment[cell] = col_id[c];
         col_size[c]++;
         cpr[c] = crp_prior[col_size[c]];
+        NOTE_PRIOR(c)
     }
     return 0;
+#undef NOTE_PRIOR
 }
 
 extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

@@ -166,6 +166,17 @@ def _native_batch_is_exact(table):
                             np.cumsum(want[1], axis=1)[:, -1])
                     if want[3] is not None:
                         ok &= np.array_equal(got[4], want[3])
+            # scalar truncated-normal densities (error-rate moves / priors)
+            for x, lo, sc in ((0.013, 0.01, 0.005), (0.19, 0.2, 0.15),
+                    (0.0004, 0.001, 0.0005), (0.2, 0.2, 0.1), (1.5, 0.2, 0.1),
+                    (0.9999, 0.2, 0.05)):
+                for a, b in (((0 - lo) / sc, (1 - lo) / sc),
+                        ((0 - x) / sc, (1 - x) / sc)):
+                    with np.errstate(all='ignore'):
+                        ref = fastdist.tn_logpdf(x, a, b, lo, sc)
+                    got = _lib.tn_logpdf_scalar(table, x, a, b, lo, sc)
+                    ok &= got is not None and (got == ref or
+                        (np.isnan(got) and np.isnan(ref)))
             if not probe.beta_prior_uniform:
                 dens, total = _lib.beta_logpdf_f32(table, old, p, q,
                     threads=2)
@@ -175,6 +186,18 @@ def _native_batch_is_exact(table):
         return bool(ok)
     except Exception:
         return False
+
+
+def _tn_logpdf_scalar(x, a, b, loc, scale):
+    """truncnorm.logpdf for scalar arguments: natively on SciPy's own kernels
+    when the start-up comparison allows, else through SciPy."""
+    table = _native_kernels()
+    if table is not None:
+        val = _lib.tn_logpdf_scalar(table, float(x), float(a), float(b),
+            float(loc), float(scale))
+        if val is not None:
+            return val
+    return fastdist.tn_logpdf(x, a, b, loc, scale)
 
 
 class CRP:
@@ -534,10 +557,23 @@ class CRP:
             # a few spare columns for clusters opened during the sweep (the
             # matrix is re-allocated with more if they run out)
             spare = max(4, min(16, ids.size // 4))
-            ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids], self.FP,
-                self.FN, ids.size + spare)
+            # with few clusters the device also reports, per cell, the two
+            # best columns under the priors at launch: the native loop then
+            # decides most cells without scanning them
+            hint = None
+            if ids.size <= 64 and os.environ.get('BNPC_SWEEP_HINT', '1') != '0':
+                col_prior = np.ascontiguousarray(crp_prior[sizes])
+                ll, top2 = ctx.ll_theta_pinned_top2(VIEW_ALL,
+                    self.parameters[ids], self.FP, self.FN, ids.size + spare,
+                    col_prior)
+                if top2 is not None:
+                    hint = (top2, col_prior)
+            else:
+                ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids],
+                    self.FP, self.FN, ids.size + spare)
             ids, sizes, born = self._gibbs_window(perm, 0, N, VIEW_ALL, ll,
-                ids, ids, sizes, (), assignment, post_new, crp_prior)
+                ids, ids, sizes, (), assignment, post_new, crp_prior,
+                hint=hint)
             opened, tiles = len(born), 1
         else:
             # Tiled sweep.  The parameter rows stay resident on the device
@@ -603,7 +639,7 @@ class CRP:
             int(i): int(n) for i, n in zip(ids, sizes)}
 
     def _gibbs_window(self, perm, pos, pos_end, view, ll, cols, ids, sizes,
-                stale, assignment, post_new, crp_prior):
+                stale, assignment, post_new, crp_prior, hint=None):
         """Positions [pos, pos_end) of the sweep.
 
         ll: (rows, ld) matrix whose first cols.size columns were evaluated for
@@ -653,6 +689,11 @@ class CRP:
 
         st = _lib.GibbsState(N, ld, n_cols, K, pos, -1, pos_end,
             -1 if whole else pos, _lib.host_threads())
+        if hint is not None and whole and not late.size:
+            # columns 0..cols.size-1 of ll are the hint's columns
+            st.hint = hint[0].ctypes.data
+            st.hint_prior = hint[1].ctypes.data
+            st.hint_cols = cols.size
         i64, f64 = C.c_int64, C.c_double
         born = []
         while True:
@@ -695,6 +736,7 @@ class CRP:
             assignment[cell] = new_id
             born.append(new_id)
         live = order[:st.n_active]
+        self._hint_used = getattr(self, '_hint_used', 0) + int(st.hint_used)
         if tile_timing:
             print(f'[bnpc]   tile [{pos},{pos_end}) cols={cols.size} '
                 f'late={late.size} born={len(born)}: host '
@@ -1342,7 +1384,7 @@ class CRP_errors_learning(CRP):
         a, b, mean, sd = (self.FP_prior if which == 'FP'
             else self.FN_prior).args
         return self._memo((which, float(x)),
-            lambda: fastdist.tn_logpdf(x, a, b, mean, sd))
+            lambda: _tn_logpdf_scalar(x, a, b, mean, sd))
 
     def update_error_rates(self):
         """libs/CRP_learning_errors.py:52-55"""
@@ -1370,8 +1412,8 @@ class CRP_errors_learning(CRP):
         except FloatingPointError:
             new = truncnorm.rvs(a, np.inf, loc=old, scale=std)
 
-        fwd = fastdist.tn_logpdf(new, a, b, old, std)
-        rev = fastdist.tn_logpdf(old, (0 - new) / std, (1 - new) / std, new,
+        fwd = _tn_logpdf_scalar(new, a, b, old, std)
+        rev = _tn_logpdf_scalar(old, (0 - new) / std, (1 - new) / std, new,
             std)
 
         if error_type == 'FP':

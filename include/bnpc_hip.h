@@ -119,6 +119,22 @@ int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
                          int64_t K, double FP, double FN, int64_t ldo,
                          double **host);
 
+/* bnpc_ll_theta_pinned plus, per slot, the two largest entries of
+ *   out[s, k] + col_prior[k]   (k < K <= 64)
+ * and the column of the largest: a HINT for the sequential sweep, which then
+ * scores a cell in O(1) instead of O(K) whenever the winner is beyond doubt
+ * (bnpc_gibbs_state.hint).  col_prior[k] is the log prior of column k's
+ * cluster at launch time (CRP_prior[size], libs/CRP.py:226).  *top2 points
+ * into pinned host memory, valid until the next call on the context. */
+typedef struct bnpc_top2 {
+    double best, second;    /* largest / second largest entry of the row */
+    int64_t col;            /* column of the largest (first one on ties) */
+} bnpc_top2;
+int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
+                              int64_t K, double FP, double FN, int64_t ldo,
+                              const double *col_prior, double **host,
+                              bnpc_top2 **top2);
+
 /* Resident parameter rows for tiled sweeps: store row r holds the float32
  * parameter vector of cluster id r (libs/CRP.py:155-180 keeps them in an
  * N x M array indexed by id).  bnpc_theta_put copies R rows starting at row0;
@@ -323,6 +339,13 @@ int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x, int64_t n,
                          const double *known_prior, double *out,
                          double *seq_sum, int threads);
 
+/* scipy.stats.truncnorm.logpdf(x, a, b, loc, scale) for scalar arguments (the
+ * error-rate proposals and priors, libs/CRP_learning_errors.py:47-49, 85-91)
+ * on the same kernel table; *status = 1: not evaluated (left to SciPy). */
+int bnpc_tn_logpdf_scalar(const bnpc_host_kernels *k, double x, double a,
+                          double b, double loc, double scale, double *out,
+                          int *status);
+
 /* Checker hook: the cumulative sums np.cumsum(p) holds for the probability
  * vector p[top] = 1.0, p[a != top] = 1e-15-floor (a = 0..A) - the case in
  * which one cluster dominates _normalize_log_probs (libs/CRP.py:88-100).  The
@@ -363,6 +386,15 @@ typedef struct bnpc_gibbs_state {
     int64_t threads;    /* host threads for the scan of a cell over thousands
                            of live clusters (first sweeps); <= 1: none.  The
                            result does not depend on it. */
+    /* optional (NULL: none; whole-matrix sweeps only): per CELL the two
+     * largest entries of ll[cell, k] + hint_prior[k] over the first hint_cols
+     * columns, from bnpc_ll_theta_pinned_top2.  Where those, widened by how
+     * far the priors have moved since, leave no doubt about the winner, the
+     * cell is not scanned.  The result does not depend on it. */
+    const struct bnpc_top2 *hint;
+    const double *hint_prior;
+    int64_t hint_cols;
+    int64_t hint_used;  /* out: cells decided from the hint, accumulated */
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

@@ -63,6 +63,21 @@ class FakeContext:
         out = np.empty((n, ld))
         return self.ll_theta(view, theta, FP, FN, out=out)
 
+    def ll_theta_pinned_top2(self, view, theta, FP, FN, ld, col_prior):
+        mat = self.ll_theta_pinned(view, theta, FP, FN, ld)
+        K = np.asarray(theta).shape[0]
+        if K > 64:
+            return mat, None
+        post = mat[:, :K] + np.asarray(col_prior)[None, :]
+        hint = np.empty(post.shape[0], dtype=[('best', np.float64),
+            ('second', np.float64), ('col', np.int64)])
+        hint['col'] = np.argmax(post, axis=1)
+        hint['best'] = post[np.arange(post.shape[0]), hint['col']]
+        rest = post.copy()
+        rest[np.arange(post.shape[0]), hint['col']] = -np.inf
+        hint['second'] = rest.max(axis=1) if K > 1 else -np.inf
+        return mat, hint
+
     def theta_put(self, row0, theta):
         theta = np.atleast_2d(np.asarray(theta, dtype=np.float32))
         self._poison_in_flight(row0, theta.shape[0])

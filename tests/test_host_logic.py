@@ -641,3 +641,87 @@ def test_team_scan_of_many_clusters_changes_nothing(tiled, monkeypatch):
             assert list(o.cells_per_cluster.items()) == \
                 list(p.cells_per_cluster.items())
             assert np.array_equal(o._tail, p._tail)
+
+
+def test_sweep_hints_change_nothing(monkeypatch):
+    """The per-cell top-2 hint (bnpc_top2) lets the native loop skip the scan
+    of a cell: sweeps with and without it are the same sweeps - from a
+    fragmented start where clusters die and are born under the hint, with
+    clear winners (many mutations) and with close calls (few mutations) -
+    and both equal the oracle's."""
+    for M, seed in ((5, 6), (80, 7)):
+        data = synth(seed, 160, M, 3, 0.15)
+        runs = []
+        for mod, hint in ((O, None), (P, '1'), (P, '0')):
+            if hint is not None:
+                monkeypatch.setenv('BNPC_SWEEP_HINT', hint)
+            m = make(mod, 'fixed', data)
+            np.random.seed(17)
+            m.init(assign=list(np.random.RandomState(seed).randint(0, 40, 160)))
+            out = []
+            for sweep in range(3):
+                np.random.seed(50 + sweep)
+                m.update_assignments_Gibbs()
+                out.append((m.assignment.copy(),
+                    list(m.cells_per_cluster.items()), np.random.random()))
+                m.update_parameters()
+            runs.append(out)
+        for other in runs[1:]:
+            for a, b in zip(runs[0], other):
+                assert np.array_equal(a[0], b[0]) and a[1] == b[1] \
+                    and a[2] == b[2]
+
+
+def test_sweep_hint_is_used_and_falls_back():
+    """Direct calls: a row whose hint leaves no doubt is decided without
+    reading the matrix (a poisoned row goes unnoticed), a row whose runner-up
+    is close is scanned (the poison is seen)."""
+    from bnpc_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    N, K, ld = 6, 3, 4
+    crp = np.append(0, O.CRP.log_CRP_prior(
+        np.append(np.arange(1, N + 1), 2.0), N, 2.0))
+    sizes = np.array([2, 2, 2], dtype=np.int64)
+    col_prior = np.ascontiguousarray(crp[sizes])
+    ll = np.full((N, ld), -500.0)
+    truth = np.array([0, 0, 1, 1, 2, 2])
+    ll[np.arange(N), truth] = -100.0
+    hint = np.zeros(N, dtype=_lib.TOP2)
+    hint['best'] = -100.0 + col_prior[truth]
+    hint['second'] = -500.0 + col_prior.max()
+    hint['col'] = truth
+    post_new = np.full(N, -800.0)
+
+    def sweep(mat, hints):
+        np.random.seed(3)
+        perm = _lib.as_i64(np.random.permutation(N))
+        assignment = truth.astype(np.int64).copy()
+        col_of_id = np.full(N, -1, dtype=np.int64)
+        col_of_id[:K] = np.arange(K)
+        col_id = np.array([0, 1, 2, -1], dtype=np.int64)
+        col_size = np.array([2, 2, 2, 0], dtype=np.int64)
+        order = np.array([0, 1, 2, 0], dtype=np.int64)
+        scratch = np.empty(2 * (ld + 1))
+        st = _lib.GibbsState(N, ld, K, K, 0, -1, N, -1, 1)
+        if hints is not None:
+            st.hint = hints.ctypes.data
+            st.hint_prior = col_prior.ctypes.data
+            st.hint_cols = K
+        with _lib.NumpyStream() as rng:
+            _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), rng, _lib.ptr(perm),
+                _lib.ptr(mat), _lib.ptr(post_new), _lib.ptr(crp),
+                _lib.ptr(assignment), _lib.ptr(col_of_id), _lib.ptr(col_id),
+                _lib.ptr(col_size), _lib.ptr(order), _lib.ptr(scratch)),
+                'sweep')
+        return assignment, np.random.random()
+
+    want = sweep(ll, None)
+    assert np.array_equal(want[0], truth)
+    poisoned = np.full_like(ll, np.nan)
+    got = sweep(poisoned, hint)         # never looks at the matrix
+    assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+    close = hint.copy()
+    close['second'] = close['best'] - 1.0   # a runner-up 1 nat away: scan
+    got = sweep(ll, close)
+    assert np.array_equal(got[0], want[0]) and got[1] == want[1]

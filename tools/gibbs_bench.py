@@ -55,10 +55,12 @@ class Wrap:
 
 lib.bnpc_gibbs_sweep = Wrap()
 reps = 100
+model._hint_used = 0
 t0 = time.perf_counter()
 for _ in range(reps):
     model.update_assignments_Gibbs()
 total = time.perf_counter() - t0
+print(f'cells decided from the hint: {getattr(model, "_hint_used", 0) / reps:.0f} of {N} per sweep')
 print(f'{cfg} K={len(model.cells_per_cluster)} prefetch='
     f'{os.environ.get("BNPC_SWEEP_PREFETCH", "default")}: sweep '
     f'{1e6 * total / reps:7.1f} us | ' + ' | '.join(
