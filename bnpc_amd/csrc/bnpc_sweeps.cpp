@@ -332,11 +332,17 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 const char *r = (const char *)(ll + (size_t)(
                     st->row_base >= 0 ? st->pos + ahead_by - st->row_base
                                       : ahead) * ld);
-                const size_t bytes = (size_t)st->n_cols * sizeof(double);
-                const char *end = r + (bytes < 512 ? bytes : 512);
-                for (const char *q = (const char *)((uintptr_t)r & ~(uintptr_t)63);
-                     q < end; q += 64)
-                    __builtin_prefetch(q, 0, 1);
+                if (hint) {
+                    // the row itself is only read if the hint is in doubt
+                    __builtin_prefetch(&hint[ahead], 0, 1);
+                } else {
+                    const size_t bytes = (size_t)st->n_cols * sizeof(double);
+                    const char *end = r + (bytes < 512 ? bytes : 512);
+                    for (const char *q =
+                             (const char *)((uintptr_t)r & ~(uintptr_t)63);
+                         q < end; q += 64)
+                        __builtin_prefetch(q, 0, 1);
+                }
                 __builtin_prefetch(&assignment[ahead], 1, 1);
                 __builtin_prefetch(&post_new[ahead], 0, 1);
             }
