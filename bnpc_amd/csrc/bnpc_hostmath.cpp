@@ -23,6 +23,7 @@
 #include <linux/futex.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/syscall.h>
@@ -419,6 +420,16 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
 
     std::atomic<int64_t> next(0), rows_ready(rng ? 0 : G);
     std::atomic<int> bail(0);
+    static const bool trace = getenv("BNPC_MH_TRACE") != nullptr;
+    timespec ts0;
+    long t_draws = 0;
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto since = [&]() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (ts.tv_sec - ts0.tv_sec) * 1000000000L
+            + (ts.tv_nsec - ts0.tv_nsec);
+    };
 
     auto work = [&](int rank) {
         if (rank == 0 && rng) {
@@ -432,13 +443,18 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 mt_fill_double(rng, ug, M);
                 rows_ready.store(g + 1, std::memory_order_release);
             }
+            if (trace) t_draws = since();
         }
         for (;;) {
             const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
             if (t >= tasks) break;
             const int64_t g = t / chunks, ch = t - g * chunks;
-            while (rows_ready.load(std::memory_order_acquire) <= g)
-                std::this_thread::yield();
+            // the draws of this cluster are a few microseconds away at most
+            while (rows_ready.load(std::memory_order_acquire) <= g) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
             if (bail.load(std::memory_order_relaxed)) continue;
             const int64_t m0 = ch * BLK;
             const int64_t m1 = m0 + BLK < M ? m0 + BLK : M;
@@ -451,6 +467,10 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     else
         work(0);
 
+    if (trace)
+        fprintf(stderr, "[mh_batch] G=%lld M=%lld threads=%d: draws done at "
+                "%.1f us, all done at %.1f us\n", (long long)G, (long long)M,
+                threads, t_draws / 1e3, since() / 1e3);
     if (bail.load()) {
         *status = 1;
         return 0;
