@@ -326,16 +326,51 @@ def mh_draws(G, M, n_sd):
     return sd_idx, U, u
 
 
+_threads_memo = {}
+
+
 def host_threads():
     """Size of the native host thread team (BNPC_HOST_THREADS; default
-    min(16, cores); 1 = the calling thread only)."""
-    try:
-        n = int(os.environ.get('BNPC_HOST_THREADS', 0))
-    except ValueError:
-        n = 0
-    if n < 1:
-        n = min(16, os.cpu_count() or 1)
+    min(16, cores this process may run on); 1 = the calling thread only)."""
+    env = os.environ.get('BNPC_HOST_THREADS')
+    n = _threads_memo.get(env)
+    if n is None:
+        try:
+            n = int(env or 0)
+        except ValueError:
+            n = 0
+        if n < 1:
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                cores = os.cpu_count() or 1
+            n = min(16, cores)
+        _threads_memo[env] = n
     return n
+
+
+_mh_scratch = {}
+
+
+def _mh_buffers(G, M):
+    """Per-shape scratch of mh_batch that never leaves it (the draws, the log
+    acceptance ratios) and a pre-filled argument block: allocating and
+    describing them per call costs as much as a small batch itself."""
+    key = (os.getpid(), G, M)
+    buf = _mh_scratch.get(key)
+    if buf is None:
+        if len(_mh_scratch) > 16:
+            _mh_scratch.clear()
+        sd_idx = np.empty((G, M), dtype=np.int32)
+        U = np.empty((G, M))
+        u = np.empty((G, M))
+        A = np.empty((G, M))
+        args = MHArgs()
+        args.G, args.M = G, M
+        args.sd_idx, args.U, args.u = (x.ctypes.data for x in (sd_idx, U, u))
+        args.A = A.ctypes.data
+        buf = _mh_scratch[key] = (args, sd_idx, U, u, A)
+    return buf
 
 
 def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
@@ -345,23 +380,20 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
     the G rows of `old` (float32 G x M).  `draws` = (sd_idx, U, u) evaluates
     given draws instead of taking them from the global stream.  Returns
     (status, new, log_prob, declined, prior, (sd_idx, U, u)); status 1: only
-    the draws are valid."""
+    the draws are valid - they are views of scratch that the next call
+    overwrites."""
     old = np.ascontiguousarray(old, dtype=np.float32)
     G, M = old.shape
     n1 = np.ascontiguousarray(n1, dtype=np.int32)
     n0 = np.ascontiguousarray(n0, dtype=np.int32)
     sd = np.ascontiguousarray(sd, dtype=np.float64)
     assert n1.shape == n0.shape == (G, M)
-    if draws is None:
-        sd_idx = np.empty((G, M), dtype=np.int32)
-        U = np.empty((G, M))
-        u = np.empty((G, M))
-    else:
-        sd_idx = np.ascontiguousarray(draws[0], dtype=np.int32)
-        U = np.ascontiguousarray(draws[1], dtype=np.float64)
-        u = np.ascontiguousarray(draws[2], dtype=np.float64)
+    a, sd_idx, U, u, _ = _mh_buffers(G, M)
+    if draws is not None:
+        sd_idx[...] = draws[0]
+        U[...] = draws[1]
+        u[...] = draws[2]
     new = np.empty((G, M), dtype=np.float32)
-    A = np.empty((G, M))
     prior = np.empty((G, M)) if want_prior and not uniform else None
     log_prob = np.empty(G)
     declined = np.empty(G, dtype=np.int64)
@@ -370,14 +402,16 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
         kt = np.ascontiguousarray(known[0], dtype=np.float32)
         kp = np.ascontiguousarray(known[1], dtype=np.float64)
         assert kt.shape == kp.shape == (G, M)
-    a = MHArgs(G, M, old.ctypes.data, n1.ctypes.data, n0.ctypes.data,
-        sd.ctypes.data, sd.size, tmin, tmax, FP, FN, p, q, int(bool(uniform)),
-        int(bool(trans_prob)), kt.ctypes.data if kt is not None else None,
-        kp.ctypes.data if kp is not None else None, sd_idx.ctypes.data,
-        U.ctypes.data, u.ctypes.data, new.ctypes.data,
-        prior.ctypes.data if prior is not None else None, A.ctypes.data,
-        log_prob.ctypes.data, declined.ctypes.data,
-        host_threads() if threads is None else threads)
+    a.old_theta, a.n1, a.n0 = old.ctypes.data, n1.ctypes.data, n0.ctypes.data
+    a.sd, a.n_sd = sd.ctypes.data, sd.size
+    a.tmin, a.tmax, a.FP, a.FN, a.p, a.q = tmin, tmax, FP, FN, p, q
+    a.uniform_prior, a.trans_prob = int(bool(uniform)), int(bool(trans_prob))
+    a.known_theta = kt.ctypes.data if kt is not None else None
+    a.known_prior = kp.ctypes.data if kp is not None else None
+    a.new_theta = new.ctypes.data
+    a.prior_out = prior.ctypes.data if prior is not None else None
+    a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
+    a.threads = host_threads() if threads is None else threads
     status = C.c_int(0)
     lib = load()
     if draws is None:

@@ -72,8 +72,13 @@ public:
         job_ = &fn;
         pending_.store(n - 1, std::memory_order_relaxed);
         gen_ = (gen_ + 1) & 0xffffff;
-        word_.store((gen_ << 8) | (uint32_t)n, std::memory_order_release);
-        if (sleepers_.load(std::memory_order_acquire) > 0)
+        // store the word, THEN look for sleepers - in that order for every
+        // observer (a full fence: x86 may otherwise satisfy the load before
+        // the store is visible, while a worker that has just announced itself
+        // still reads the old word in futex_wait, and nobody wakes it)
+        word_.store((gen_ << 8) | (uint32_t)n, std::memory_order_seq_cst);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        if (sleepers_.load(std::memory_order_seq_cst) > 0)
             syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAKE_PRIVATE, INT_MAX,
                     nullptr, nullptr, 0);
         fn(0);
@@ -105,7 +110,7 @@ private:
             while ((w = word_.load(std::memory_order_acquire)) == seen) {
                 cpu_relax();
                 if ((++polls & 63) == 0 && now_ns() - t0 > spin_ns_) {
-                    sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                    sleepers_.fetch_add(1, std::memory_order_seq_cst);
                     // re-checked by the kernel: returns at once if the word
                     // has moved on
                     syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAIT_PRIVATE,
@@ -450,10 +455,17 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             if (t >= tasks) break;
             const int64_t g = t / chunks, ch = t - g * chunks;
             // the draws of this cluster are a few microseconds away at most
-            while (rows_ready.load(std::memory_order_acquire) <= g) {
+            // (a short spin; beyond it the waiters get out of the way of the
+            // thread that draws - they may share its core)
+            for (int spins = 0;
+                 rows_ready.load(std::memory_order_acquire) <= g; spins++) {
+                if (spins < 256) {
 #if defined(__x86_64__)
-                __builtin_ia32_pause();
+                    __builtin_ia32_pause();
 #endif
+                } else {
+                    std::this_thread::yield();
+                }
             }
             if (bail.load(std::memory_order_relaxed)) continue;
             const int64_t m0 = ch * BLK;

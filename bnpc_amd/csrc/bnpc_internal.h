@@ -82,72 +82,12 @@ static inline uint64_t mt_interval(bnpc_mt19937 *s, uint64_t max)
     return v;
 }
 
-// ---- bulk draws: the same stream as mt_double / mt_interval one by one, but
-// tempered straight out of the state block in loops without dependencies
-// (the compiler vectorises them) --------------------------------------------
-static inline uint32_t mt_temper(uint32_t y)
-{
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-
-// n x random_sample()
-static inline void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n)
-{
-    int64_t i = 0;
-    while (i < n) {
-        if (s->pos >= 624) mt_refill(s);
-        int64_t pairs = (624 - s->pos) / 2;
-        if (pairs > n - i) pairs = n - i;
-        if (pairs == 0) {               // a double straddles two blocks
-            out[i++] = mt_double(s);
-            continue;
-        }
-        const uint32_t *k = s->key + s->pos;
-        double *o = out + i;
-        for (int64_t j = 0; j < pairs; j++) {
-            const int32_t a = (int32_t)(mt_temper(k[2 * j]) >> 5);
-            const int32_t b = (int32_t)(mt_temper(k[2 * j + 1]) >> 6);
-            o[j] = (a * 67108864.0 + b) / 9007199254740992.0;
-        }
-        s->pos += (int32_t)(2 * pairs);
-        i += pairs;
-    }
-}
-
-// n x random_interval(max) for max < 2^32 (masked rejection on 32-bit draws)
-static inline void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max,
-                                      int32_t *out, int64_t n)
-{
-    if (max == 0) {
-        for (int64_t i = 0; i < n; i++) out[i] = 0;
-        return;
-    }
-    uint32_t mask = max;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
-    int64_t cnt = 0;
-    while (cnt < n) {
-        if (s->pos >= 624) mt_refill(s);
-        const uint32_t *k = s->key + s->pos;
-        const int avail = 624 - s->pos;
-        int j = 0;
-        // every word is written to the next free slot; the slot only advances
-        // when the word is accepted (no data-dependent branch)
-        for (; j < avail && cnt < n; j++) {
-            const uint32_t v = mt_temper(k[j]) & mask;
-            out[cnt] = (int32_t)v;
-            cnt += (v <= max);
-        }
-        s->pos += j;
-    }
-}
+// ---- bulk draws (bnpc_mt.cpp): the same stream as mt_double / mt_interval
+// one by one, tempered straight out of the state block in vectorised loops
+// (AVX-512 / AVX2 / baseline clones, picked at load time) -------------------
+void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n);
+void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max, int32_t *out,
+                        int64_t n);
 
 // One element of bnpc_log_diff_pi (include/bnpc_hip.h): complex exp of
 // (q - p, pi) = exp(q - p) * (cos pi, sin pi); the maximal term is split off
