@@ -39,8 +39,7 @@ for N, M, Ks in SHAPES:
         for r in range(ncell):
             om._calc_ll(data[[r]], theta)
         cpu = ncell * K / (time.perf_counter() - t0)
-        kw = min((8, 4, 2, 1), key=lambda w: (-(-K // w) * w) * (1 + 1 / w))
-        kern = 'k_ll8_asm' if kw == 8 else f'k_ll<{kw}>'
+        kern = ctx.last_launch()[0]
         print(f'| {N} | {M} | {K} | {kern} | {ms:.4f} | {ev:.3e} | '
             f'{ev * M:.3e} | {ev * M / 19.65e12 * 100:.1f} | '
             f'{B / ms / 1e6:.1f} | {cpu:.3e} | {ev / cpu:.0f}x |')
