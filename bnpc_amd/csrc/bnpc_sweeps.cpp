@@ -468,6 +468,17 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             best = gt ? v : best;
         }
 
+        // A posterior without a finite maximum (NaN likelihoods, every entry
+        // -inf) has no counterpart here: the reference would go through its
+        // FloatingPointError branches (CRP.py:94-98).  Nothing has been drawn
+        // for this cell yet; fail loudly instead of opening a cluster.
+        if (!hinted && !(best > -INFINITY && best < INFINITY)) {
+            bnpc_set_error("non-finite log posterior for cell %lld "
+                           "(maximum %g over %lld clusters)",
+                           (long long)cell, best, (long long)A);
+            return 4;
+        }
+
         // _normalize_log_probs (CRP.py:88-100) + choice(p=): cdf = cumsum(p);
         // cdf /= cdf[-1]; searchsorted(u, right).
         const double ptop = best;
@@ -647,6 +658,14 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
         const int64_t n_i = n - n_j - 1;
         const double p0 = ll[2 * cell] + (log((double)n_i) - lden);
         const double p1 = ll[2 * cell + 1] + (log((double)n_j) - lden);
+        if (!(p0 == p0) || !(p1 == p1) || (p0 == -INFINITY && p1 == -INFINITY)
+            || p0 == INFINITY || p1 == INFINITY) {
+            // (the reference's 2-entry fallback, CRP.py:110-114, is for
+            // overflow in exp, which max-shifting cannot produce)
+            bnpc_set_error("non-finite log posterior in the restricted scan "
+                           "(cell %lld: %g, %g)", (long long)cell, p0, p1);
+            return 4;
+        }
         // _normalize_log for two entries; first maximum wins ties
         double l0, l1;
         if (p1 > p0) {

@@ -331,3 +331,41 @@ def test_dominated_rows_with_thousands_of_clusters():
         new_columns)
     assert np.array_equal(ref[0], got[0]) and ref[1] == got[1]
     assert ref[2] == got[2] and ref[2] > 0
+
+
+def test_non_finite_posteriors_are_errors():
+    """NaN / all -inf log posteriors have no counterpart in the native loops
+    (the reference takes its FloatingPointError branches there): the calls
+    fail loudly, before any draw for the cell, instead of opening clusters."""
+    lib = _lib.load()
+    N, K, ld = 4, 2, 3
+    crp = np.append(0, O.CRP.log_CRP_prior(
+        np.append(np.arange(1, N + 1), 2.0), N, 2.0))
+    for poison in (np.nan, -np.inf):
+        ll = np.full((N, ld), -5.0)
+        ll[2, :] = poison
+        post_new = np.full(N, -9.0)
+        post_new[2] = poison
+        np.random.seed(1)
+        perm = _lib.as_i64(np.arange(N))
+        assignment = np.array([0, 0, 1, 1], dtype=np.int64)
+        col_of_id = np.array([0, 1, -1, -1], dtype=np.int64)
+        col_id = np.array([0, 1, -1], dtype=np.int64)
+        col_size = np.array([2, 2, 0], dtype=np.int64)
+        order = np.array([0, 1, 0], dtype=np.int64)
+        scratch = np.empty(2 * (ld + 1))
+        st = _lib.GibbsState(N, ld, K, K, 0, -1, N, -1)
+        with _lib.NumpyStream() as rng:
+            rc = lib.bnpc_gibbs_sweep(C.byref(st), rng, _lib.ptr(perm),
+                _lib.ptr(ll), _lib.ptr(post_new), _lib.ptr(crp),
+                _lib.ptr(assignment), _lib.ptr(col_of_id), _lib.ptr(col_id),
+                _lib.ptr(col_size), _lib.ptr(order), _lib.ptr(scratch))
+        assert rc == 4 and st.pos == 2
+        assert b'non-finite' in lib.bnpc_last_error()
+        rg = np.zeros(N, dtype=np.int64)
+        out = C.c_double(0)
+        llrg = np.full((N, 2), -3.0)
+        llrg[1] = poison
+        rc = lib.bnpc_rg_scan(None, 1, N, _lib.ptr(llrg), 2.0, _lib.ptr(rg),
+            _lib.ptr(np.zeros(N, dtype=np.int64)), C.byref(out))
+        assert rc == 4
