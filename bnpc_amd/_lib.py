@@ -55,6 +55,17 @@ class MHArgs(C.Structure):
         ('threads', C.c_int)]
 
 
+class LogAArgs(C.Structure):
+    """bnpc_accept_args (include/bnpc_hip.h)"""
+    _fields_ = [('G', _i64), ('M', _i64), ('new_theta', C.c_void_p),
+        ('old_theta', C.c_void_p), ('std', C.c_void_p), ('n1', C.c_void_p),
+        ('n0', C.c_void_p), ('fmin', C.c_double), ('fmax', C.c_double),
+        ('tmin', C.c_double), ('tmax', C.c_double), ('FP', C.c_double),
+        ('FN', C.c_double), ('p', C.c_double), ('q', C.c_double),
+        ('uniform_prior', C.c_int), ('clip', C.c_int), ('A', C.c_void_p),
+        ('sum', C.c_void_p), ('threads', C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
     'bnpc_last_error': (C.c_char_p, []),
@@ -110,6 +121,8 @@ SIGNATURES = {
     'bnpc_log_diff_pi': (C.c_int, [_pd, _pd, _i64, _pd]),
     'bnpc_mh_batch': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
         C.POINTER(MHArgs),
+        C.POINTER(C.c_int)]),
+    'bnpc_log_accept': (C.c_int, [C.c_void_p, C.POINTER(LogAArgs),
         C.POINTER(C.c_int)]),
     'bnpc_tn_logpdf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
         C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
@@ -422,6 +435,29 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
         check(lib.bnpc_mh_batch(C.addressof(kernels), None, C.byref(a),
             C.byref(status)), 'mh_batch')
     return status.value, new, log_prob, declined, prior, (sd_idx, U, u)
+
+
+def log_A(kernels, new, old, std, n1, n0, fmin, fmax, tmin, tmax, FP, FN, p,
+            q, uniform, clip, threads=None):
+    """bnpc_log_accept: (A (G, M), row sums (G,)) or None when the library leaves
+    an element to SciPy."""
+    new = np.ascontiguousarray(np.atleast_2d(new), dtype=np.float32)
+    old = np.ascontiguousarray(np.atleast_2d(old), dtype=np.float32)
+    std = np.ascontiguousarray(np.atleast_2d(std), dtype=np.float64)
+    n1 = np.ascontiguousarray(np.atleast_2d(n1), dtype=np.int32)
+    n0 = np.ascontiguousarray(np.atleast_2d(n0), dtype=np.int32)
+    G, M = new.shape
+    assert old.shape == std.shape == n1.shape == n0.shape == (G, M)
+    A = np.empty((G, M))
+    total = np.empty(G)
+    a = LogAArgs(G, M, new.ctypes.data, old.ctypes.data, std.ctypes.data,
+        n1.ctypes.data, n0.ctypes.data, fmin, fmax, tmin, tmax, FP, FN, p, q,
+        int(bool(uniform)), int(bool(clip)), A.ctypes.data, total.ctypes.data,
+        host_threads() if threads is None else threads)
+    status = C.c_int(0)
+    check(load().bnpc_log_accept(C.addressof(kernels), C.byref(a),
+        C.byref(status)), 'log_A')
+    return None if status.value else (A, total)
 
 
 def tn_logpdf_scalar(kernels, x, a, b, loc, scale):

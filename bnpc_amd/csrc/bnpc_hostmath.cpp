@@ -587,3 +587,125 @@ extern "C" int bnpc_tn_logpdf_scalar(const bnpc_host_kernels *k, double x,
     *out = ((a <= xs) && (xs <= b)) ? v : -INFINITY;
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// CRP._get_log_A (libs/CRP.py:347-383) for GIVEN new / old parameter rows and
+// proposal standard deviations - the transition-probability terms of the
+// split / merge ratios (libs/CRP.py:674-681, 777-799), which score a move to
+// parameters that already exist instead of proposing some.  Same arithmetic
+// as the batch above minus the draws, the ppf and the accept step.
+// ---------------------------------------------------------------------------
+namespace {
+
+bool logA_block(const bnpc_host_kernels *k, const bnpc_accept_args *a,
+                double betaln_pq, int64_t g, int64_t m0, int64_t m1)
+{
+    const int n = (int)(m1 - m0);
+    const size_t off = (size_t)g * a->M + m0;
+    const float *nw = a->new_theta + off, *old = a->old_theta + off;
+    const double *sd = a->std + off;
+    const int32_t *n1 = a->n1 + off, *n0 = a->n0 + off;
+    const float fmin32 = (float)a->fmin, fmax32 = (float)a->fmax;
+    const float tmin32 = (float)a->tmin, tmax32 = (float)a->tmax;
+    double lsd[BLK], t0[BLK], t1[BLK], t2[BLK], t3[BLK];
+    double fwd[BLK], rev[BLK], ll_new[BLK], ll_old[BLK];
+    uloop(k->np_log, k->np_log_data, sd, lsd, n);
+    for (int i = 0; i < n; i++) {
+        if (!(sd[i] > 0.0)) return false;
+        const double lo = (double)(fmin32 - old[i]) / sd[i];
+        const double hi = (double)(fmax32 - old[i]) / sd[i];
+        double mass;
+        if (!gauss_mass(k, lo, hi, &mass)) return false;
+        const double xs = (double)(nw[i] - old[i]) / sd[i];
+        double v = -(xs * xs) / 2.0 - k->norm_pdf_logC;
+        v = v - mass - lsd[i];
+        fwd[i] = ((lo <= xs) && (xs <= hi)) ? v : -INFINITY;
+
+        const double ar = (double)(tmin32 - nw[i]) / sd[i];
+        const double br = (double)(tmax32 - nw[i]) / sd[i];
+        double mass_r;
+        if (!gauss_mass(k, ar, br, &mass_r)) return false;
+        const double xr = (double)(old[i] - nw[i]) / sd[i];
+        double w = -(xr * xr) / 2.0 - k->norm_pdf_logC;
+        w = w - mass_r - lsd[i];
+        rev[i] = ((ar <= xr) && (xr <= br)) ? w : -INFINITY;
+    }
+    const double pFN1 = 1.0 - a->FN, pFP0 = 1.0 - a->FP;
+    for (int pass = 0; pass < 2; pass++) {
+        const float *th = pass == 0 ? nw : old;
+        for (int i = 0; i < n; i++) {
+            const double t64 = (double)th[i];
+            const double om64 = (double)(1.0f - th[i]);
+            t0[i] = t64 * pFN1 + om64 * a->FP;
+            t1[i] = t64 * a->FN + om64 * pFP0;
+        }
+        uloop(k->np_log, k->np_log_data, t0, t2, n);
+        uloop(k->np_log, k->np_log_data, t1, t3, n);
+        double *dst = pass == 0 ? ll_new : ll_old;
+        for (int i = 0; i < n; i++)
+            dst[i] = (double)n1[i] * t2[i] + (double)n0[i] * t3[i];
+    }
+    double *A = a->A + off;
+    for (int i = 0; i < n; i++) {
+        double pn = 0.0, po = 0.0;
+        if (!a->uniform_prior) {
+            pn = beta_logpdf1(k, nw[i], a->p, a->q, betaln_pq);
+            po = beta_logpdf1(k, old[i], a->p, a->q, betaln_pq);
+        }
+        double v = ll_new[i] + pn;
+        v = v - ll_old[i];
+        v = v - po;
+        v = v + rev[i];
+        v = v - fwd[i];
+        if (a->clip && v > 0.0) v = 0.0;
+        A[i] = v;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_args *a,
+                          int *status)
+{
+    if (check_kernels(k)) return 2;
+    if (!a || !status || a->G < 0 || a->M < 1 || !a->new_theta
+        || !a->old_theta || !a->std || !a->n1 || !a->n0 || !a->A || !a->sum) {
+        bnpc_set_error("bad argument: log_A");
+        return 2;
+    }
+    *status = 0;
+    const double bl = a->uniform_prior ? 0.0 : k->betaln(a->p, a->q, 0);
+    const int64_t chunks = (a->M + BLK - 1) / BLK, tasks = a->G * chunks;
+    int threads = a->threads;
+    if (threads > tasks) threads = (int)tasks;
+    if (tasks * BLK < 2048) threads = 1;
+    std::atomic<int64_t> next(0);
+    std::atomic<int> bail(0);
+    auto work = [&](int) {
+        for (;;) {
+            const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
+            if (t >= tasks) break;
+            if (bail.load(std::memory_order_relaxed)) continue;
+            const int64_t g = t / chunks, m0 = (t - g * chunks) * BLK;
+            const int64_t m1 = m0 + BLK < a->M ? m0 + BLK : a->M;
+            if (!logA_block(k, a, bl, g, m0, m1))
+                bail.store(1, std::memory_order_relaxed);
+        }
+    };
+    if (threads > 1)
+        team_for(threads)->run(threads, work);
+    else
+        work(0);
+    if (bail.load()) {
+        *status = 1;
+        return 0;
+    }
+    for (int64_t g = 0; g < a->G; g++) {
+        const double *A = a->A + g * a->M;
+        double s = A[0];
+        for (int64_t m = 1; m < a->M; m++) s += A[m];       // np.cumsum order
+        a->sum[g] = s;
+    }
+    return 0;
+}

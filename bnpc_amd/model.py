@@ -166,6 +166,23 @@ def _native_batch_is_exact(table):
                             np.cumsum(want[1], axis=1)[:, -1])
                     if want[3] is not None:
                         ok &= np.array_equal(got[4], want[3])
+            # log acceptance ratios of given rows (split / merge ratios)
+            new_rows = np.clip(rng.uniform(size=(2, M)), TMIN, TMAX) \
+                .astype(np.float32)
+            new_rows[:, :30] = np.float32(TMIN)
+            new_rows[:, 30:60] = np.float32(TMAX)
+            for fmin, fmax in ((TMIN, TMAX), (0, 1)):
+                for clip in (False, True):
+                    a_ = (fmin - old[:2]) / std[:2]
+                    b_ = (fmax - old[:2]) / std[:2]
+                    ref = probe._get_log_A(new_rows, old[:2], None, a_, b_,
+                        std[:2], clip, counts=(n1[:2], n0[:2]))
+                    got = _lib.log_A(table, new_rows, old[:2], std[:2],
+                        n1[:2], n0[:2], fmin, fmax, TMIN, TMAX, FP, FN, p, q,
+                        probe.beta_prior_uniform, clip, threads=2)
+                    ok &= got is not None and np.array_equal(got[0], ref) \
+                        and np.array_equal(got[1],
+                            np.cumsum(ref, axis=1)[:, -1])
             # scalar truncated-normal densities (error-rate moves / priors)
             for x, lo, sc in ((0.013, 0.01, 0.005), (0.19, 0.2, 0.15),
                     (0.0004, 0.001, 0.0005), (0.2, 0.2, 0.1), (1.5, 0.2, 0.1),
@@ -955,6 +972,26 @@ class CRP:
             return np.clip(A, a_min=None, a_max=0)
         return A
 
+    def _log_A_sum(self, new_params, old_params, std, counts, fmin, fmax):
+        """np.cumsum(_get_log_A(new, old, None, (fmin - old) / std,
+        (fmax - old) / std, std, True, counts))[-1] per row: natively when
+        the start-up comparison allows, else through the array path."""
+        table = _native_kernels()
+        if table is not None:
+            res = _lib.log_A(table, new_params, old_params, std, counts[0],
+                counts[1], fmin, fmax, TMIN, TMAX, self.FP, self.FN, self.p,
+                self.q, self.beta_prior_uniform, True)
+            if res is not None:
+                return res[1]
+        new_params = np.atleast_2d(new_params)
+        old_params = np.atleast_2d(old_params)
+        std = np.atleast_2d(std)
+        a = (fmin - old_params) / std
+        b = (fmax - old_params) / std
+        A = self._get_log_A(new_params, old_params, None, a, b, std, True,
+            counts=(np.atleast_2d(counts[0]), np.atleast_2d(counts[1])))
+        return np.cumsum(A, axis=1)[:, -1]
+
     # ------------------------------------------------------------- DP alpha
     def update_DP_alpha(self):
         """libs/CRP.py:386-410"""
@@ -1242,11 +1279,9 @@ class CRP:
         """libs/CRP.py:668-682"""
         gs_split = self._rg_scan_split(cells, trans_prob=True)
         std = np.random.choice(self.param_proposal_sd, size=self.muts_total)
-        a = (TMIN - self.rg_params_merge) / std
-        b = (TMAX - self.rg_params_merge) / std
-        gs_merge = np.cumsum(self._get_log_A(
+        gs_merge = self._log_A_sum(
             self.parameters[self.assignment[cells[0]]], self.rg_params_merge,
-            cells, a, b, std, True, counts=self._rg_all_counts(cells)))[-1]
+            std, self._rg_all_counts(cells), TMIN, TMAX)[0]
         return gs_merge - gs_split
 
     def _get_trans_prob_ratio_merge(self, cells):
@@ -1324,19 +1359,16 @@ class CRP:
         """libs/CRP.py:777-820"""
         std = np.random.choice(self.param_proposal_sd,
             size=(2, self.muts_total))
-        a = (0 - self.rg_params_split) / std
-        b = (1 - self.rg_params_split) / std
 
         i, j, S = cells[0], cells[-1], cells[1:-1]
         cl_i = self.assignment[i]
         cl_j = self.assignment[j]
         cnt = self._rg_split_counts(cells)
-        prob_i = np.cumsum(self._get_log_A(
-            self.parameters[cl_i], self.rg_params_split[0], None,
-            a[0], b[0], std[0], True, counts=cnt[0]))[-1]
-        prob_j = np.cumsum(self._get_log_A(
-            self.parameters[cl_j], self.rg_params_split[1], None,
-            a[1], b[1], std[1], True, counts=cnt[1]))[-1]
+        # both rows in one batch; forward bounds 0 / 1 (libs/CRP.py:779-780)
+        prob_i, prob_j = self._log_A_sum(
+            self.parameters[[cl_i, cl_j]], self.rg_params_split, std,
+            (np.stack([cnt[0][0], cnt[1][0]]),
+                np.stack([cnt[0][1], cnt[1][1]])), 0, 1)
 
         if S.size == 0:
             return prob_i + prob_j + 0.0

@@ -330,6 +330,27 @@ typedef struct bnpc_mh_args {
 int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                   const bnpc_mh_args *a, int *status);
 
+/* CRP._get_log_A (libs/CRP.py:347-383) for GIVEN rows: the log acceptance
+ * ratio of moving old -> new under proposal standard deviations std, forward
+ * truncation bounds (fmin, fmax) around old, reverse bounds (tmin, tmax)
+ * around new (libs/CRP.py:674-681: TMIN / TMAX both; :777-799: 0 / 1 forward),
+ * A[g, m] clipped at 0 if clip, sum[g] its sum in index order.  Same kernel
+ * table and *status convention as bnpc_mh_batch. */
+typedef struct bnpc_accept_args {
+    int64_t G, M;
+    const float *new_theta, *old_theta;     /* G x M */
+    const double *std;                      /* G x M */
+    const int32_t *n1, *n0;                 /* G x M column counts */
+    double fmin, fmax, tmin, tmax;
+    double FP, FN, p, q;
+    int uniform_prior, clip;
+    double *A;                              /* G x M */
+    double *sum;                            /* G */
+    int threads;
+} bnpc_accept_args;
+int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_args *a,
+               int *status);
+
 /* Beta(p, q) log-density of n float32 values (scipy.stats.beta._logpdf with
  * the public wrapper's support handling), re-using known_prior[i] where
  * known_theta[i] has the bits of x[i]; *seq_sum (optional) receives the sum
