@@ -790,43 +790,71 @@ __device__ __forceinline__ unsigned long long readlane_u64(
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// KC = clusters per wave: 2 shares the mask fetch and the EXEC writes between
+// two independent add chains (the launch clusters of a split: K = 2) and
+// hides each chain's add latency behind the other; 1 otherwise.
+template <int KC>
 __global__ __launch_bounds__(256) void k_ll_seq(
     const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
     long long nblk, const double *__restrict__ L1,
-    const double *__restrict__ L0, long long ldo, double *__restrict__ out)
+    const double *__restrict__ L0, int K, long long ldo,
+    double *__restrict__ out)
 {
-    extern __shared__ double2 seq_tab[];    // [Mpad + 8] {L1, L0} of cluster k
-    const int k = blockIdx.y;
-    for (int m = threadIdx.x; m < Mpad + 8; m += 256)
-        seq_tab[m] = (m < M)
+    // [KC][Mpad + 8] {L1, L0} of clusters k0 .. k0 + KC - 1
+    extern __shared__ double2 seq_tab[];
+    const int k0 = blockIdx.y * KC;
+    const int stride = Mpad + 8;
+    for (int i = threadIdx.x; i < KC * stride; i += 256) {
+        const int kk = i / stride, m = i - kk * stride;
+        const int k = k0 + kk;
+        seq_tab[i] = (m < M && k < K)
             ? make_double2(L1[(size_t)k * M + m], L0[(size_t)k * M + m])
             : make_double2(0.0, 0.0);
+    }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const long long blk = (long long)blockIdx.x * 4 + wave;
     if (blk >= nblk) return;            // whole wave, after the barrier
     const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
-    double acc = 0.0;
+    double acc[KC];
+#pragma unroll
+    for (int kk = 0; kk < KC; kk++) acc[kk] = 0.0;
     ulonglong2 cur = mk[lane];
     // table pairs of 8 mutations at a time, ping-pong: the LDS reads of the
     // next 8 are in flight while the masked adds of these 8 issue (the asm
     // blocks keep program order, so the prefetch is spelled out)
-    double2 ta[8], tb[8];
+    double2 ta[KC][8], tb[KC][8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) ta[u] = seq_tab[u];
-#define SEQ_STEP(T, J)                                                        \
+    for (int kk = 0; kk < KC; kk++)
+#pragma unroll
+        for (int u = 0; u < 8; u++) ta[kk][u] = seq_tab[kk * stride + u];
+#define SEQ_STEP(T, U, J)                                                     \
     {                                                                         \
         const unsigned long long ones = readlane_u64(cur.x, (J));             \
         const unsigned long long zeros = readlane_u64(cur.y, (J));            \
-        asm volatile(                                                         \
-            "s_mov_b64 exec, %1\n\t"                                          \
-            "v_add_f64 %0, %0, %3\n\t"                                        \
-            "s_mov_b64 exec, %2\n\t"                                          \
-            "v_add_f64 %0, %0, %4\n\t"                                        \
-            "s_mov_b64 exec, -1"                                              \
-            : "+v"(acc)                                                       \
-            : "s"(ones), "s"(zeros), "v"((T).x), "v"((T).y));                 \
+        if constexpr (KC == 1) {                                              \
+            asm volatile(                                                     \
+                "s_mov_b64 exec, %1\n\t"                                      \
+                "v_add_f64 %0, %0, %3\n\t"                                    \
+                "s_mov_b64 exec, %2\n\t"                                      \
+                "v_add_f64 %0, %0, %4\n\t"                                    \
+                "s_mov_b64 exec, -1"                                          \
+                : "+v"(acc[0])                                                \
+                : "s"(ones), "s"(zeros), "v"((T)[0][U].x), "v"((T)[0][U].y)); \
+        } else {                                                              \
+            asm volatile(                                                     \
+                "s_mov_b64 exec, %2\n\t"                                      \
+                "v_add_f64 %0, %0, %4\n\t"                                    \
+                "v_add_f64 %1, %1, %6\n\t"                                    \
+                "s_mov_b64 exec, %3\n\t"                                      \
+                "v_add_f64 %0, %0, %5\n\t"                                    \
+                "v_add_f64 %1, %1, %7\n\t"                                    \
+                "s_mov_b64 exec, -1"                                          \
+                : "+v"(acc[0]), "+v"(acc[KC - 1])                             \
+                : "s"(ones), "s"(zeros), "v"((T)[0][U].x), "v"((T)[0][U].y),  \
+                  "v"((T)[KC - 1][U].x), "v"((T)[KC - 1][U].y));              \
+        }                                                                     \
     }
     for (int m0 = 0; m0 < Mpad; m0 += 64) {
         ulonglong2 nxt = make_ulonglong2(0ull, 0ull);
@@ -834,19 +862,29 @@ __global__ __launch_bounds__(256) void k_ll_seq(
 #pragma unroll
         for (int sb = 0; sb < 8; sb += 2) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) tb[u] = seq_tab[m0 + 8 * (sb + 1) + u];
+            for (int kk = 0; kk < KC; kk++)
 #pragma unroll
-            for (int u = 0; u < 8; u++) SEQ_STEP(ta[u], 8 * sb + u)
+                for (int u = 0; u < 8; u++)
+                    tb[kk][u] = seq_tab[kk * stride + m0 + 8 * (sb + 1) + u];
 #pragma unroll
-            for (int u = 0; u < 8; u++) ta[u] = seq_tab[m0 + 8 * (sb + 2) + u];
+            for (int u = 0; u < 8; u++) SEQ_STEP(ta, u, 8 * sb + u)
 #pragma unroll
-            for (int u = 0; u < 8; u++) SEQ_STEP(tb[u], 8 * (sb + 1) + u)
+            for (int kk = 0; kk < KC; kk++)
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    ta[kk][u] = seq_tab[kk * stride + m0 + 8 * (sb + 2) + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) SEQ_STEP(tb, u, 8 * (sb + 1) + u)
         }
         cur = nxt;
     }
 #undef SEQ_STEP
     const long long slot = blk * 64 + lane;
-    if (slot < n) out[(size_t)slot * ldo + k] = acc;
+    if (slot < n) {
+#pragma unroll
+        for (int kk = 0; kk < KC; kk++)
+            if (k0 + kk < K) out[(size_t)slot * ldo + k0 + kk] = acc[kk];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1492,19 +1530,29 @@ static int issue_seq(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                      double *d_out)
 {
     static bool lds_raised = false;
-    const size_t lds = (size_t)(c->Mpad + 8) * sizeof(double2);
-    if (lds > 48 * 1024 && !lds_raised) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq,
+    if (!lds_raised) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq<1>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SEQ_LDS_MAX));
+        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq<2>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)SEQ_LDS_MAX));
         lds_raised = true;
     }
-    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)K);
-    snprintf(c->last_name, sizeof(c->last_name), "k_ll_seq");
-    hipLaunchKernelGGL(k_ll_seq, grid, dim3(256), lds, c->stream,
-                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
-                       (long long)v.n, (long long)v.nblk, c->tab_src,
-                       c->tab_src + (size_t)K * c->M, (long long)ldo, d_out);
+    const size_t one = (size_t)(c->Mpad + 8) * sizeof(double2);
+    // two clusters per wave when there are at least two and both tables fit
+    const int KC = (K >= 2 && 2 * one <= SEQ_LDS_MAX) ? 2 : 1;
+    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)((K + KC - 1) / KC));
+    snprintf(c->last_name, sizeof(c->last_name), "k_ll_seq<%d>", KC);
+#define LAUNCH_SEQ(KC_)                                                       \
+    hipLaunchKernelGGL(k_ll_seq<KC_>, grid, dim3(256), KC_ * one, c->stream,  \
+                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,     \
+                       (long long)v.n, (long long)v.nblk, c->tab_src,         \
+                       c->tab_src + (size_t)K * c->M, (int)K, (long long)ldo, \
+                       d_out)
+    if (KC == 2) LAUNCH_SEQ(2);
+    else LAUNCH_SEQ(1);
+#undef LAUNCH_SEQ
     HIPCHK(hipGetLastError());
     return 0;
 }
