@@ -95,6 +95,7 @@ struct Tunables {
     int64_t zc_sweep_max = 0;       // the sweep's matrix (pinned) in place
     int mask_counts_max = 64;       // segments for the mask-popcount counts
     int seq_kernel = 1;             // k_ll_seq for caller-built tables
+    int seq_kc = 1;                 // clusters per wave in k_ll_seq
     int fused_small = 1;            // one-launch small-K likelihood
 };
 
@@ -123,6 +124,7 @@ static void read_tunables(Tunables &t)
     t.zc_sweep_max = (int64_t)env_int("BNPC_ZC_SWEEP_KB", 0) << 10;
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 1);
+    t.seq_kc = env_int("BNPC_SEQ_KC", 1);
     t.fused_small = env_int("BNPC_FUSED_SMALL", 1);
 }
 
@@ -1540,8 +1542,12 @@ static int issue_seq(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         lds_raised = true;
     }
     const size_t one = (size_t)(c->Mpad + 8) * sizeof(double2);
-    // two clusters per wave when there are at least two and both tables fit
-    const int KC = (K >= 2 && 2 * one <= SEQ_LDS_MAX) ? 2 : 1;
+    // one cluster per wave; BNPC_SEQ_KC=2 puts two on a wave (shared mask
+    // fetch and EXEC writes: measured SLOWER, 44 us against 34 us at 500 x 2
+    // x 1000 - the longer instruction stream of the one wave outweighs the
+    // sharing; kept selectable for the A/B)
+    const int KC = (c->tun.seq_kc == 2 && K >= 2 && 2 * one <= SEQ_LDS_MAX)
+        ? 2 : 1;
     dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)((K + KC - 1) / KC));
     snprintf(c->last_name, sizeof(c->last_name), "k_ll_seq<%d>", KC);
 #define LAUNCH_SEQ(KC_)                                                       \
