@@ -697,3 +697,54 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
     *log_prob = sum;
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// One intermediate restricted-Gibbs scan of a split/merge move as ONE call
+// (CRP._rg_scan_split followed by CRP._rg_scan_merge, libs/CRP.py:570-606,
+// as called from run_rg_nc :535-537): the log-likelihoods of the move's cells
+// under the two launch clusters (device), the sequential 2-way assignment
+// scan (here, on the stream), the column counts of the two launch clusters for
+// the NEW assignment (device; the merged cluster's are their sum), and the MH
+// update of the three parameter rows (bnpc_mh_batch).  Nothing here is new
+// arithmetic - it is the four calls the binding used to make one by one,
+// without the interpreter in between.
+// ---------------------------------------------------------------------------
+extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                                 bnpc_mt19937 *rng, int view, int64_t n,
+                                 int64_t *rg_assignment, double DP_a,
+                                 const bnpc_mh_args *mh, int32_t *n1,
+                                 int32_t *n0, int *status)
+{
+    if (!ctx || !k || !rng || !rg_assignment || !mh || !n1 || !n0 || !status
+        || n < 3 || mh->G != 3 || mh->n1 != n1 || mh->n0 != n0) {
+        bnpc_set_error("bad argument: rg_scan_step");
+        return 2;
+    }
+    *status = 0;
+    const int64_t S = n - 2, M = mh->M;
+    static thread_local std::vector<double> ll;
+    static thread_local std::vector<int64_t> labels;
+    ll.resize((size_t)n * 2);
+    labels.resize((size_t)n);
+
+    // rows 0 and 1 of the parameter block are the launch clusters
+    int rc = bnpc_ll_theta(ctx, view, mh->old_theta, 2, mh->FP, mh->FN,
+                           ll.data(), 0);
+    if (rc) return rc;
+    double log_prob = 0.0;
+    rc = bnpc_rg_scan(rng, 0, S, ll.data() + 2, DP_a, rg_assignment, nullptr,
+                      &log_prob);
+    if (rc) return rc;
+
+    // anchors: first slot -> cluster i, last slot -> cluster j
+    labels[0] = 0;
+    for (int64_t s = 0; s < S; s++) labels[s + 1] = rg_assignment[s] ? 1 : 0;
+    labels[n - 1] = 1;
+    rc = bnpc_view_counts(ctx, view, labels.data(), 2, n1, n0);
+    if (rc) return rc;
+    for (int64_t m = 0; m < M; m++) {
+        n1[2 * M + m] = n1[m] + n1[M + m];
+        n0[2 * M + m] = n0[m] + n0[M + m];
+    }
+    return bnpc_mh_batch(k, rng, mh, status);
+}

@@ -838,7 +838,8 @@ class CRP:
                 lambda t: fastdist.beta_logpdf(t, self.p, self.q), theta)
         return np.cumsum(density.ravel())[-1]
 
-    def _mh_batch(self, old, counts, trans_prob, known=None, keep_prior=None):
+    def _mh_batch(self, old, counts, trans_prob, known=None, keep_prior=None,
+                draws=None):
         """MH_cluster_params (libs/CRP.py:314-344) for G clusters at once.
 
         old: (G, M) float32; counts: (n1, n0) each (G, M).  RNG order per
@@ -851,8 +852,7 @@ class CRP:
         the result is remembered."""
         G, M = old.shape
         n1, n0 = counts
-        draws = None
-        table = _native_kernels()
+        table = _native_kernels() if draws is None else None
         if table is not None:
             status, new, prob, declined, prior, draws = _lib.mh_batch(
                 table, old, n1, n0, self.param_proposal_sd, TMIN, TMAX,
@@ -1183,6 +1183,8 @@ class CRP:
         and of the merged cluster.  No draw separates the three MH updates and
         they do not depend on each other, so they are ONE batch (rows in the
         reference's order i, j, merge)."""
+        if self._rg_scan_fused(cells):
+            return
         if cells.size != 2:
             self._rg_scan_assign(cells)
         ci, cj = self._rg_split_counts(cells)
@@ -1193,6 +1195,35 @@ class CRP:
         new, _, _ = self._mh_batch(old, counts, False)
         self.rg_params_split = new[:2]
         self.rg_params_merge = new[2]
+
+    def _rg_scan_fused(self, cells):
+        """The whole intermediate scan as ONE native call (bnpc_rg_scan_step:
+        device sums, assignment scan, counts, parameter batch).  False if it
+        does not apply - tiny moves, no native kernel table, a view that is
+        not this move's - and nothing was drawn."""
+        table = _native_kernels()
+        ctx = self._dev()
+        view = getattr(self, '_rg_view', None)
+        if table is None or cells.size <= 4 or not getattr(ctx, '_h', None) \
+                or view is None or view.size != cells.size \
+                or not np.array_equal(view, cells) \
+                or os.environ.get('BNPC_RG_FUSED', '1') == '0':
+            return False
+        rg = np.array(self.rg_assignment, dtype=np.int64, order='C')
+        theta3 = np.concatenate([self.rg_params_split,
+            self.rg_params_merge[None, :]]).astype(np.float32)
+        status, new, n1, n0, draws = _lib.rg_scan_step(ctx, table, VIEW_MOVE,
+            cells.size, rg, self.DP_a, theta3, self.param_proposal_sd, TMIN,
+            TMAX, self.FP, self.FN, self.p, self.q, self.beta_prior_uniform)
+        self.rg_assignment = rg
+        self._rg_counts = (rg.tobytes(), [
+            (n1[g].astype(np.float64), n0[g].astype(np.float64))
+            for g in range(2)])
+        if status != 0:     # the batch left an element to SciPy
+            new, _, _ = self._mh_batch(theta3, (n1, n0), False, draws=draws)
+        self.rg_params_split = new[:2]
+        self.rg_params_merge = new[2]
+        return True
 
     def _rg_scan_merge(self, cells, trans_prob=False):
         """libs/CRP.py:581-587"""

@@ -351,6 +351,20 @@ typedef struct bnpc_accept_args {
 int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_args *a,
                int *status);
 
+/* One intermediate restricted-Gibbs scan of a split/merge move in one call
+ * (libs/CRP.py:535-537 -> :570-606): log-likelihoods of the view's slots
+ * under the parameter rows 0 and 1 of mh->old_theta (device), the 2-way
+ * assignment scan over slots 1..n-2 on the stream (bnpc_rg_scan mode 0),
+ * column counts of the two launch clusters for the new assignment (slot 0
+ * belongs to the first, slot n-1 to the second; row 2 = their sum) into n1 /
+ * n0 (3 x M, the buffers mh->n1 / mh->n0 point at), then bnpc_mh_batch on the
+ * three rows (mh->G == 3).  *status as bnpc_mh_batch. */
+int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                      bnpc_mt19937 *rng, int view, int64_t n,
+                      int64_t *rg_assignment, double DP_a,
+                      const bnpc_mh_args *mh, int32_t *n1, int32_t *n0,
+                      int *status);
+
 /* Beta(p, q) log-density of n float32 values (scipy.stats.beta._logpdf with
  * the public wrapper's support handling), re-using known_prior[i] where
  * known_theta[i] has the bits of x[i]; *seq_sum (optional) receives the sum

@@ -797,3 +797,55 @@ def test_context_from_bit_planes_equals_context_from_matrix(tmp_path):
     bad[0, 0, 0] |= 1
     with pytest.raises(RuntimeError, match='inconsistent'):
         _lib.Context(data=B.BitPlanes(bad, M))
+
+
+def test_sweep_hint_from_the_device_is_the_rows_top_two():
+    """bnpc_ll_theta_pinned_top2: per cell the two largest entries of
+    ll + prior and the FIRST column of the largest, computed from the very
+    matrix that is returned (ties included)."""
+    rng = np.random.RandomState(12)
+    N, M = 700, 130
+    data = (rng.random_sample((N, M)) < 0.3).astype(float)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    ctx = _lib.Context(data=data)
+    for K in (1, 2, 13, 64):
+        theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+            .astype(np.float32)
+        if K > 2:
+            theta[2] = theta[0]             # an exact tie between columns
+        prior = -rng.uniform(0, 9, size=K)
+        if K > 2:
+            prior[2] = prior[0]
+        ll, hint = ctx.ll_theta_pinned_top2(0, theta, .01, .2, K + 3, prior)
+        assert np.array_equal(ll[:, :K], ctx.ll_theta(0, theta, .01, .2))
+        post = ll[:, :K] + prior[None, :]
+        col = np.argmax(post, axis=1)       # first maximum
+        assert np.array_equal(hint['col'], col)
+        assert np.array_equal(hint['best'], post[np.arange(N), col])
+        rest = post.copy()
+        rest[np.arange(N), col] = -np.inf
+        assert np.array_equal(hint['second'], rest.max(axis=1))
+    theta = np.clip(rng.uniform(size=(65, M)), 1e-5, 1 - 1e-5) \
+        .astype(np.float32)
+    assert ctx.ll_theta_pinned_top2(0, theta, .01, .2, 70, np.zeros(65))[1] \
+        is None
+    ctx.close()
+
+
+def test_fused_restricted_scan_changes_nothing(monkeypatch):
+    """bnpc_rg_scan_step (device sums + assignment scan + counts + parameter
+    batch in one native call) against the same scan made call by call: a
+    split/merge-heavy chain is identical either way, and identical to the
+    oracle's."""
+    data = H.synth(9, 600, 150, 5, 0.15)
+    kw = dict(sm_prob=.6, sm_steps=4, eup=.25)
+    runs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('BNPC_RG_FUSED', fused)
+        runs.append(H.run_chain(H.make(P, 'learn', data), 30, 5, **kw))
+    ro = H.run_chain(H.make(O, 'learn', data), 30, 5, **kw)
+    for r in runs:
+        assert np.array_equal(r['assignments'], ro['assignments'])
+        np.testing.assert_allclose(r['ML'], ro['ML'], rtol=1e-9)
+        assert np.array_equal(r['params'], ro['params'])
+    assert np.array_equal(runs[0]['ML'], runs[1]['ML'])

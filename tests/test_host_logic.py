@@ -725,3 +725,34 @@ def test_sweep_hint_is_used_and_falls_back():
     close['second'] = close['best'] - 1.0   # a runner-up 1 nat away: scan
     got = sweep(ll, close)
     assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+
+
+def test_given_row_acceptance_ratios_equal_the_array_path(monkeypatch):
+    """bnpc_log_accept (the transition terms of the split / merge ratios)
+    against CRP._get_log_A through SciPy, both truncation settings, with the
+    native path switched off as well."""
+    from bnpc_amd import _lib
+    rng = np.random.RandomState(5)
+    M = 300
+    data = synth(3, 50, M, 3, 0.1)
+    m = make(P, 'fixed', data)
+    new = np.clip(rng.uniform(size=(2, M)), P.TMIN, P.TMAX).astype(np.float32)
+    old = np.clip(rng.uniform(size=(2, M)), P.TMIN, P.TMAX).astype(np.float32)
+    new[:, :20] = np.float32(P.TMIN)
+    old[:, 10:40] = np.float32(P.TMAX)
+    std = rng.choice(m.param_proposal_sd, size=(2, M))
+    counts = (rng.randint(0, 30, size=(2, M)), rng.randint(0, 30, size=(2, M)))
+    for fmin, fmax in ((P.TMIN, P.TMAX), (0, 1)):
+        a, b = (fmin - old) / std, (fmax - old) / std
+        want = np.cumsum(m._get_log_A(new, old, None, a, b, std, True,
+            counts=counts), axis=1)[:, -1]
+        monkeypatch.setenv('BNPC_NATIVE_MH', '1')
+        P._NATIVE.clear()
+        assert P._native_kernels() is not None
+        assert np.array_equal(m._log_A_sum(new, old, std, counts, fmin, fmax),
+            want)
+        monkeypatch.setenv('BNPC_NATIVE_MH', '0')
+        P._NATIVE.clear()
+        assert np.array_equal(m._log_A_sum(new, old, std, counts, fmin, fmax),
+            want)
+    P._NATIVE.clear()
