@@ -817,6 +817,7 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         if K > 2:
             prior[2] = prior[0]
         ll, hint = ctx.ll_theta_pinned_top2(0, theta, .01, .2, K + 3, prior)
+        ll, hint = ll.copy(), hint.copy()   # views, valid until the next call
         assert np.array_equal(ll[:, :K], ctx.ll_theta(0, theta, .01, .2))
         post = ll[:, :K] + prior[None, :]
         col = np.argmax(post, axis=1)       # first maximum
