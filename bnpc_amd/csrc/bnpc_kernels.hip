@@ -168,6 +168,8 @@ struct bnpc_ctx {
     // small results written by kernels straight into pinned host memory
     void *zc_out = nullptr;
     char *zc_out_dev = nullptr;
+    void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
+    size_t hint_cap = 0;
     // where the kernels of the current call read their inputs from: device
     // scratch filled by a DMA copy, or the staging arena in place
     const float *theta_src = nullptr;
@@ -1297,6 +1299,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->zc_out) (void)hipHostFree(c->zc_out);
+    if (c->hint_pin) (void)hipHostFree(c->hint_pin);
     for (int s = 0; s < 2; s++) {
         if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
         if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
@@ -1729,10 +1732,24 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
     *top2 = nullptr;
     if (ldo == 0) ldo = K;
     const int64_t n = c->views[view].n;
+    // the hints of all slots, written in place into pinned host memory of
+    // their own: they must outlive the calls made DURING the sweep (a column
+    // for a cluster opened half-way), which use the shared result buffer
     void *zc_dev = nullptr;
-    // the hints of all slots, written in place into pinned host memory
-    bnpc_top2 *hint = n ? (bnpc_top2 *)zc_result(
-        c, (size_t)n * sizeof(bnpc_top2), &zc_dev) : nullptr;
+    bnpc_top2 *hint = nullptr;
+    if (n && c->tun.zero_copy) {
+        const size_t need = (size_t)n * sizeof(bnpc_top2);
+        if (need > c->hint_cap) {
+            if (c->hint_pin) HIPCHK(hipHostFree(c->hint_pin));
+            c->hint_pin = nullptr;
+            c->hint_cap = 0;
+            HIPCHK(hipHostMalloc(&c->hint_pin, need + need / 4,
+                                 hipHostMallocDefault));
+            c->hint_cap = need + need / 4;
+        }
+        if (hipHostGetDevicePointer(&zc_dev, c->hint_pin, 0) == hipSuccess)
+            hint = (bnpc_top2 *)c->hint_pin;
+    }
     // the matrix itself as bnpc_ll_theta_pinned, minus its final wait
     ARGCHK(theta, "theta is NULL");
     ARGCHK(ldo >= K, "ldo smaller than K");

@@ -817,8 +817,15 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         if K > 2:
             prior[2] = prior[0]
         ll, hint = ctx.ll_theta_pinned_top2(0, theta, .01, .2, K + 3, prior)
-        ll, hint = ll.copy(), hint.copy()   # views, valid until the next call
+        live_ll, live_hint = ll, hint
+        ll, hint = ll.copy(), hint.copy()
         assert np.array_equal(ll[:, :K], ctx.ll_theta(0, theta, .01, .2))
+        # both views survive the calls a sweep makes while it uses them (a
+        # column for a cluster opened half-way, counts, totals)
+        ctx.ll_theta(0, theta[:1], .02, .3)
+        ctx.colcounts_by_label(rng.randint(0, 3, N), np.arange(3))
+        assert np.array_equal(live_ll, ll, equal_nan=True)
+        assert np.array_equal(live_hint, hint)
         post = ll[:, :K] + prior[None, :]
         col = np.argmax(post, axis=1)       # first maximum
         assert np.array_equal(hint['col'], col)
