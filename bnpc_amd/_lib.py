@@ -389,6 +389,22 @@ def _mh_buffers(G, M):
     return buf
 
 
+def threads_for(elements):
+    """Team ranks for a batch of `elements` matrix entries: the configured
+    team; a batch of 100k+ entries (configs 4 and 5: 1.6 ms on 16 threads)
+    takes up to twice as many unless BNPC_HOST_THREADS pins the number
+    (measured at 50 x 5000: 16 threads 2.9 ms, 32 threads 1.6 ms; at 10 x 1000
+    more than 16 gain nothing)."""
+    n = host_threads()
+    if elements >= 100000 and os.environ.get('BNPC_HOST_THREADS') is None:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 1
+        n = max(n, min(32, cores // 2))
+    return n
+
+
 def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
             trans_prob, known=None, want_prior=False, draws=None,
             threads=None):
@@ -427,7 +443,7 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
     a.new_theta = new.ctypes.data
     a.prior_out = prior.ctypes.data if prior is not None else None
     a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
-    a.threads = host_threads() if threads is None else threads
+    a.threads = threads_for(G * M) if threads is None else threads
     status = C.c_int(0)
     lib = load()
     if draws is None:
