@@ -37,7 +37,8 @@ class GibbsState(C.Structure):
         ('n_active', _i64), ('pos', _i64), ('new_cell', _i64),
         ('pos_end', _i64), ('row_base', _i64), ('threads', _i64),
         ('hint', C.c_void_p), ('hint_prior', C.c_void_p), ('hint_cols', _i64),
-        ('hint_used', _i64)]
+        ('hint_used', _i64), ('matrix_wait', C.c_void_p),
+        ('matrix_wait_arg', C.c_void_p)]
 
 
 class MHArgs(C.Structure):
@@ -95,6 +96,7 @@ SIGNATURES = {
         C.c_double, _i64, _ppd]),
     'bnpc_ll_theta_pinned_top2': (C.c_int, [_ctx, C.c_int, _pf, _i64,
         C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
+    'bnpc_matrix_wait': (C.c_int, [_ctx]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, _ppd]),
@@ -678,6 +680,15 @@ class Context:
             return mat, None
         raw = (C.c_char * (n * TOP2.itemsize)).from_address(hint.value)
         return mat, np.frombuffer(raw, dtype=TOP2, count=n)
+
+    def matrix_wait(self):
+        """The matrix of the last ll_theta_pinned_top2 is complete."""
+        check(self._lib.bnpc_matrix_wait(self._h), 'matrix_wait')
+
+    def matrix_wait_hook(self):
+        """(function address, argument) for bnpc_gibbs_state.matrix_wait."""
+        return (C.cast(self._lib.bnpc_matrix_wait, C.c_void_p).value,
+            self._h.value if hasattr(self._h, 'value') else self._h)
 
     def theta_put(self, row0, theta):
         """Store parameter rows on the device (row index = cluster id)."""

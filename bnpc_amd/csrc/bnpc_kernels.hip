@@ -96,7 +96,7 @@ struct Tunables {
     int mask_counts_max = 64;       // segments for the mask-popcount counts
     int seq_kernel = 1;             // k_ll_seq for caller-built tables
     int seq_kc = 1;                 // clusters per wave in k_ll_seq
-    int fused_small = 1;            // one-launch small-K likelihood
+    int lazy_matrix = 1;            // sweep matrix copied behind the hints
 };
 
 static int env_int(const char *name, int dflt)
@@ -125,7 +125,7 @@ static void read_tunables(Tunables &t)
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 1);
     t.seq_kc = env_int("BNPC_SEQ_KC", 1);
-    t.fused_small = env_int("BNPC_FUSED_SMALL", 1);
+    t.lazy_matrix = env_int("BNPC_LAZY_MATRIX", 1);
 }
 
 struct bnpc_ctx {
@@ -170,6 +170,8 @@ struct bnpc_ctx {
     char *zc_out_dev = nullptr;
     void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
     size_t hint_cap = 0;
+    hipEvent_t hint_done = nullptr, pin_done = nullptr;
+    bool pin_pending = false;       // the sweep matrix is still being copied
     // where the kernels of the current call read their inputs from: device
     // scratch filled by a DMA copy, or the staging arena in place
     const float *theta_src = nullptr;
@@ -306,6 +308,11 @@ static void d2h_finish(const D2H &t)
 
 static int ensure_pin(bnpc_ctx *c, size_t bytes)
 {
+    // a copy into the buffer may still be running behind a sweep
+    if (c->pin_pending) {
+        c->pin_pending = false;
+        HIPCHK(hipEventSynchronize(c->pin_done));
+    }
     if (bytes <= c->pin_cap) return 0;
     if (c->pin) HIPCHK(hipHostFree(c->pin));
     c->pin = nullptr;
@@ -1300,6 +1307,8 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
+    if (c->hint_done) (void)hipEventDestroy(c->hint_done);
+    if (c->pin_done) (void)hipEventDestroy(c->pin_done);
     for (int s = 0; s < 2; s++) {
         if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
         if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
@@ -1773,11 +1782,39 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
                            (bnpc_top2 *)zc_dev);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
-                          c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hint && c->tun.lazy_matrix) {
+        // the caller gets the hints now and the matrix when it first needs
+        // it (bnpc_matrix_wait): the copy runs behind the sweep
+        if (!c->hint_done) {
+            HIPCHK(hipEventCreateWithFlags(&c->hint_done,
+                                           hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->pin_done,
+                                           hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(c->hint_done, c->stream));
+        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipEventRecord(c->pin_done, c->stream));
+        HIPCHK(hipEventSynchronize(c->hint_done));
+        c->pin_pending = true;
+    } else {
+        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     *host = (double *)c->pin;
     *top2 = hint;
+    return 0;
+}
+
+// The matrix of the last bnpc_ll_theta_pinned_top2 is complete on return.
+extern "C" int bnpc_matrix_wait(bnpc_ctx *c)
+{
+    ARGCHK(c, "ctx is NULL");
+    if (!c->pin_pending) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    c->pin_pending = false;
+    HIPCHK(hipEventSynchronize(c->pin_done));
     return 0;
 }
 

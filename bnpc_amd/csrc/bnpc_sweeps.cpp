@@ -316,6 +316,18 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             }
         index_live();
     }
+    // the matrix may still be on its way from the device (it is only read
+    // where a hint is in doubt): wait for it before the first read
+    bool matrix_ready = st->matrix_wait == nullptr;
+#define NEED_MATRIX()                                                         \
+    if (!matrix_ready) {                                                      \
+        if (st->matrix_wait(st->matrix_wait_arg)) {                           \
+            bnpc_set_error("waiting for the log-likelihood matrix failed");   \
+            return 5;                                                         \
+        }                                                                     \
+        matrix_ready = true;                                                  \
+        st->matrix_wait = nullptr;                                            \
+    }
 #define NOTE_PRIOR(c_)                                                        \
     if ((c_) < hint_cols) {                                                   \
         const double d_ = fabs(cpr[c_] - cpr0[c_]);                           \
@@ -403,6 +415,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 const double pn = post_new[cell];
                 if (pn > other) other = pn;
                 for (int64_t a = A - 1; a >= 0 && order[a] >= hint_cols; a--) {
+                    NEED_MATRIX()
                     const double v = row[order[a]] + cpr[order[a]];
                     if (v > other) other = v;
                 }
@@ -413,6 +426,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
+        if (!hinted) NEED_MATRIX()
         if (hinted) {
             // `top` is known and dominates: nothing else is needed below
         } else if (par && A >= par_min) {
@@ -571,6 +585,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     }
     return 0;
 #undef NOTE_PRIOR
+#undef NEED_MATRIX
 }
 
 extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

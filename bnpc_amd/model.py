@@ -685,6 +685,8 @@ class CRP:
         late = np.flatnonzero(live_col < 0)
         n_cols = cols.size + late.size
         if n_cols + 1 > ld:
+            if hint is not None:
+                ctx.matrix_wait()
             ll = np.concatenate([ll, np.empty((n_rows, n_cols + 16 - ld))],
                 axis=1)
             ld = ll.shape[1]
@@ -711,6 +713,11 @@ class CRP:
             st.hint = hint[0].ctypes.data
             st.hint_prior = hint[1].ctypes.data
             st.hint_cols = cols.size
+            hook = getattr(ctx, 'matrix_wait_hook', None)
+            if hook is not None:
+                # the matrix is copied behind the loop, which waits for it
+                # itself before the first row it has to read
+                st.matrix_wait, st.matrix_wait_arg = hook()
         i64, f64 = C.c_int64, C.c_double
         born = []
         while True:
@@ -724,6 +731,10 @@ class CRP:
                     'gibbs_sweep')
             if st.new_cell < 0:
                 break
+            if hint is not None:
+                # the matrix may still be on its way: it is about to be
+                # copied / written to from here
+                ctx.matrix_wait()
             # open a new cluster for this cell (libs/CRP.py:281-282, 291-299);
             # its Beta draws continue the same stream
             cell = int(st.new_cell)

@@ -134,6 +134,11 @@ int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
                               int64_t K, double FP, double FN, int64_t ldo,
                               const double *col_prior, double **host,
                               bnpc_top2 **top2);
+/* When *top2 is returned non-NULL the matrix behind *host may still be on its
+ * way (the copy runs behind the sweep, which reads it only where a hint is in
+ * doubt): it is complete after bnpc_matrix_wait (cheap when it already is).
+ * bnpc_gibbs_sweep calls it itself through bnpc_gibbs_state.matrix_wait. */
+int bnpc_matrix_wait(bnpc_ctx *ctx);
 
 /* Resident parameter rows for tiled sweeps: store row r holds the float32
  * parameter vector of cluster id r (libs/CRP.py:155-180 keeps them in an
@@ -430,6 +435,10 @@ typedef struct bnpc_gibbs_state {
     const double *hint_prior;
     int64_t hint_cols;
     int64_t hint_used;  /* out: cells decided from the hint, accumulated */
+    /* if not NULL: called (once) with matrix_wait_arg before the first read
+     * of ll, e.g. bnpc_matrix_wait with its context */
+    int (*matrix_wait)(void *);
+    void *matrix_wait_arg;
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

@@ -78,6 +78,9 @@ class FakeContext:
         hint['second'] = rest.max(axis=1) if K > 1 else -np.inf
         return mat, hint
 
+    def matrix_wait(self):
+        pass
+
     def theta_put(self, row0, theta):
         theta = np.atleast_2d(np.asarray(theta, dtype=np.float32))
         self._poison_in_flight(row0, theta.shape[0])

@@ -817,6 +817,7 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         if K > 2:
             prior[2] = prior[0]
         ll, hint = ctx.ll_theta_pinned_top2(0, theta, .01, .2, K + 3, prior)
+        ctx.matrix_wait()       # the matrix is copied behind the hints
         live_ll, live_hint = ll, hint
         ll, hint = ll.copy(), hint.copy()
         assert np.array_equal(ll[:, :K], ctx.ll_theta(0, theta, .01, .2))
