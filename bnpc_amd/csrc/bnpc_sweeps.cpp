@@ -10,6 +10,14 @@
 // random_sample / random_interval / choice(p=) algorithms), whose state is
 // exchanged with np.random.get_state()/set_state().
 //
+// Caveat (exactness is "same stack", not a theorem): the normalisations below
+// call the C library's exp / log1p, the reference NumPy's (SIMD) exp; the two
+// agree to the last bit almost everywhere, and a 1-ulp difference only matters
+// if a uniform draw falls within that ulp of a cumulative probability (never
+// observed: profiles/r02/soak_*.log).  Non-finite posteriors, for which the
+// reference has FloatingPointError branches (CRP.py:94-98, 110-114), are
+// reported as errors (code 4), not guessed at.
+//
 // NumPy is a third-party dependency of the reference (unpinned, implied by
 // requirements.txt:1-5); the algorithms restated here are those of
 // numpy/random/_legacy (mt19937 genrand, legacy_double, random_interval,
