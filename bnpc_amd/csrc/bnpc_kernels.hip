@@ -170,8 +170,7 @@ struct bnpc_ctx {
     char *zc_out_dev = nullptr;
     void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
     size_t hint_cap = 0;
-    hipEvent_t hint_done = nullptr, pin_done = nullptr;
-    bool pin_pending = false;       // the sweep matrix is still being copied
+    size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
     // where the kernels of the current call read their inputs from: device
     // scratch filled by a DMA copy, or the staging arena in place
     const float *theta_src = nullptr;
@@ -308,11 +307,7 @@ static void d2h_finish(const D2H &t)
 
 static int ensure_pin(bnpc_ctx *c, size_t bytes)
 {
-    // a copy into the buffer may still be running behind a sweep
-    if (c->pin_pending) {
-        c->pin_pending = false;
-        HIPCHK(hipEventSynchronize(c->pin_done));
-    }
+    c->pin_lazy_bytes = 0;      // a new request supersedes a matrix not fetched
     if (bytes <= c->pin_cap) return 0;
     if (c->pin) HIPCHK(hipHostFree(c->pin));
     c->pin = nullptr;
@@ -1307,8 +1302,6 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
-    if (c->hint_done) (void)hipEventDestroy(c->hint_done);
-    if (c->pin_done) (void)hipEventDestroy(c->pin_done);
     for (int s = 0; s < 2; s++) {
         if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
         if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
@@ -1582,6 +1575,7 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     if (v.n == 0 || K == 0) return 0;
     if (ldo == 0) ldo = K;
     ARGCHK(ldo >= K, "ldo smaller than K");
+    c->pin_lazy_bytes = 0;      // (a matrix left on the device is given up)
     const size_t out_bytes = (size_t)v.n * ldo * sizeof(double);
     // a small result that the caller wants on the host is written by the
     // kernels straight into pinned host memory (no copy-engine launch)
@@ -1783,20 +1777,11 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
         HIPCHK(hipGetLastError());
     }
     if (hint && c->tun.lazy_matrix) {
-        // the caller gets the hints now and the matrix when it first needs
-        // it (bnpc_matrix_wait): the copy runs behind the sweep
-        if (!c->hint_done) {
-            HIPCHK(hipEventCreateWithFlags(&c->hint_done,
-                                           hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->pin_done,
-                                           hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(c->hint_done, c->stream));
-        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
-                              c->stream));
-        HIPCHK(hipEventRecord(c->pin_done, c->stream));
-        HIPCHK(hipEventSynchronize(c->hint_done));
-        c->pin_pending = true;
+        // the caller gets the hints now; the matrix stays on the device and
+        // is copied if and when the sweep first needs a row of it
+        // (bnpc_matrix_wait) - a converged sweep never does
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->pin_lazy_bytes = bytes;
     } else {
         HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
                               c->stream));
@@ -1811,10 +1796,13 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
 extern "C" int bnpc_matrix_wait(bnpc_ctx *c)
 {
     ARGCHK(c, "ctx is NULL");
-    if (!c->pin_pending) return 0;
+    if (!c->pin_lazy_bytes) return 0;
     HIPCHK(hipSetDevice(c->device));
-    c->pin_pending = false;
-    HIPCHK(hipEventSynchronize(c->pin_done));
+    const size_t bytes = c->pin_lazy_bytes;
+    c->pin_lazy_bytes = 0;
+    HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

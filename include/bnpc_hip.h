@@ -134,10 +134,11 @@ int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
                               int64_t K, double FP, double FN, int64_t ldo,
                               const double *col_prior, double **host,
                               bnpc_top2 **top2);
-/* When *top2 is returned non-NULL the matrix behind *host may still be on its
- * way (the copy runs behind the sweep, which reads it only where a hint is in
- * doubt): it is complete after bnpc_matrix_wait (cheap when it already is).
- * bnpc_gibbs_sweep calls it itself through bnpc_gibbs_state.matrix_wait. */
+/* When *top2 is returned non-NULL the matrix behind *host has NOT been copied
+ * yet: it stays on the device until bnpc_matrix_wait fetches it (the sweep
+ * reads it only where a hint is in doubt - a converged sweep never does).
+ * Valid until the next log-likelihood call on the context.  bnpc_gibbs_sweep
+ * calls it itself through bnpc_gibbs_state.matrix_wait. */
 int bnpc_matrix_wait(bnpc_ctx *ctx);
 
 /* Resident parameter rows for tiled sweeps: store row r holds the float32
