@@ -129,6 +129,9 @@ SIGNATURES = {
         C.POINTER(C.c_int)]),
     'bnpc_log_accept': (C.c_int, [C.c_void_p, C.POINTER(LogAArgs),
         C.POINTER(C.c_int)]),
+    'bnpc_tn_ppf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
+        C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
+        C.POINTER(C.c_int)]),
     'bnpc_tn_logpdf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
         C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
         C.POINTER(C.c_int)]),
@@ -512,6 +515,15 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
             n, rg_assignment.ctypes.data, float(DP_a), C.byref(a),
             n1.ctypes.data, n0.ctypes.data, C.byref(status)), 'rg_scan_step')
     return status.value, new, n1, n0, (sd_idx, U, u)
+
+
+def tn_ppf_scalar(kernels, q, a, b, loc, scale):
+    """truncnorm.ppf for scalars on the kernel table, or None (left to
+    SciPy)."""
+    out, status = C.c_double(0.0), C.c_int(0)
+    check(load().bnpc_tn_ppf_scalar(C.addressof(kernels), q, a, b, loc, scale,
+        C.byref(out), C.byref(status)), 'tn_ppf_scalar')
+    return None if status.value else np.float64(out.value)
 
 
 def tn_logpdf_scalar(kernels, x, a, b, loc, scale):

@@ -709,3 +709,40 @@ extern "C" int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_arg
     }
     return 0;
 }
+
+// truncnorm.ppf(q, a, b, loc, scale) for scalars = truncnorm.rvs given its one
+// uniform (the error-rate proposals, libs/CRP_learning_errors.py:81-84), as
+// scipy's truncnorm_gen._ppf evaluates it (the per-element arithmetic of the
+// batch above).  *status = 1: left to SciPy.
+extern "C" int bnpc_tn_ppf_scalar(const bnpc_host_kernels *k, double q,
+                                  double a, double b, double loc, double scale,
+                                  double *out, int *status)
+{
+    if (check_kernels(k)) return 2;
+    if (!out || !status) {
+        bnpc_set_error("bad argument: tn_ppf_scalar");
+        return 2;
+    }
+    *status = 1;
+    double mass;
+    if (!(q > 0.0 && q < 1.0) || !gauss_mass(k, a, b, &mass)) return 0;
+    const bool left = a < 0.0;
+    double lq, arg = left ? q : -q;
+    if (left) uloop(k->np_log, k->np_log_data, &arg, &lq, 1);       // log(q)
+    else uloop(k->np_log1p, k->np_log1p_data, &arg, &lq, 1);        // log1p(-q)
+    const double pp = k->log_ndtr(left ? a : -b, 0);
+    const double qq = lq + mass;
+    if (!isfinite(pp) || !isfinite(qq)) return 0;
+    const double top = pp > qq ? pp : qq, bot = pp > qq ? qq : pp;
+    const bool tie = pp == qq;
+    double d = bot - top, e, l1p, lm, m = tie ? 2.0 : 1.0;
+    uloop(k->np_exp, k->np_exp_data, &d, &e, 1);
+    if (tie) e = 0.0;
+    uloop(k->np_log1p, k->np_log1p_data, &e, &l1p, 1);
+    uloop(k->np_log, k->np_log_data, &m, &lm, 1);
+    double x = k->ndtri_exp(l1p + lm + top, 0);
+    if (!left) x = -x;
+    *out = x * scale + loc;
+    *status = 0;
+    return 0;
+}

@@ -159,18 +159,36 @@ class TraceStore:
         d['assignments'][slot] = model.assignment
 
     def put_params(self, slot, model):
-        """MCMC.py:260-282: parameter rows of the populated clusters."""
+        """MCMC.py:260-282: parameter rows of the populated clusters, zero
+        padded to the largest cluster count seen.  The array is allocated a
+        few clusters wider than that (re-padding the whole trace for every
+        new maximum costs a millisecond a time) and cut back to the
+        reference's shape when the chain hands its results over (`finish`)."""
         d = self.data
         live = np.sort(np.fromiter(model.cells_per_cluster.keys(), dtype=int))
         if 'params' not in d:
-            d['params'] = np.zeros((self.slots - slot, live.size, self.n_muts),
-                dtype=np.float32)
+            self._k_seen = 0
+            d['params'] = np.zeros((self.slots - slot,
+                live.size + self.PARAMS_SPARE, self.n_muts), dtype=np.float32)
         wider = live.size - d['params'].shape[1]
         if wider > 0:
-            d['params'] = np.pad(d['params'], [(0, 0), (0, wider), (0, 0)],
+            d['params'] = np.pad(d['params'],
+                [(0, 0), (0, wider + self.PARAMS_SPARE), (0, 0)],
                 mode='constant')
+        self._k_seen = max(getattr(self, '_k_seen', 0), live.size)
         row = slot - (self.slots - d['params'].shape[0])
         d['params'][row][:live.size] = model.parameters[live]
+
+    PARAMS_SPARE = 8
+
+    def finish(self):
+        """Results in the reference's layout: the parameter trace exactly as
+        wide as the largest cluster count seen."""
+        k = getattr(self, '_k_seen', None)
+        if k is not None and 'params' in self.data \
+                and self.data['params'].shape[1] != k:
+            self.data['params'] = np.ascontiguousarray(
+                self.data['params'][:, :k])
 
     def __getstate__(self):
         """Chains return from their workers through a pipe: cluster labels
@@ -374,6 +392,7 @@ class Chain_steps(Chain):
             self.do_step()
             self.update_results(step + init_steps,
                 _before(step, self.burn_in))
+        self.trace.finish()
         self.trace.data['burn_in'] = self.burn_in
 
 
@@ -398,6 +417,7 @@ class Chain_time(Chain):
             self.update_results(step, _before(now, self.burn_in))
             now = datetime.now()
         self.trace.drop_unused_tail()
+        self.trace.finish()
         kept = self.trace.data['params'].shape[0]
         self.trace.data['burn_in'] = self.trace.slots - kept
 

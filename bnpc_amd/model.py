@@ -194,6 +194,11 @@ def _native_batch_is_exact(table):
                     got = _lib.tn_logpdf_scalar(table, x, a, b, lo, sc)
                     ok &= got is not None and (got == ref or
                         (np.isnan(got) and np.isnan(ref)))
+                for q_ in (1e-12, 0.03, 0.5, 0.97, 1 - 1e-12):
+                    a, b = (0 - lo) / sc, (1 - lo) / sc
+                    ref = fastdist.tn_rvs_from_uniform(q_, a, b, lo, sc)
+                    got = _lib.tn_ppf_scalar(table, q_, a, b, lo, sc)
+                    ok &= got is not None and bool(got == ref)
             if not probe.beta_prior_uniform:
                 dens, total = _lib.beta_logpdf_f32(table, old, p, q,
                     threads=2)
@@ -203,6 +208,20 @@ def _native_batch_is_exact(table):
         return bool(ok)
     except Exception:
         return False
+
+
+def _tn_rvs_scalar(a, b, loc, scale):
+    """truncnorm.rvs(a, b, loc=loc, scale=scale), one draw: one uniform of the
+    global stream through the ppf - natively when allowed, else SciPy."""
+    table = _native_kernels()
+    if table is not None:
+        q = np.random.uniform()
+        val = _lib.tn_ppf_scalar(table, q, float(a), float(b), float(loc),
+            float(scale))
+        if val is None:     # same uniform, SciPy's kernel
+            val = np.float64(fastdist.tn_rvs_from_uniform(q, a, b, loc, scale))
+        return val
+    return fastdist.tn_rvs_scalar(a, b, loc, scale)
 
 
 def _tn_logpdf_scalar(x, a, b, loc, scale):
@@ -1482,7 +1501,7 @@ class CRP_errors_learning(CRP):
         a = (0 - old) / std
         b = (1 - old) / std
         try:
-            new = fastdist.tn_rvs_scalar(a, b, old, std)
+            new = _tn_rvs_scalar(a, b, old, std)
         except FloatingPointError:
             new = truncnorm.rvs(a, np.inf, loc=old, scale=std)
 

@@ -387,6 +387,12 @@ int bnpc_tn_logpdf_scalar(const bnpc_host_kernels *k, double x, double a,
                           double b, double loc, double scale, double *out,
                           int *status);
 
+/* scipy.stats.truncnorm.ppf(q, a, b, loc, scale) for scalars: the error-rate
+ * proposal given its one uniform (libs/CRP_learning_errors.py:81-84). */
+int bnpc_tn_ppf_scalar(const bnpc_host_kernels *k, double q, double a,
+                       double b, double loc, double scale, double *out,
+                       int *status);
+
 /* Checker hook: the cumulative sums np.cumsum(p) holds for the probability
  * vector p[top] = 1.0, p[a != top] = 1e-15-floor (a = 0..A) - the case in
  * which one cluster dominates _normalize_log_probs (libs/CRP.py:88-100).  The
