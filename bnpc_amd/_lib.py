@@ -549,7 +549,7 @@ def beta_logpdf_f32(kernels, x, p, q, known=None, threads=None):
         ptr(x, C.c_float), x.size, p, q,
         kt.ctypes.data if kt is not None else None,
         kp.ctypes.data if kp is not None else None, ptr(out, C.c_double),
-        C.byref(total), host_threads() if threads is None else threads),
+        C.byref(total), threads_for(x.size) if threads is None else threads),
         'beta_logpdf_f32')
     return out, total.value
 

@@ -520,7 +520,8 @@ extern "C" int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x,
             misses += memcmp(known_theta + i, x + i, sizeof(float)) != 0;
     else
         misses = n;
-    if (misses < 4096) threads = 1;
+    // (large arrays go to the team anyway: the pass is memory traffic)
+    if (misses < 4096 && n < 65536) threads = 1;
     std::atomic<int64_t> next(0);
     auto work = [&](int) {
         for (;;) {
