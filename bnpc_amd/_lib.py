@@ -109,6 +109,8 @@ SIGNATURES = {
     'bnpc_colcounts_by_label': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32,
         _pi32]),
     'bnpc_ll_total': (C.c_int, [_ctx, _pf, _i64, _pd, _pd, C.c_int, _pd]),
+    'bnpc_ll_total_issue': (C.c_int, [_ctx, _pf, _i64, _pd, _pd, C.c_int]),
+    'bnpc_ll_total_wait': (C.c_int, [_ctx, _pd]),
     'bnpc_bench_ll': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
     'bnpc_bench_ll_full': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
     'bnpc_last_launch': (C.c_int, [_ctx, C.c_char_p, C.c_int,
@@ -807,6 +809,23 @@ class Context:
         check(self._lib.bnpc_ll_total(self._h, ptr(theta, C.c_float),
             theta.shape[0], ptr(FP, C.c_double), ptr(FN, C.c_double), E,
             ptr(out, C.c_double)), 'll_total')
+        return out
+
+    def ll_total_issue(self, theta, FP, FN):
+        """Launch ll_total and return; ll_total_wait() picks the result up."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        FP = np.ascontiguousarray(np.atleast_1d(FP), dtype=np.float64)
+        FN = np.ascontiguousarray(np.atleast_1d(FN), dtype=np.float64)
+        assert FP.shape == FN.shape and FP.ndim == 1
+        check(self._lib.bnpc_ll_total_issue(self._h, ptr(theta, C.c_float),
+            theta.shape[0], ptr(FP, C.c_double), ptr(FN, C.c_double),
+            FP.size), 'll_total_issue')
+        self._total_E = FP.size
+
+    def ll_total_wait(self):
+        out = np.empty(self._total_E, dtype=np.float64)
+        check(self._lib.bnpc_ll_total_wait(self._h, ptr(out, C.c_double)),
+            'll_total_wait')
         return out
 
     def bench_ll(self, reps=10):

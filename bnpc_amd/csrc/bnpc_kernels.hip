@@ -171,6 +171,8 @@ struct bnpc_ctx {
     void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
     size_t hint_cap = 0;
     size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
+    bool total_pending = false;     // a deferred bnpc_ll_total_issue
+    int total_blocks = 0, total_E = 0;
     // where the kernels of the current call read their inputs from: device
     // scratch filled by a DMA copy, or the staging arena in place
     const float *theta_src = nullptr;
@@ -226,6 +228,16 @@ static void *stage_slot(bnpc_ctx *c, size_t bytes)
     if (at + bytes > STAGE_BYTES) return nullptr;
     c->stage_used = at + bytes;
     return (char *)c->stage + at;
+}
+
+// Start of a call that stages inputs: the arena is free again - unless a
+// deferred total (bnpc_ll_total_issue) may still be reading its parameters
+// from it; then that kernel is waited for first (its result stays parked).
+static int arena_reset(bnpc_ctx *c)
+{
+    if (c->total_pending) HIPCHK(hipStreamSynchronize(c->stream));
+    c->stage_used = 0;
+    return 0;
 }
 
 // Zero-copy input: the payload is copied into the pinned arena and the
@@ -1352,7 +1364,7 @@ extern "C" int bnpc_view_set(bnpc_ctx *c, int view, const int64_t *cells,
         c->views[view].nblk = 0;
         return 0;
     }
-    c->stage_used = 0;
+    if (arena_reset(c)) return 1;
     const long long *d_cells = (const long long *)stage_in_place(
         c, cells, n * sizeof(long long));
     if (!d_cells) {
@@ -1657,7 +1669,7 @@ static int ll_theta_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     if (K == 0) return 0;
     SideLane lane(c);
     const size_t bytes = (size_t)K * c->M * sizeof(float);
-    c->stage_used = 0;
+    if (arena_reset(c)) return 1;
     void *slot = nullptr;
     c->theta_src = (const float *)stage_in_place(c, theta, bytes);
     if (c->theta_src) {
@@ -1956,7 +1968,7 @@ extern "C" int bnpc_ll_tables(bnpc_ctx *c, int view, const double *L1,
     HIPCHK(hipSetDevice(c->device));
     if (K == 0) return 0;
     const size_t bytes = (size_t)K * c->M * sizeof(double);
-    c->stage_used = 0;
+    if (arena_reset(c)) return 1;
     c->tab_src = nullptr;
     if (c->tun.zero_copy && (int64_t)(2 * bytes) <= c->tun.zc_in_max) {
         // L1 then L0, contiguous in the arena
@@ -1984,7 +1996,7 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
                             const int64_t *seg_offsets, int64_t G,
                             DevBuf &cnt)
 {
-    c->stage_used = 0;
+    if (arena_reset(c)) return 1;
     const size_t cnt_bytes = (size_t)2 * G * c->M * sizeof(int32_t);
     if (ensure(cnt, cnt_bytes)) return 1;
     HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_bytes, c->stream));
@@ -2029,7 +2041,7 @@ static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
     const View &v = c->views[view];
     const size_t half = (size_t)G * c->M * sizeof(int32_t);
     if (ensure(cnt, 2 * half)) return 1;
-    c->stage_used = 0;
+    if (arena_reset(c)) return 1;
     if (v.n == 0) {
         HIPCHK(hipMemsetAsync(cnt.p, 0, 2 * half, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -2208,21 +2220,21 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
     return 0;
 }
 
-extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
-                             const double *FP, const double *FN, int E,
-                             double *out)
+extern "C" int bnpc_ll_total_issue(bnpc_ctx *c, const float *theta, int64_t K,
+                                   const double *FP, const double *FN, int E)
 {
-    ARGCHK(c && theta && FP && FN && out, "NULL argument");
+    ARGCHK(c && theta && FP && FN, "NULL argument");
     ARGCHK(E >= 1 && E <= BNPC_MAX_TRIALS, "E out of range");
     ARGCHK(K == c->lab_K && K > 0,
            "K does not match the resident counts (call "
            "bnpc_colcounts_by_label first)");
+    ARGCHK(!c->total_pending, "a deferred total is already pending");
     for (int e = 0; e < E; e++)
         ARGCHK(FP[e] > 0.0 && FP[e] < 1.0 && FN[e] > 0.0 && FN[e] < 1.0,
                "error rates must lie in (0, 1)");
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = (size_t)K * c->M * sizeof(float);
-    c->stage_used = 0;
+    if (arena_reset(c)) return 1;
     const float *d_theta = (const float *)stage_in_place(c, theta, bytes);
     if (!d_theta) {
         if (ensure(c->theta, bytes)) return 1;
@@ -2237,17 +2249,17 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
     int blocks = (int)((KM + 255) / 256);
     if (blocks > TOTAL_BLOCKS) blocks = TOTAL_BLOCKS;
     if (blocks < 1) blocks = 1;
-    const size_t part_bytes = (size_t)blocks * 4 * sizeof(double);
-    void *zc_dev = nullptr;
-    const double *p = (const double *)zc_result(c, part_bytes, &zc_dev);
-    double *d_part = (double *)zc_dev;
-    if (!p) {
+    // the partial sums land in a small pinned buffer of their own (a
+    // deferred total must survive the calls made before it is picked up)
+    if (!c->pin_small)
+        HIPCHK(hipHostMalloc(&c->pin_small, TOTAL_BLOCKS * 4 * sizeof(double),
+                             hipHostMallocDefault));
+    void *d_part = nullptr;
+    const bool in_place = c->tun.zero_copy
+        && hipHostGetDevicePointer(&d_part, c->pin_small, 0) == hipSuccess;
+    if (!in_place) {
         if (ensure(c->partial, TOTAL_BLOCKS * 4 * sizeof(double))) return 1;
-        if (!c->pin_small)
-            HIPCHK(hipHostMalloc(&c->pin_small,
-                                 TOTAL_BLOCKS * 4 * sizeof(double),
-                                 hipHostMallocDefault));
-        d_part = (double *)c->partial.p;
+        d_part = c->partial.p;
     }
     double fp[4] = {0.5, 0.5, 0.5, 0.5}, fn[4] = {0.5, 0.5, 0.5, 0.5};
     for (int e = 0; e < E; e++) {
@@ -2258,20 +2270,42 @@ extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
     const int *n0 = n1 + (size_t)K * c->M;
     hipLaunchKernelGGL(k_ll_total, dim3(blocks), dim3(256), 0, c->stream,
                        d_theta, n1, n0, KM, E, fp[0], fn[0], fp[1], fn[1],
-                       fp[2], fn[2], fp[3], fn[3], d_part);
+                       fp[2], fn[2], fp[3], fn[3], (double *)d_part);
     HIPCHK(hipGetLastError());
-    if (!p) {
-        HIPCHK(hipMemcpyAsync(c->pin_small, c->partial.p, part_bytes,
+    if (!in_place)
+        HIPCHK(hipMemcpyAsync(c->pin_small, c->partial.p,
+                              (size_t)blocks * 4 * sizeof(double),
                               hipMemcpyDeviceToHost, c->stream));
-        p = (const double *)c->pin_small;
-    }
+    c->total_pending = true;
+    c->total_blocks = blocks;
+    c->total_E = E;
+    return 0;
+}
+
+extern "C" int bnpc_ll_total_wait(bnpc_ctx *c, double *out)
+{
+    ARGCHK(c && out, "NULL argument");
+    ARGCHK(c->total_pending, "no deferred total is pending");
+    HIPCHK(hipSetDevice(c->device));
+    c->total_pending = false;
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int e = 0; e < E; e++) {
+    const double *p = (const double *)c->pin_small;
+    for (int e = 0; e < c->total_E; e++) {
         double sum = 0.0;
-        for (int b = 0; b < blocks; b++) sum += p[b * 4 + e];
+        for (int b = 0; b < c->total_blocks; b++) sum += p[b * 4 + e];
         out[e] = sum;
     }
     return 0;
+}
+
+extern "C" int bnpc_ll_total(bnpc_ctx *c, const float *theta, int64_t K,
+                             const double *FP, const double *FN, int E,
+                             double *out)
+{
+    ARGCHK(out, "NULL argument");
+    int rc = bnpc_ll_total_issue(c, theta, K, FP, FN, E);
+    if (rc) return rc;
+    return bnpc_ll_total_wait(c, out);
 }
 
 extern "C" int bnpc_last_launch(const bnpc_ctx *c, char *name, int len,

@@ -150,9 +150,16 @@ class TraceStore:
         """a8: the total log-likelihood of every step is what the 1e-6 parity
         criterion is checked on (MCMC.py:252-258)."""
         d = self.data
-        log_lik = model.get_ll_full()
+        deferred = getattr(model, 'get_ll_full_deferred', None)
+        if deferred is None:
+            log_lik = model.get_ll_full()
+            log_prior = model.get_lprior_full()
+        else:       # the prior is host work: it runs under the launch
+            pick_up = deferred()
+            log_prior = model.get_lprior_full()
+            log_lik = pick_up()
         d['ML'][slot] = log_lik
-        d['MAP'][slot] = log_lik + model.get_lprior_full()
+        d['MAP'][slot] = log_lik + log_prior
         d['DP_alpha'][slot] = model.DP_a
         d['FN'][slot] = model.FN
         d['FP'][slot] = model.FP

@@ -541,6 +541,15 @@ class CRP:
         """libs/CRP.py:237-238"""
         return float(self._ll_total([self.FP], [self.FN])[0])
 
+    def get_ll_full_deferred(self):
+        """get_ll_full in two halves: the launch now, the value when the
+        returned function is called - host work (get_lprior_full) runs under
+        the launch in between."""
+        lab = self._label_counts()
+        ctx = self._dev()
+        ctx.ll_total_issue(self.parameters[lab['ids']], [self.FP], [self.FN])
+        return lambda: float(ctx.ll_total_wait()[0])
+
     def get_lprior_full(self):
         """libs/CRP.py:241-251"""
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)

@@ -208,6 +208,14 @@ int bnpc_colcounts_by_label(bnpc_ctx *ctx, const int64_t *assignment,
  * theta is K x M float32 (row g = parameters of ids[g]). */
 int bnpc_ll_total(bnpc_ctx *ctx, const float *theta, int64_t K,
                   const double *FP, const double *FN, int E, double *out);
+/* The same in two halves: issue launches the sum and returns; wait picks the
+ * E totals up.  The driver records the state of a step as likelihood + prior
+ * (libs/MCMC.py:252-254): the prior is host work that runs under the launch.
+ * Other calls on the context may be made in between (they first let the
+ * pending kernel finish reading its staged parameters); one total at a time. */
+int bnpc_ll_total_issue(bnpc_ctx *ctx, const float *theta, int64_t K,
+                        const double *FP, const double *FN, int E);
+int bnpc_ll_total_wait(bnpc_ctx *ctx, double *out);
 
 /* ---- timing on the context's stream (HIP events) -------------------------- */
 /* Re-issue the cells x clusters x mutations kernel of the last bnpc_ll_theta /

@@ -81,6 +81,13 @@ class FakeContext:
     def matrix_wait(self):
         pass
 
+    def ll_total_issue(self, theta, FP, FN):
+        self._pending_total = self.ll_total(theta, FP, FN)
+
+    def ll_total_wait(self):
+        out, self._pending_total = self._pending_total, None
+        return out
+
     def theta_put(self, row0, theta):
         theta = np.atleast_2d(np.asarray(theta, dtype=np.float32))
         self._poison_in_flight(row0, theta.shape[0])

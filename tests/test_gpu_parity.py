@@ -328,6 +328,17 @@ def test_ll_total_trials_match_oracle(golden_dir):
     # deterministic: same launch twice gives the same bits
     again = ctx.ll_total(g['le_parameters'], trials[:4, 0], trials[:4, 1])
     assert np.array_equal(again, got[:4])
+    # the two halves, with other calls on the context in between (they use
+    # the same staging arena and result buffer)
+    ctx.ll_total_issue(g['le_parameters'], trials[:4, 0], trials[:4, 1])
+    theta = np.clip(np.random.RandomState(3).uniform(size=(3, data.shape[1])),
+        1e-5, 1 - 1e-5).astype(np.float32)
+    ctx.ll_theta(0, theta, 0.01, 0.2)
+    ctx.view_set(1, np.arange(min(40, data.shape[0])))
+    ctx.view_counts(1, np.zeros(min(40, data.shape[0]), dtype=np.int64), 1)
+    assert np.array_equal(ctx.ll_total_wait(), got[:4])
+    with pytest.raises(RuntimeError, match='no deferred total'):
+        ctx.ll_total_wait()
     ctx.close()
 
 
