@@ -128,7 +128,7 @@ SIGNATURES = {
         C.POINTER(C.c_int)]),
     'bnpc_rg_scan_step': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
         C.c_int, _i64, _pi64, C.c_double, C.POINTER(MHArgs), _pi32, _pi32,
-        C.POINTER(C.c_int)]),
+        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'bnpc_log_accept': (C.c_int, [C.c_void_p, C.POINTER(LogAArgs),
         C.POINTER(C.c_int)]),
     'bnpc_tn_ppf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
@@ -487,14 +487,15 @@ def log_A(kernels, new, old, std, n1, n0, fmin, fmax, tmin, tmax, FP, FN, p,
 
 
 def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
-            tmax, FP, FN, p, q, uniform, threads=None):
+            tmax, FP, FN, p, q, uniform, trans_prob=False, threads=None):
     """bnpc_rg_scan_step on the device context `ctx`: (status, new theta
-    (3, M), rg_assignment (updated in place), n1, n0 (3, M) int32,
-    (sd_idx, U, u)).  status 1: the scan and the counts are done and the draws
-    taken; the parameter rows are to be evaluated from the draws."""
+    (G, M), n1, n0 (G, M) int32, (sd_idx, U, u), scan log-prob, batch
+    log-probs (G,)); rg_assignment is updated in place.  G = 3 rows (launch
+    clusters + merged) or 2.  status 1: the scan and the counts are done and
+    the draws taken; the parameter rows are to be evaluated from the draws."""
     theta3 = np.ascontiguousarray(theta3, dtype=np.float32)
     G, M = theta3.shape
-    assert G == 3 and rg_assignment.dtype == np.int64 \
+    assert G in (2, 3) and rg_assignment.dtype == np.int64 \
         and rg_assignment.flags['C_CONTIGUOUS'] and rg_assignment.size == n - 2
     sd = np.ascontiguousarray(sd, dtype=np.float64)
     a, sd_idx, U, u, _ = _mh_buffers(G, M)
@@ -506,17 +507,21 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
     a.old_theta, a.n1, a.n0 = theta3.ctypes.data, n1.ctypes.data, n0.ctypes.data
     a.sd, a.n_sd = sd.ctypes.data, sd.size
     a.tmin, a.tmax, a.FP, a.FN, a.p, a.q = tmin, tmax, FP, FN, p, q
-    a.uniform_prior, a.trans_prob = int(bool(uniform)), 0
+    a.uniform_prior = int(bool(uniform))
+    a.trans_prob = int(bool(trans_prob))
     a.known_theta = a.known_prior = a.prior_out = None
     a.new_theta = new.ctypes.data
     a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
     a.threads = host_threads() if threads is None else threads
     status = C.c_int(0)
+    scan_prob = C.c_double(0.0)
     with NumpyStream() as rng:
         check(load().bnpc_rg_scan_step(ctx._h, C.addressof(kernels), rng, view,
             n, rg_assignment.ctypes.data, float(DP_a), C.byref(a),
-            n1.ctypes.data, n0.ctypes.data, C.byref(status)), 'rg_scan_step')
-    return status.value, new, n1, n0, (sd_idx, U, u)
+            n1.ctypes.data, n0.ctypes.data, C.byref(scan_prob),
+            C.byref(status)), 'rg_scan_step')
+    return (status.value, new, n1, n0, (sd_idx, U, u), scan_prob.value,
+        log_prob)
 
 
 def tn_ppf_scalar(kernels, q, a, b, loc, scale):

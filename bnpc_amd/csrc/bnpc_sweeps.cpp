@@ -736,10 +736,12 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
                                  bnpc_mt19937 *rng, int view, int64_t n,
                                  int64_t *rg_assignment, double DP_a,
                                  const bnpc_mh_args *mh, int32_t *n1,
-                                 int32_t *n0, int *status)
+                                 int32_t *n0, double *scan_log_prob,
+                                 int *status)
 {
     if (!ctx || !k || !rng || !rg_assignment || !mh || !n1 || !n0 || !status
-        || n < 3 || mh->G != 3 || mh->n1 != n1 || mh->n0 != n0) {
+        || n < 3 || (mh->G != 3 && mh->G != 2) || mh->n1 != n1
+        || mh->n0 != n0) {
         bnpc_set_error("bad argument: rg_scan_step");
         return 2;
     }
@@ -765,9 +767,11 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     labels[n - 1] = 1;
     rc = bnpc_view_counts(ctx, view, labels.data(), 2, n1, n0);
     if (rc) return rc;
-    for (int64_t m = 0; m < M; m++) {
-        n1[2 * M + m] = n1[m] + n1[M + m];
-        n0[2 * M + m] = n0[m] + n0[M + m];
-    }
+    if (scan_log_prob) *scan_log_prob = log_prob;
+    if (mh->G == 3)
+        for (int64_t m = 0; m < M; m++) {       // the merged cluster
+            n1[2 * M + m] = n1[m] + n1[M + m];
+            n0[2 * M + m] = n0[m] + n0[M + m];
+        }
     return bnpc_mh_batch(k, rng, mh, status);
 }

@@ -1207,6 +1207,10 @@ class CRP:
 
     def _rg_scan_split(self, cells, trans_prob=False):
         """libs/CRP.py:570-578"""
+        if trans_prob:
+            fused = self._rg_scan_fused(cells, final=True)
+            if fused is not None:
+                return fused
         if cells.size == 2:
             prob_cl = 0
         else:
@@ -1222,7 +1226,7 @@ class CRP:
         and of the merged cluster.  No draw separates the three MH updates and
         they do not depend on each other, so they are ONE batch (rows in the
         reference's order i, j, merge)."""
-        if self._rg_scan_fused(cells):
+        if self._rg_scan_fused(cells) is not None:
             return
         if cells.size != 2:
             self._rg_scan_assign(cells)
@@ -1235,11 +1239,13 @@ class CRP:
         self.rg_params_split = new[:2]
         self.rg_params_merge = new[2]
 
-    def _rg_scan_fused(self, cells):
-        """The whole intermediate scan as ONE native call (bnpc_rg_scan_step:
-        device sums, assignment scan, counts, parameter batch).  False if it
-        does not apply - tiny moves, no native kernel table, a view that is
-        not this move's - and nothing was drawn."""
+    def _rg_scan_fused(self, cells, final=False):
+        """A whole scan as ONE native call (bnpc_rg_scan_step: device sums,
+        assignment scan, counts, parameter batch): the intermediate scans
+        (launch clusters + merged cluster) or, `final`, the scored last scan
+        of a split (launch clusters only, transition probabilities; returns
+        their sum).  None if it does not apply - tiny moves, no native kernel
+        table, a view that is not this move's - and nothing was drawn."""
         table = _native_kernels()
         ctx = self._dev()
         view = getattr(self, '_rg_view', None)
@@ -1247,20 +1253,24 @@ class CRP:
                 or view is None or view.size != cells.size \
                 or not np.array_equal(view, cells) \
                 or os.environ.get('BNPC_RG_FUSED', '1') == '0':
-            return False
+            return None
         rg = np.array(self.rg_assignment, dtype=np.int64, order='C')
-        theta3 = np.concatenate([self.rg_params_split,
-            self.rg_params_merge[None, :]]).astype(np.float32)
-        status, new, n1, n0, draws = _lib.rg_scan_step(ctx, table, VIEW_MOVE,
-            cells.size, rg, self.DP_a, theta3, self.param_proposal_sd, TMIN,
-            TMAX, self.FP, self.FN, self.p, self.q, self.beta_prior_uniform)
+        rows = self.rg_params_split if final else np.concatenate(
+            [self.rg_params_split, self.rg_params_merge[None, :]])
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        status, new, n1, n0, draws, scan_prob, probs = _lib.rg_scan_step(
+            ctx, table, VIEW_MOVE, cells.size, rg, self.DP_a, rows,
+            self.param_proposal_sd, TMIN, TMAX, self.FP, self.FN, self.p,
+            self.q, self.beta_prior_uniform, trans_prob=final)
         self.rg_assignment = rg
         self._rg_counts = (rg.tobytes(), [
             (n1[g].astype(np.float64), n0[g].astype(np.float64))
             for g in range(2)])
         if status != 0:     # the batch left an element to SciPy
-            new, _, _ = self._mh_batch(theta3, (n1, n0), False, draws=draws)
+            new, probs, _ = self._mh_batch(rows, (n1, n0), final, draws=draws)
         self.rg_params_split = new[:2]
+        if final:
+            return scan_prob + probs.sum()
         self.rg_params_merge = new[2]
         return True
 

@@ -371,13 +371,16 @@ int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_args *a,
  * assignment scan over slots 1..n-2 on the stream (bnpc_rg_scan mode 0),
  * column counts of the two launch clusters for the new assignment (slot 0
  * belongs to the first, slot n-1 to the second; row 2 = their sum) into n1 /
- * n0 (3 x M, the buffers mh->n1 / mh->n0 point at), then bnpc_mh_batch on the
- * three rows (mh->G == 3).  *status as bnpc_mh_batch. */
+ * n0 (G x M, the buffers mh->n1 / mh->n0 point at), then bnpc_mh_batch on the
+ * rows: mh->G == 3 (launch clusters + merged cluster, an intermediate scan)
+ * or 2 (the launch clusters only: the scored final scan of a split,
+ * libs/CRP.py:672, with mh->trans_prob set; *scan_log_prob then carries the
+ * assignment scan's part).  *status as bnpc_mh_batch. */
 int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
                       bnpc_mt19937 *rng, int view, int64_t n,
                       int64_t *rg_assignment, double DP_a,
                       const bnpc_mh_args *mh, int32_t *n1, int32_t *n0,
-                      int *status);
+                      double *scan_log_prob, int *status);
 
 /* Beta(p, q) log-density of n float32 values (scipy.stats.beta._logpdf with
  * the public wrapper's support handling), re-using known_prior[i] where
