@@ -94,7 +94,9 @@ struct Tunables {
     int64_t zc_out_max = 512 << 10;
     int64_t zc_sweep_max = 0;       // the sweep's matrix (pinned) in place
     int mask_counts_max = 64;       // segments for the mask-popcount counts
-    int seq_kernel = 1;             // k_ll_seq for caller-built tables
+    int seq_kernel = 2;             // caller-built tables: 2 = k_ll_seqp
+                                    // (pipeline), 1 = k_ll_seq, 0 = k_ll
+    int seq_stage = 1;              // k_ll_seqp: tables copied to the device
     int seq_kc = 1;                 // clusters per wave in k_ll_seq
     int lazy_matrix = 1;            // sweep matrix copied behind the hints
 };
@@ -123,7 +125,8 @@ static void read_tunables(Tunables &t)
     t.zc_out_max = (int64_t)env_int("BNPC_ZC_OUT_KB", 512) << 10;
     t.zc_sweep_max = (int64_t)env_int("BNPC_ZC_SWEEP_KB", 0) << 10;
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
-    t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 1);
+    t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 2);
+    t.seq_stage = env_int("BNPC_SEQ_STAGE", 1);
     t.seq_kc = env_int("BNPC_SEQ_KC", 1);
     t.lazy_matrix = env_int("BNPC_LAZY_MATRIX", 1);
 }
@@ -906,6 +909,159 @@ __global__ __launch_bounds__(256) void k_ll_seq(
 }
 
 // ---------------------------------------------------------------------------
+// K2p: K2s as a producer/consumer pipeline - same sums, same order, same bits.
+// A launch of K2s has a handful of (block, cluster) chains and a thousand
+// idle SIMDs, and what a chain costs is the instruction stream of its ONE
+// wave (selection AND add).  Here a workgroup is one chain on four SIMDs:
+//   waves 1-3 (producers), lane <-> MUTATION m0 + j of the current 64-chunk:
+//     the lane masks {ones, zeros}[m0 + j] and the table pair {L1, L0}[m0 + j]
+//     arrive by coalesced loads (4 chunks ahead); for each of its ~21 cells c
+//     the value that cell adds at that mutation,
+//         x[c][j] = bit c of ones ? L1 : bit c of zeros ? L0 : +0.0,
+//     is selected with integer ops (sign-extended bit AND the table words) and
+//     written to LDS - conflict-free, lane j = consecutive 8 bytes;
+//   wave 0 (consumer), lane <-> CELL c: reads its row x[c][0..63] two values
+//     per ds_read_b128 (row stride 66 doubles: conflict-free) and performs the
+//     chain's adds, one v_add_f64 per mutation in mutation order.
+// Adding +0.0 where K2s adds nothing is exact (a partial sum is never -0.0:
+// it starts at +0.0 and +0.0 + -0.0 = +0.0).  Two x stages: the producers
+// fill chunk i + 1 while the consumer adds chunk i; one s_barrier per chunk,
+// with an LDS-only wait so that the global prefetch stays in flight.
+// ---------------------------------------------------------------------------
+#define SEQP_XS 66                      // doubles per cell row of a stage
+#define SEQP_DEPTH 4                    // chunks of global loads in flight
+#define SEQP_LDS (2 * 64 * SEQP_XS * sizeof(double))
+
+__device__ __forceinline__ void seqp_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef unsigned seqp_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int C0, int C1>
+__device__ __forceinline__ void seqp_select(const seqp_u32x4 &mk, double l1,
+                                            double l0, double *xs)
+{
+    // mk = {ones lo, ones hi, zeros lo, zeros hi}
+    const unsigned l1lo = (unsigned)__double2loint(l1);
+    const unsigned l1hi = (unsigned)__double2hiint(l1);
+    const unsigned l0lo = (unsigned)__double2loint(l0);
+    const unsigned l0hi = (unsigned)__double2hiint(l0);
+#pragma unroll
+    for (int c = C0; c < C1; c++) {
+        const unsigned t1 = (unsigned)__builtin_amdgcn_sbfe(
+            (int)(c < 32 ? mk.x : mk.y), c & 31, 1);
+        const unsigned t0 = (unsigned)__builtin_amdgcn_sbfe(
+            (int)(c < 32 ? mk.z : mk.w), c & 31, 1);
+        xs[c * SEQP_XS] = __hiloint2double(
+            (int)((t1 & l1hi) | (t0 & l0hi)), (int)((t1 & l1lo) | (t0 & l0lo)));
+    }
+}
+
+// One producer wave: cells C0 .. C1 - 1 of every chunk.  The global loads are
+// spelled out with their own vmcnt bookkeeping - three loads per chunk,
+// SEQP_DEPTH chunks in flight, so a chunk is complete when at most
+// 3 (SEQP_DEPTH - 1) younger loads are outstanding (the compiler's own counter
+// insertion gives up at the loop edge and waits for everything, i.e. one
+// memory round trip per chunk).  The chunk count is rounded up to the depth
+// (straight-line loop body); a chunk past the end re-reads the last one and
+// is ignored by the consumer, a mutation past M re-reads table entry M - 1,
+// which the empty padding masks turn into +0.0.
+template <int C0, int C1>
+__device__ __forceinline__ void seqp_producer(
+    const ulonglong2 *__restrict__ mk, const double *__restrict__ t1,
+    const double *__restrict__ t0, int nch, int nch_up, int M, int lane,
+    double *xs)
+{
+    static_assert(SEQP_DEPTH == 4, "vmcnt below is 3 * (SEQP_DEPTH - 1)");
+    seqp_u32x4 mq[SEQP_DEPTH];
+    double l1q[SEQP_DEPTH], l0q[SEQP_DEPTH];
+#define SEQP_LOAD(D, CH)                                                      \
+    {                                                                         \
+        const int ch_ = ((CH) < nch) ? (CH) : nch - 1;                        \
+        const int m_ = (ch_ << 6) + lane;                                     \
+        const int mt_ = (m_ < M) ? m_ : M - 1;                                \
+        const unsigned om_ = (unsigned)m_ * 16u, ot_ = (unsigned)mt_ * 8u;    \
+        asm volatile("global_load_dwordx4 %0, %1, %2"                         \
+                     : "=&v"(mq[D]) : "v"(om_), "s"(mk) : "memory");          \
+        asm volatile("global_load_dwordx2 %0, %1, %2"                         \
+                     : "=&v"(l1q[D]) : "v"(ot_), "s"(t1) : "memory");         \
+        asm volatile("global_load_dwordx2 %0, %1, %2"                         \
+                     : "=&v"(l0q[D]) : "v"(ot_), "s"(t0) : "memory");         \
+    }
+#pragma unroll
+    for (int d = 0; d < SEQP_DEPTH; d++) SEQP_LOAD(d, d)
+    for (int ch = 0; ch < nch_up; ch += SEQP_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SEQP_DEPTH; d++) {
+            asm volatile("s_waitcnt vmcnt(9)"
+                         : "+v"(mq[d]), "+v"(l1q[d]), "+v"(l0q[d]));
+            seqp_select<C0, C1>(mq[d], l1q[d], l0q[d],
+                                xs + (size_t)(d & 1) * 64 * SEQP_XS);
+            SEQP_LOAD(d, ch + d + SEQP_DEPTH)
+            seqp_barrier();
+        }
+    }
+    // nothing may be in flight into dead registers at the end of the wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef SEQP_LOAD
+}
+
+__global__ __launch_bounds__(256) void k_ll_seqp(
+    const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
+    long long nblk, const double *__restrict__ L1,
+    const double *__restrict__ L0, int K, long long ldo,
+    double *__restrict__ out)
+{
+    extern __shared__ double seqp_x[];          // [2][64][SEQP_XS]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const long long blk = blockIdx.x;
+    const int k = blockIdx.y;
+    const int nch = Mpad >> 6;
+    const int nch_up = (nch + SEQP_DEPTH - 1) & ~(SEQP_DEPTH - 1);
+    if (wave == 0) {
+        double acc = 0.0;
+        for (int ch = 0; ch < nch; ch++) {
+            seqp_barrier();                     // chunk ch is complete
+            const double2 *xr = (const double2 *)(seqp_x
+                + (size_t)(ch & 1) * 64 * SEQP_XS + (size_t)lane * SEQP_XS);
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                const double2 v = xr[u];
+                acc += v.x;
+                acc += v.y;
+            }
+        }
+        for (int ch = nch; ch < nch_up; ch++) seqp_barrier();
+        const long long slot = blk * 64 + lane;
+        if (slot < n) out[(size_t)slot * ldo + k] = acc;
+        return;
+    }
+    // wave-uniform bases (SGPR pairs); the lane enters as a 32-bit offset
+    const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
+    const double *__restrict__ t1 = L1 + (size_t)k * M;
+    const double *__restrict__ t0 = L0 + (size_t)k * M;
+    double *xs = seqp_x + lane;
+    if (wave == 1)
+        seqp_producer<0, 22>(mk, t1, t0, nch, nch_up, M, lane, xs);
+    else if (wave == 2)
+        seqp_producer<22, 43>(mk, t1, t0, nch, nch_up, M, lane, xs);
+    else
+        seqp_producer<43, 64>(mk, t1, t0, nch, nch_up, M, lane, xs);
+}
+
+// tables of a K2p launch, pinned arena -> device: ONE trip over the host link
+// (the chains of a launch would each re-read them in place)
+__global__ __launch_bounds__(256) void k_stage_copy(
+    const double2 *__restrict__ src, double2 *__restrict__ dst, long long n2)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
 // K2t: per slot the two largest entries of out[s][k] + prior[k], k < K <= 64,
 // and the column of the largest (first on ties): the sweep's hint.  The
 // priors travel as kernel arguments (no memory to fetch them from); the matrix
@@ -1544,10 +1700,44 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
 
 #define SEQ_LDS_MAX ((size_t)144 << 10)
 
-// K2s on the caller's tables (c->tab_src: L1 [K][M] then L0 [K][M])
+// K2p on the caller's tables (c->tab_src: L1 [K][M] then L0 [K][M])
+static int issue_seqp(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
+                      double *d_out)
+{
+    static bool lds_raised = false;
+    if (!lds_raised) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seqp,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SEQP_LDS));
+        lds_raised = true;
+    }
+    const double *tabs = c->tab_src;
+    const size_t n2 = (size_t)K * c->M;         // double2 elements: 2 K M / 2
+    if (c->tun.seq_stage && (const void *)tabs != c->tab_in.p) {
+        // staged in the pinned arena: every chain of the launch would pull
+        // its table over the host link again - one copy kernel instead
+        if (ensure(c->tab_in, 2 * n2 * sizeof(double))) return 1;
+        hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+                           dim3(256), 0, c->stream, (const double2 *)tabs,
+                           (double2 *)c->tab_in.p, (long long)n2);
+        tabs = (const double *)c->tab_in.p;
+    }
+    dim3 grid((unsigned)v.nblk, (unsigned)K);
+    snprintf(c->last_name, sizeof(c->last_name), "k_ll_seqp");
+    hipLaunchKernelGGL(k_ll_seqp, grid, dim3(256), SEQP_LDS, c->stream,
+                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
+                       (long long)v.n, (long long)v.nblk, tabs,
+                       tabs + (size_t)K * c->M, (int)K, (long long)ldo, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// K2s on the caller's tables
 static int issue_seq(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                      double *d_out)
 {
+    if (c->tun.seq_kernel == 2 && v.nblk <= 0x7fffffff)
+        return issue_seqp(c, v, K, ldo, d_out);
     static bool lds_raised = false;
     if (!lds_raised) {
         HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq<1>,
@@ -1613,7 +1803,7 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     int rc;
     const size_t seq_lds = (size_t)(c->Mpad + 8) * sizeof(double2);
     if (!from_theta && c->tun.seq_kernel && !c->tun.force_kw
-        && seq_lds <= SEQ_LDS_MAX && K <= 65535) {
+        && (c->tun.seq_kernel == 2 || seq_lds <= SEQ_LDS_MAX) && K <= 65535) {
         rc = issue_seq(c, v, K, ldo, d_out);
         kw = -1;
         MS = 1;
