@@ -352,23 +352,35 @@ def mh_draws(G, M, n_sd):
 _threads_memo = {}
 
 
+def _host_cores():
+    """Cores this process may run on, divided by the chains that share them
+    (BNPC_HOST_SHARE, set per worker by bnpc_amd.mcmc)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    try:
+        share = max(1, int(os.environ.get('BNPC_HOST_SHARE') or 1))
+    except ValueError:
+        share = 1
+    return max(1, cores // share)
+
+
 def host_threads():
     """Size of the native host thread team (BNPC_HOST_THREADS; default
-    min(16, cores this process may run on); 1 = the calling thread only)."""
+    min(16, cores of this process / chains sharing them); 1 = the calling
+    thread only)."""
     env = os.environ.get('BNPC_HOST_THREADS')
-    n = _threads_memo.get(env)
+    key = (env, os.environ.get('BNPC_HOST_SHARE'))
+    n = _threads_memo.get(key)
     if n is None:
         try:
             n = int(env or 0)
         except ValueError:
             n = 0
         if n < 1:
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except (AttributeError, OSError):
-                cores = os.cpu_count() or 1
-            n = min(16, cores)
-        _threads_memo[env] = n
+            n = min(16, _host_cores())
+        _threads_memo[key] = n
     return n
 
 
@@ -404,11 +416,7 @@ def threads_for(elements):
     more than 16 gain nothing)."""
     n = host_threads()
     if elements >= 100000 and os.environ.get('BNPC_HOST_THREADS') is None:
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            cores = os.cpu_count() or 1
-        n = max(n, min(32, cores // 2))
+        n = max(n, min(32, _host_cores() // 2))
     return n
 
 

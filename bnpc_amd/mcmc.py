@@ -97,11 +97,16 @@ def device_for_chain(chain_index, n_devices=None):
     return chain_index % (n_devices or _visible_gpus())
 
 
-def _bind_worker_to_gpu(chain_index, n_devices=None):
+def _bind_worker_to_gpu(chain_index, n_devices=None, n_chains=1):
     """Called in the worker before its model creates a device context.  The
     assignment is explicit: a BNPC_DEVICE inherited from the parent's
-    environment does not pin every chain to one GPU."""
+    environment does not pin every chain to one GPU.  BNPC_HOST_SHARE tells
+    the worker how many chains run next to it on that GPU - they are bound to
+    the same NUMA node, so the default host thread team is that node's cores
+    divided among them (_lib.host_threads)."""
+    n_devices = n_devices or _visible_gpus()
     os.environ['BNPC_DEVICE'] = str(device_for_chain(chain_index, n_devices))
+    os.environ['BNPC_HOST_SHARE'] = str(max(1, -(-int(n_chains) // n_devices)))
 
 
 # ------------------------------------------------------------------- traces
@@ -518,7 +523,7 @@ class MCMC:
 
     def run_chain(self, chain_type, run_var, assign, i, verbosity):
         """Worker body (MCMC.py:126-135): seed, private model copy, init, run."""
-        _bind_worker_to_gpu(i)
+        _bind_worker_to_gpu(i, n_chains=len(self.seeds))
         np.random.seed(self.seeds[i])
         model = deepcopy(self.model)
         model.init(assign=assign)
@@ -560,7 +565,7 @@ class MCMC:
     def extend_chain(self, chain_no, add_steps):
         """MCMC.py:180-189; the worker re-seeds with the chain's own seed, as
         the reference does."""
-        _bind_worker_to_gpu(chain_no)
+        _bind_worker_to_gpu(chain_no, n_chains=len(self.seeds))
         np.random.seed(self.seeds[chain_no])
         chain = self.chains[chain_no]
         already = chain.get_steps()

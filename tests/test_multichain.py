@@ -306,3 +306,28 @@ def test_host_threads_are_kept_on_the_devices_numa_node(monkeypatch, tmp_path):
             str(tmp_path / 'node')) is None
     finally:
         os.sched_setaffinity(0, have)
+
+
+def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
+    """8 chains on 2 GPUs: 4 per GPU (and per NUMA node), so each worker's
+    default team is a quarter of its cores, capped at 16; an explicit
+    BNPC_HOST_THREADS wins."""
+    from bnpc_amd import mcmc
+    monkeypatch.delenv('BNPC_HOST_THREADS', raising=False)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(24)))
+    monkeypatch.setattr(_lib, '_threads_memo', {})
+    for chain in range(8):
+        mcmc._bind_worker_to_gpu(chain, n_devices=2, n_chains=8)
+        assert os.environ['BNPC_HOST_SHARE'] == '4'
+        assert os.environ['BNPC_DEVICE'] == str(chain % 2)
+        assert _lib.host_threads() == 6
+        assert _lib.threads_for(10 ** 6) == 6
+    mcmc._bind_worker_to_gpu(0, n_devices=8, n_chains=3)
+    assert os.environ['BNPC_HOST_SHARE'] == '1'
+    assert _lib.host_threads() == 16
+    assert _lib.threads_for(10 ** 6) == 16
+    monkeypatch.setenv('BNPC_HOST_THREADS', '5')
+    monkeypatch.setenv('BNPC_HOST_SHARE', '4')
+    assert _lib.host_threads() == 5
+    monkeypatch.delenv('BNPC_HOST_SHARE')
+    monkeypatch.delenv('BNPC_DEVICE', raising=False)

@@ -1,0 +1,68 @@
+// How long after a kernel has finished does hipStreamSynchronize return?
+// The kernel's last act is a system-scope store to a pinned flag the host
+// spins on; compared with the return of the synchronisation.  Dev probe.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <algorithm>
+#include <vector>
+
+__global__ void k_flag(volatile unsigned *flag, unsigned v, int spin)
+{
+    // a little work, so that the launch is not empty
+    unsigned x = v;
+    for (int i = 0; i < spin; i++) x = x * 1664525u + 1013904223u;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        __threadfence_system();
+        flag[0] = v | (x & 0u);
+    }
+}
+
+static double now()
+{
+    return std::chrono::duration<double>(
+        std::chrono::steady_clock::now().time_since_epoch()).count() * 1e6;
+}
+
+int main()
+{
+    unsigned *flag;
+    hipHostMalloc(&flag, 64, hipHostMallocDefault);
+    unsigned *dflag;
+    hipHostGetDevicePointer((void **)&dflag, flag, 0);
+    hipStream_t s;
+    hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    for (int mode = 0; mode < 2; mode++) {
+        std::vector<double> t_launch, t_flag, t_sync;
+        for (unsigned r = 1; r <= 2000; r++) {
+            flag[0] = 0;
+            double t0 = now();
+            hipLaunchKernelGGL(k_flag, dim3(1), dim3(64), 0, s, dflag, r, 2000);
+            double t1 = now();
+            double tf = 0;
+            if (mode == 0) {
+                while (*(volatile unsigned *)flag != r) {}
+                tf = now();
+            }
+            hipStreamSynchronize(s);
+            double t2 = now();
+            if (r > 100) {
+                t_launch.push_back(t1 - t0);
+                t_flag.push_back(tf - t0);
+                t_sync.push_back(t2 - t0);
+            }
+        }
+        auto med = [](std::vector<double> &v) {
+            std::sort(v.begin(), v.end());
+            return v[v.size() / 2];
+        };
+        if (mode == 0)
+            printf("spin on flag, then sync: launch call %.2f us, flag seen %.2f us, "
+                   "sync returned %.2f us after the launch began\n",
+                   med(t_launch), med(t_flag), med(t_sync));
+        else
+            printf("sync only:               launch call %.2f us, sync returned %.2f us\n",
+                   med(t_launch), med(t_sync));
+    }
+    return 0;
+}
