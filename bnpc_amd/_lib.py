@@ -352,24 +352,38 @@ def mh_draws(G, M, n_sd):
 _threads_memo = {}
 
 
-def _host_cores():
-    """Cores this process may run on, divided by the chains that share them
+def _host_share():
+    """Chains running next to this one on the same GPU / NUMA node
     (BNPC_HOST_SHARE, set per worker by bnpc_amd.mcmc)."""
     try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        cores = os.cpu_count() or 1
-    try:
-        share = max(1, int(os.environ.get('BNPC_HOST_SHARE') or 1))
+        return max(1, int(os.environ.get('BNPC_HOST_SHARE') or 1))
     except ValueError:
-        share = 1
-    return max(1, cores // share)
+        return 1
+
+
+def _host_cores():
+    """Logical CPUs this process may run on."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def _default_team(cap):
+    """A chain alone: one rank per CPU up to `cap`.  Chains sharing a node:
+    a quarter of the logical CPUs divided among them (measured on the
+    2 x 64-core MI355X host, 128 logical CPUs per node, config 3, aggregate
+    steps/s: 8 chains x 16 ranks 1980, x 8 2550, x 4 3170, x 2 2830;
+    4 chains x 16 1990, x 8 2280, x 4 2020; 2 chains x 16 1320, x 8 1240)."""
+    share = _host_share()
+    if share == 1:
+        return max(1, min(cap, _host_cores()))
+    return max(1, min(cap, _host_cores() // (4 * share)))
 
 
 def host_threads():
-    """Size of the native host thread team (BNPC_HOST_THREADS; default
-    min(16, cores of this process / chains sharing them); 1 = the calling
-    thread only)."""
+    """Size of the native host thread team (BNPC_HOST_THREADS; default: see
+    _default_team; 1 = the calling thread only)."""
     env = os.environ.get('BNPC_HOST_THREADS')
     key = (env, os.environ.get('BNPC_HOST_SHARE'))
     n = _threads_memo.get(key)
@@ -379,7 +393,7 @@ def host_threads():
         except ValueError:
             n = 0
         if n < 1:
-            n = min(16, _host_cores())
+            n = _default_team(16)
         _threads_memo[key] = n
     return n
 
@@ -416,7 +430,7 @@ def threads_for(elements):
     more than 16 gain nothing)."""
     n = host_threads()
     if elements >= 100000 and os.environ.get('BNPC_HOST_THREADS') is None:
-        n = max(n, min(32, _host_cores() // 2))
+        n = max(n, min(_default_team(32), _host_cores() // 2))
     return n
 
 

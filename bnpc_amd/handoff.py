@@ -22,7 +22,7 @@ before the run), forking would hand the children a runtime they cannot use, so
 the workers are spawned instead (the model then travels by pickle, once).
 """
 import multiprocessing as mp
-from multiprocessing import connection, shared_memory
+from multiprocessing import connection, resource_tracker, shared_memory
 import pickle
 import traceback
 
@@ -40,6 +40,13 @@ def pack(obj):
         at += size
     name = block.name
     block.close()
+    # the block now belongs to whoever unpacks it: without this the creating
+    # process's resource tracker unlinks it again at exit ("leaked
+    # shared_memory objects") - or, if it exits first, before it was read
+    try:
+        resource_tracker.unregister(block._name, 'shared_memory')
+    except Exception:       # noqa: BLE001 - bookkeeping only
+        pass
     return data, name, sizes
 
 

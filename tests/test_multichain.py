@@ -309,23 +309,28 @@ def test_host_threads_are_kept_on_the_devices_numa_node(monkeypatch, tmp_path):
 
 
 def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
-    """8 chains on 2 GPUs: 4 per GPU (and per NUMA node), so each worker's
-    default team is a quarter of its cores, capped at 16; an explicit
-    BNPC_HOST_THREADS wins."""
+    """8 chains on 2 GPUs: 4 per GPU (and per NUMA node): each worker's
+    default team is a quarter of the node's logical CPUs divided by 4, and
+    idle ranks spin briefly; a chain alone on its GPU keeps the full team; an
+    explicit BNPC_HOST_THREADS / BNPC_HOST_SPIN_US wins."""
     from bnpc_amd import mcmc
     monkeypatch.delenv('BNPC_HOST_THREADS', raising=False)
-    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(24)))
+    monkeypatch.delenv('BNPC_HOST_SPIN_US', raising=False)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(128)))
     monkeypatch.setattr(_lib, '_threads_memo', {})
     for chain in range(8):
         mcmc._bind_worker_to_gpu(chain, n_devices=2, n_chains=8)
         assert os.environ['BNPC_HOST_SHARE'] == '4'
+        assert os.environ['BNPC_HOST_SPIN_US'] == '5'
         assert os.environ['BNPC_DEVICE'] == str(chain % 2)
-        assert _lib.host_threads() == 6
-        assert _lib.threads_for(10 ** 6) == 6
+        assert _lib.host_threads() == 8
+        assert _lib.threads_for(10 ** 6) == 8
+    monkeypatch.delenv('BNPC_HOST_SPIN_US')
     mcmc._bind_worker_to_gpu(0, n_devices=8, n_chains=3)
     assert os.environ['BNPC_HOST_SHARE'] == '1'
+    assert 'BNPC_HOST_SPIN_US' not in os.environ
     assert _lib.host_threads() == 16
-    assert _lib.threads_for(10 ** 6) == 16
+    assert _lib.threads_for(10 ** 6) == 32
     monkeypatch.setenv('BNPC_HOST_THREADS', '5')
     monkeypatch.setenv('BNPC_HOST_SHARE', '4')
     assert _lib.host_threads() == 5
