@@ -86,7 +86,7 @@ struct View {
 // Switches, read from the environment when a context is created and again
 // by bnpc_reload_options (A/B tools and tests); never on the launch path.
 struct Tunables {
-    int msplit = 1, msplit_waves = 4096, msplit_max = 64;
+    int msplit = 1, msplit_waves = 0, msplit_max = 64;  // waves 0 = auto
     int xcd_remap = 1, ll_asm = 2, asm2_min_wgs = 448;
     int tables_flat_max = 1 << 20, force_kw = 0;
     int zero_copy = 1;              // small payloads are read / written in
@@ -110,7 +110,7 @@ static int env_int(const char *name, int dflt)
 static void read_tunables(Tunables &t)
 {
     t.msplit = env_int("BNPC_MSPLIT", 1);
-    t.msplit_waves = env_int("BNPC_MSPLIT_WAVES", 4096);
+    t.msplit_waves = env_int("BNPC_MSPLIT_WAVES", 0);
     t.msplit_max = env_int("BNPC_MSPLIT_MAX", 64);
     t.xcd_remap = env_int("BNPC_XCD_REMAP", 1);
     t.ll_asm = env_int("BNPC_LL_ASM", 2);       // 0 C++, 1 asm, 2 asm x2
@@ -1559,16 +1559,32 @@ static int pick_kw(int64_t K)
     return best;
 }
 
-// mutation split of a small launch: enough waves to fill the chip, chunks of
-// at least 16 mutations, a multiple of 8 (stage sizes divide 8)
+// Mutation split of a launch with too few waves to fill the chip and hide
+// its table loads.  `waves` = slot blocks x cluster groups.  The split kernel
+// gives the 4 waves of a workgroup 4 consecutive chunks, so the chunk count
+// is a multiple of 4 (2 or 3 chunks leave waves idle: 50000 x 5000 x 30 in 2
+// chunks 1172 us, in 4 chunks 688 us) and exactly 4 needs no combine pass.
+// Measured (tools/msplit_tune_big.py): 50000 x 5000: K = 53 unsplit 1322 us,
+// 4 chunks 1117 us; K = 100 (10166 waves) unsplit 2060 us, 4 chunks 2105 us
+// -> no split from 8192 waves on; small launches want more chunks (10000 x
+// 2000 x 40, 785 waves: 6 chunks 121 us, 21 chunks 100 us, 42 chunks 92 us;
+// 5000 x 1000 x 14, 158 waves: 25 / 42 / 63 chunks 25.0 / 23.3 / 27.1 us).  Chunks
+// hold at least 16 mutations, a multiple of 8 (stage sizes divide 8).
+static int64_t msplit_limit(const Tunables &tun)
+{
+    return tun.msplit_waves > 0 ? tun.msplit_waves : 8192;
+}
+
 static void pick_msplit(const Tunables &tun, int64_t waves, int Mt,
                         bool allowed, int *MS, int *m_chunk)
 {
     *MS = 1;
     *m_chunk = Mt;
-    const int64_t target = tun.msplit_waves;
-    if (!allowed || waves >= target) return;
+    if (!allowed || waves >= msplit_limit(tun)) return;
+    const int64_t target = tun.msplit_waves > 0 ? tun.msplit_waves
+        : (waves >= 512 && waves < 2048 ? 16384 : 8192);
     int64_t want = (target + waves - 1) / waves;
+    want = (want + 3) / 4 * 4;
     const int64_t cap = tun.msplit_max;
     if (want > cap) want = cap;
     int chunk = (int)((Mt + want - 1) / want);
@@ -1790,7 +1806,7 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     // LDS, which beats the narrower C++ tilings from K = 2 on (measured
     // K = 2..12: 11-17 us against 11-25 us; profiles/r01/small_launch_study.md)
     if (K >= 2 && from_theta && c->tun.msplit
-        && v.nblk * ((K + 7) / 8) < c->tun.msplit_waves)
+        && v.nblk * ((K + 7) / 8) < msplit_limit(c->tun))
         kw = 8;
     if (c->tun.force_kw) kw = c->tun.force_kw;
     // Sums over caller-built tables keep the strict mutation order (they are
