@@ -117,9 +117,17 @@ class Ranks:
         # run on a 1-GPU box) ranks share devices round-robin
         from bnpc_amd import _lib
         try:
-            self.device = self.local_rank % max(1, _lib.device_count())
+            n_dev = max(1, _lib.device_count())
         except RuntimeError:        # no GPU: the CPU tests of this harness
-            self.device = 0
+            n_dev = 1
+        self.device = self.local_rank % n_dev
+        # ranks bound to the same NUMA node divide its CPUs (as the chains of
+        # a multi-chain run do, bnpc_amd.mcmc._bind_worker_to_gpu)
+        local = int(os.environ.get('LOCAL_WORLD_SIZE', self.world))
+        share = _lib.host_share(local, n_dev)
+        if share > 1:
+            os.environ.setdefault('BNPC_HOST_SHARE', str(share))
+            os.environ.setdefault('BNPC_HOST_SPIN_US', '5')
         return self
 
     def barrier_sync(self):

@@ -229,6 +229,31 @@ def _cpus_of_node(node, sysfs='/sys/devices/system/node'):
     return cpus
 
 
+def numa_node_count(sysfs='/sys/devices/system/node'):
+    """NUMA nodes that have CPUs (1 if the layout cannot be read)."""
+    n = 0
+    try:
+        for entry in os.listdir(sysfs):
+            if entry.startswith('node') and entry[4:].isdigit():
+                try:
+                    n += bool(_cpus_of_node(int(entry[4:]), sysfs))
+                except (OSError, ValueError):
+                    pass
+    except OSError:
+        pass
+    return max(1, n)
+
+
+def host_share(n_chains, n_devices, nodes=None):
+    """How many of `n_chains` concurrent chains, dealt round-robin over
+    `n_devices` GPUs, end up on the CPUs of one NUMA node (every chain is bound
+    to the node of its GPU; the GPUs are assumed spread evenly over the
+    nodes): what BNPC_HOST_SHARE carries."""
+    nodes = nodes or numa_node_count()
+    groups = max(1, min(int(nodes), int(n_devices), int(n_chains)))
+    return max(1, -(-int(n_chains) // groups))
+
+
 def bind_near_device(device, pci_sysfs='/sys/bus/pci/devices',
             node_sysfs='/sys/devices/system/node'):
     """Keep this process (and the host threads it starts later) on the CPUs

@@ -101,12 +101,13 @@ def _bind_worker_to_gpu(chain_index, n_devices=None, n_chains=1):
     """Called in the worker before its model creates a device context.  The
     assignment is explicit: a BNPC_DEVICE inherited from the parent's
     environment does not pin every chain to one GPU.  BNPC_HOST_SHARE tells
-    the worker how many chains run next to it on that GPU - they are bound to
-    the same NUMA node, so the default host thread team is that node's cores
-    divided among them (_lib.host_threads)."""
+    the worker how many chains end up on the CPUs of its NUMA node (each is
+    bound to the node of its GPU): the default host thread team is a share of
+    that node (_lib.host_threads)."""
+    from bnpc_amd import _lib
     n_devices = n_devices or _visible_gpus()
     os.environ['BNPC_DEVICE'] = str(device_for_chain(chain_index, n_devices))
-    share = max(1, -(-int(n_chains) // n_devices))
+    share = _lib.host_share(n_chains, n_devices)
     os.environ['BNPC_HOST_SHARE'] = str(share)
     if share > 1:
         # idle ranks of a shared node give their CPU back quickly (8 chains x

@@ -318,6 +318,10 @@ def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
     monkeypatch.delenv('BNPC_HOST_SPIN_US', raising=False)
     monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(128)))
     monkeypatch.setattr(_lib, '_threads_memo', {})
+    monkeypatch.setattr(_lib, 'numa_node_count', lambda: 2)
+    # 8 GPUs on 2 nodes, 8 chains: 4 chains per node although 1 per GPU
+    assert _lib.host_share(8, 8) == 4 and _lib.host_share(2, 8) == 1
+    assert _lib.host_share(8, 1) == 8 and _lib.host_share(3, 8, nodes=1) == 3
     for chain in range(8):
         mcmc._bind_worker_to_gpu(chain, n_devices=2, n_chains=8)
         assert os.environ['BNPC_HOST_SHARE'] == '4'
@@ -326,7 +330,7 @@ def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
         assert _lib.host_threads() == 8
         assert _lib.threads_for(10 ** 6) == 8
     monkeypatch.delenv('BNPC_HOST_SPIN_US')
-    mcmc._bind_worker_to_gpu(0, n_devices=8, n_chains=3)
+    mcmc._bind_worker_to_gpu(0, n_devices=8, n_chains=2)
     assert os.environ['BNPC_HOST_SHARE'] == '1'
     assert 'BNPC_HOST_SPIN_US' not in os.environ
     assert _lib.host_threads() == 16

@@ -40,6 +40,9 @@ python3 tools/ll_microbench.py > $out/ll_microbench.md 2>&1
 python3 tools/profile_steps.py c3 200 > $out/host_step_breakdown_after.log 2>&1
 python3 tools/gibbs_bench.py > $out/gibbs_bench.log 2>&1
 python3 tools/mh_bench.py > $out/mh_bench.log 2>&1
+python3 tools/msplit_tune_big.py > $out/msplit_big.log 2>&1
+python3 tools/multichain_bench.py c3 2000 1 2 4 8 > $out/multichain_c3.log 2>&1
+python3 tools/multichain_bench.py c2 4000 1 2 4 8 > $out/multichain_c2.log 2>&1
 python3 bench.py --config c2 --steps 200 > $out/bench_config2.json 2> /dev/null
 python3 bench.py --config c4 --steps 100 --cpu-steps 0 > $out/bench_config4.json 2> /dev/null
 python3 bench.py --config c5 --steps 60 --warmup 5 --cpu-steps 0 > $out/bench_config5.json 2> /dev/null

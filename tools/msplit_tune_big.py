@@ -11,14 +11,14 @@ from bnpc_amd import _lib  # noqa: E402
 import bench  # noqa: E402
 
 rng = np.random.RandomState(1)
-for N, M, Ks in ((10000, 2000, (12, 22, 40)), (50000, 5000, (10, 53, 100)),
+for N, M, Ks in ((10000, 2000, (12, 22, 40)), (50000, 5000, (10, 30, 53, 100)),
         (5000, 1000, (14, 40))):
     data = bench.synth(0, N, M, 10, 0.2)
     ctx = _lib.Context(data=data)
     for K in Ks:
         theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
             .astype(np.float32)
-        for waves in (1, 4096, 8192, 16384, 32768):
+        for waves in (0, 1, 4096, 8192, 16384, 32768):     # 0 = the default rule
             os.environ['BNPC_MSPLIT_WAVES'] = str(waves)
             ctx.reload_options()
             ctx.ll_theta(0, theta, 0.01, 0.2, fetch=False)
