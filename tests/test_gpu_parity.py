@@ -96,6 +96,35 @@ def test_ll_tables_is_bit_exact(golden_dir):
         ctx.close()
 
 
+@pytest.mark.parametrize('seq', ['2', '1', '0'])
+def test_ll_tables_bits_on_ragged_shapes_and_views(seq, monkeypatch):
+    """bnpc_ll_tables on every kernel it can run through (2: the producer /
+    consumer pipeline, 1: one wave per chain, 0: the scalar-load tiling) at
+    shapes around the 64-slot and 64-mutation tile edges, whole matrix and
+    gathered views, tables holding -inf (an impossible observation) and +0.0:
+    the strict-order sums of the oracle, bit for bit."""
+    monkeypatch.setenv('BNPC_SEQ_KERNEL', seq)
+    rng = np.random.RandomState(int(seq) + 3)
+    for N, M, K in ((1, 1, 1), (63, 64, 2), (65, 65, 3), (130, 127, 1),
+            (517, 1000, 2), (64, 4097, 2), (200, 129, 5)):
+        data = (rng.random_sample((N, M)) < 0.35).astype(float)
+        data[rng.random_sample(data.shape) < 0.2] = np.nan
+        theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
+            .astype(np.float32)
+        L1, L0 = host_tables(theta, 0.01, 0.2)
+        if M > 2:
+            L1[0, 1] = -np.inf
+            L0[K - 1, M - 1] = 0.0
+        ctx = _lib.Context(data=data)
+        ctx.reload_options()
+        want = table_sums(data, L1, L0)
+        assert np.array_equal(ctx.ll_tables(0, L1, L0), want), (N, M, K)
+        cells = rng.permutation(N)[:max(1, N // 2)]
+        ctx.view_set(1, cells)
+        assert np.array_equal(ctx.ll_tables(1, L1, L0), want[cells]), (N, M, K)
+        ctx.close()
+
+
 @pytest.mark.parametrize('kw', ['1', '2', '4', '8'])
 def test_every_cluster_tiling_gives_identical_bits(kw, monkeypatch):
     rng = np.random.RandomState(5)
