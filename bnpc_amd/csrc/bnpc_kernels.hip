@@ -94,6 +94,7 @@ struct Tunables {
     int64_t zc_out_max = 512 << 10;
     int64_t zc_sweep_max = 0;       // the sweep's matrix (pinned) in place
     int mask_counts_max = 64;       // segments for the mask-popcount counts
+    int ll_prefetch = -1;           // k_ll8_asm L2 prefetch: -1 auto, 0, 1
     int seq_kernel = 2;             // caller-built tables: 2 = k_ll_seqp
                                     // (pipeline), 1 = k_ll_seq, 0 = k_ll
     int seq_stage = 1;              // k_ll_seqp: tables copied to the device
@@ -125,6 +126,7 @@ static void read_tunables(Tunables &t)
     t.zc_out_max = (int64_t)env_int("BNPC_ZC_OUT_KB", 512) << 10;
     t.zc_sweep_max = (int64_t)env_int("BNPC_ZC_SWEEP_KB", 0) << 10;
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
+    t.ll_prefetch = env_int("BNPC_LL_PREFETCH", -1);
     t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 2);
     t.seq_stage = env_int("BNPC_SEQ_STAGE", 1);
     t.seq_kc = env_int("BNPC_SEQ_KC", 1);
@@ -678,9 +680,16 @@ template <int CB, bool SPLIT>
 __global__ __launch_bounds__(256) void k_ll8_asm(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
-    double *__restrict__ out, int xcd_remap, int MS_arg, int m_chunk)
+    double *__restrict__ out, int xcd_remap, int MS_arg, int m_chunk,
+    const ulonglong2 *masks_pf, const double *T_pf)
 {
+    // masks_pf / T_pf: the same two arrays again, or NULL (no prefetch).  The
+    // prefetch below hands addresses to inline assembly; were they derived
+    // from the __restrict__ parameters, the compiler would have to assume the
+    // assembly may write there and would turn every SCALAR load of the kernel
+    // into a vector load.
     constexpr int KW = 8;
+    const bool PF = masks_pf != nullptr;
     const int MS = SPLIT ? MS_arg : 1;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -711,8 +720,9 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     for (int c = 0; c < CB; c++)
         mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad
             + (m_len > 0 ? m_begin : 0);
-    const double *__restrict__ tp = T
-        + ((size_t)g * Mt + (m_len > 0 ? m_begin : 0)) * (2 * KW);
+    const size_t t_off = ((size_t)g * Mt + (m_len > 0 ? m_begin : 0))
+        * (2 * KW);                     // of this wave's first table stage
+    const double *__restrict__ tp = T + t_off;
 
     double acc[CB][KW];
 #pragma unroll
@@ -730,7 +740,45 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait
     // for the current stage FIRST, then issue the next stage's loads, then
     // the masked adds run under those loads.
+    //
+    // L2 prefetch (PF): with M in the thousands the streams a wave walks no
+    // longer sit in its XCD's L2 - 80 KB of masks per slot block (782 blocks
+    // at config 5) or 640 KB of table per cluster group (thousands of groups
+    // in a first-sweep tile) - and a scalar load that goes to HBM costs
+    // several stages of adds.  Every 64 mutations the wave touches the masks
+    // and the table of the NEXT 64 with vector loads into a register nobody
+    // reads (never waited for until the wave ends): by the time the scalar
+    // loads get there the lines are in L2.  10 vector loads per 2048 adds.
+    // (No "memory" clobber on these: it would cost the kernel its scalar
+    // loads - the compiler only keeps uniform loads scalar while nothing in
+    // the kernel may write memory.)
+    typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));
+    pf_u32x4 pf_sink = {0u, 0u, 0u, 0u};
+    // wave-uniform bases in SGPRs + a per-lane byte offset that does not
+    // depend on m (a lane-dependent induction variable would make the
+    // compiler express the SCALAR loads through it, i.e. as vector loads)
+    const unsigned pf_lo = (unsigned)lane * 16u, pf_hi = pf_lo + 4096u;
     for (int m = 0; m < m_len; m += 2) {        // chunks are multiples of 8
+        if (PF && (m & 63) == 0 && m + 64 < m_len) {
+            const int mp = m + 64;
+#pragma unroll
+            for (int c = 0; c < CB; c++) {
+                const ulonglong2 *a = masks_pf + mo[c] + mp;
+                asm volatile("global_load_dwordx4 %0, %1, %2"
+                             : "+v"(pf_sink) : "v"(pf_lo), "s"(a));
+            }
+            // 8 stages of table (16 doubles each) per KiB; T keeps 8 stages
+            // of slack behind the last group
+            const double *t64 = T_pf + t_off + (size_t)mp * 16;
+#define PF_TAB(I, OFF, IMM)                                                   \
+            if (m_begin + mp + 8 * (I) < Mt)                                  \
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM    \
+                             : "+v"(pf_sink) : "v"(OFF), "s"(t64));
+            PF_TAB(0, pf_lo, 0) PF_TAB(1, pf_lo, 1024) PF_TAB(2, pf_lo, 2048)
+            PF_TAB(3, pf_lo, 3072) PF_TAB(4, pf_hi, 0) PF_TAB(5, pf_hi, 1024)
+            PF_TAB(6, pf_hi, 2048) PF_TAB(7, pf_hi, 3072)
+#undef PF_TAB
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);     // stage A landed
 #pragma unroll
         for (int c = 0; c < CB; c++) mb[c] = masks[mo[c] + m + 1];
@@ -747,6 +795,9 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
         for (int c = 0; c < CB; c++) ll_step8(acc[c], mb[c], tb);
         tp += 32;
     }
+
+    if (PF)     // the sink stays allocated to the end; nothing in flight
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
 
     if constexpr (SPLIT) {
         // sums of the 4 chunks of this workgroup, added in wave order
@@ -1608,6 +1659,12 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     ARGCHK(nwg < (1ll << 31), "launch too large");
     const int xcd = c->tun.xcd_remap;
     const int impl = c->tun.ll_asm;                 // 0 C++, 1 asm, 2 asm x2
+    // L2 prefetch of the mask / table streams: when they cannot all sit in
+    // one XCD's 4 MiB L2 (BNPC_LL_PREFETCH: 0 never, 1 always, default auto)
+    const size_t stream_bytes = (size_t)v.nblk * c->Mpad * 16
+        + (size_t)G * c->Mt * 2 * KW * sizeof(double) / 8;
+    const int pf = c->tun.ll_prefetch < 0 ? (stream_bytes > (3u << 20))
+                                           : c->tun.ll_prefetch;
     double *dst = d_out;
     if (MS > 1) {
         if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double))) return 1;
@@ -1626,7 +1683,9 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,        \
                        (long long)v.n, (long long)v.nblk,                    \
                        (const double *)c->tabs.p, (int)K, (long long)ldo,    \
-                       dst, xcd, MS, m_chunk)
+                       dst, xcd, MS, m_chunk,                                \
+                       pf ? (const ulonglong2 *)v.masks.p : nullptr,         \
+                       pf ? (const double *)c->tabs.p : nullptr)
     const char *combine = "";
     if (KW == 8 && impl == 2 && wg2 >= c->tun.asm2_min_wgs) {
         if (MS > 1) {
