@@ -11,7 +11,8 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libbnpc_hip.so')
 
-MAX_VIEWS = 5
+MAX_VIEWS = 6
+TILE_SLOTS = 3      # include/bnpc_hip.h: BNPC_TILE_SLOTS
 MAX_TRIALS = 4
 
 _i64 = C.c_int64
@@ -89,6 +90,7 @@ SIGNATURES = {
     'bnpc_shape': (C.c_int, [_ctx, _pi64, _pi64]),
     'bnpc_cell_counts': (C.c_int, [_ctx, _pi32, _pi32]),
     'bnpc_view_set': (C.c_int, [_ctx, C.c_int, _pi64, _i64]),
+    'bnpc_view_set_slot': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_int]),
     'bnpc_view_size': (C.c_int, [_ctx, C.c_int, _pi64]),
     'bnpc_ll_theta': (C.c_int, [_ctx, C.c_int, _pf, _i64, C.c_double,
         C.c_double, _pd, _i64]),
@@ -675,6 +677,14 @@ class Context:
             cells.size), 'view_set')
         return cells.size
 
+    def view_set_slot(self, view, cells, slot):
+        """view_set for the tile that will be issued on `slot`: returns
+        without waiting for the device."""
+        cells = as_i64(cells)
+        check(self._lib.bnpc_view_set_slot(self._h, view,
+            ptr(cells, C.c_int64), cells.size, slot), 'view_set_slot')
+        return cells.size
+
     def view_size(self, view):
         n = _i64(0)
         check(self._lib.bnpc_view_size(self._h, view, C.byref(n)),
@@ -779,7 +789,8 @@ class Context:
         return np.ctypeslib.as_array(host, shape=(n, ld))
 
     def ll_rows_issue(self, view, rows, FP, FN, ld, slot):
-        """Start ll_rows_pinned for pinned buffer `slot` (0 | 1) and return."""
+        """Start ll_rows_pinned for pinned buffer `slot` (0 .. TILE_SLOTS - 1)
+        and return."""
         rows = as_i64(rows)
         check(self._lib.bnpc_ll_rows_issue(self._h, view,
             ptr(rows, C.c_int64), rows.size, float(FP), float(FN), ld, slot),

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <sys/mman.h>
 #include <vector>
 #include <algorithm>
 
@@ -183,14 +184,30 @@ struct bnpc_ctx {
     const float *theta_src = nullptr;
     const double *tab_src = nullptr;
     const long long *cells_src = nullptr;
-    // double-buffered pinned results of issued (asynchronous) tiles
-    void *tile_pin[2] = {nullptr, nullptr};
-    size_t tile_cap[2] = {0, 0};
-    size_t tile_bytes[2] = {0, 0};
-    void *tile_rows[2] = {nullptr, nullptr};    // pinned staging of the ids
-    size_t tile_rows_cap[2] = {0, 0};
-    hipEvent_t tile_done[2] = {nullptr, nullptr};
-    bool tile_pending[2] = {false, false};
+    // Issued (asynchronous) tiles: up to BNPC_TILE_SLOTS in flight, each with
+    // its own pinned result buffer.  The sums of consecutive tiles alternate
+    // between two device buffers and the copy to the host runs on its own
+    // stream, so the copy of one tile overlaps the sums of the next.
+    void *tile_pin[BNPC_TILE_SLOTS] = {};
+    size_t tile_cap[BNPC_TILE_SLOTS] = {};
+    size_t tile_bytes[BNPC_TILE_SLOTS] = {};
+    void *tile_rows[BNPC_TILE_SLOTS] = {};      // pinned staging of the ids
+    size_t tile_rows_cap[BNPC_TILE_SLOTS] = {};
+    void *tile_cells[BNPC_TILE_SLOTS] = {};     // ... and of the tile's cells
+    size_t tile_cells_cap[BNPC_TILE_SLOTS] = {};
+    hipEvent_t tile_done[BNPC_TILE_SLOTS] = {}; // copy landed in tile_pin
+    bool tile_pending[BNPC_TILE_SLOTS] = {};
+    DevBuf tile_out[2];                         // by parity of the issue count
+    hipEvent_t tile_summed[2] = {};             // sums written to tile_out
+    hipEvent_t tile_out_free[2] = {};           // its last copy has left
+    uint64_t tile_seq = 0;
+    hipStream_t copy_stream = nullptr;
+    bool any_tile_pending() const
+    {
+        for (bool p : tile_pending)
+            if (p) return true;
+        return false;
+    }
     // configuration of the last k_ll launch (bnpc_bench_ll re-issues it)
     int last_kw = 0, last_view = -1, last_ms = 1, last_mchunk = 0;
     int64_t last_K = 0, last_ldo = 0;
@@ -211,6 +228,85 @@ static int ensure(DevBuf &b, size_t bytes)
     HIPCHK(hipMalloc(&b.p, cap));
     b.cap = cap;
     return 0;
+}
+
+// Large pinned host buffers (result matrices, tiles: hundreds of MiB).
+// hipHostMalloc pins 4 KiB pages - 45-48 ms per 300 MiB on the MI355X host,
+// and a first sweep needs two or three of them.  Anonymous memory on
+// transparent huge pages, touched and then registered, costs 17 + 1 ms for the
+// same size and is the same DMA target (57 GB/s either way;
+// tools/ubench/pin_probe.hip).  Falls back to hipHostMalloc when huge pages
+// are switched off (4 KiB pages would make this route the slower one) or
+// anything fails.  `cap` identifies the route at release time: huge-page
+// buffers have a capacity that is a multiple of 2 MiB and are remembered.
+#define PIN_HUGE_MIN ((size_t)16 << 20)
+#define PIN_HUGE_ALIGN ((size_t)2 << 20)
+
+static bool thp_available()
+{
+    static const bool ok = [] {
+        if (const char *e = getenv("BNPC_PIN_HUGE"))
+            if (e[0] == '0') return false;
+        FILE *f = fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r");
+        if (!f) return false;
+        char line[128] = {0};
+        const bool got = fgets(line, sizeof line, f) != nullptr;
+        fclose(f);
+        return got && !strstr(line, "[never]");
+    }();
+    return ok;
+}
+
+static std::vector<void *> &huge_pins()
+{
+    static std::vector<void *> v;
+    return v;
+}
+
+static int pinned_alloc(void **out, size_t *cap, size_t bytes)
+{
+    *out = nullptr;
+    *cap = 0;
+    if (bytes >= PIN_HUGE_MIN && thp_available()) {
+        const size_t len = (bytes + PIN_HUGE_ALIGN - 1) & ~(PIN_HUGE_ALIGN - 1);
+        char *raw = (char *)mmap(nullptr, len + PIN_HUGE_ALIGN,
+                                 PROT_READ | PROT_WRITE,
+                                 MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (raw != (char *)MAP_FAILED) {
+            char *p = (char *)(((uintptr_t)raw + PIN_HUGE_ALIGN - 1)
+                               & ~(uintptr_t)(PIN_HUGE_ALIGN - 1));
+            if (p > raw) munmap(raw, (size_t)(p - raw));
+            const size_t tail = (size_t)(raw + len + PIN_HUGE_ALIGN - (p + len));
+            if (tail) munmap(p + len, tail);
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            memset(p, 0, len);              // the pages exist before pinning
+            if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+                huge_pins().push_back(p);
+                *out = p;
+                *cap = len;
+                return 0;
+            }
+            (void)hipGetLastError();
+            munmap(p, len);
+        }
+    }
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    *cap = bytes;
+    return 0;
+}
+
+static void pinned_free(void *p, size_t cap)
+{
+    if (!p) return;
+    std::vector<void *> &v = huge_pins();
+    auto it = std::find(v.begin(), v.end(), p);
+    if (it != v.end()) {
+        v.erase(it);
+        (void)hipHostUnregister(p);
+        munmap(p, cap);
+    } else {
+        (void)hipHostFree(p);
+    }
 }
 
 #define STAGE_BYTES ((size_t)4 << 20)
@@ -326,13 +422,10 @@ static int ensure_pin(bnpc_ctx *c, size_t bytes)
 {
     c->pin_lazy_bytes = 0;      // a new request supersedes a matrix not fetched
     if (bytes <= c->pin_cap) return 0;
-    if (c->pin) HIPCHK(hipHostFree(c->pin));
+    pinned_free(c->pin, c->pin_cap);
     c->pin = nullptr;
     c->pin_cap = 0;
-    size_t cap = bytes + bytes / 4 + 4096;
-    HIPCHK(hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
-    c->pin_cap = cap;
-    return 0;
+    return pinned_alloc(&c->pin, &c->pin_cap, bytes + bytes / 4 + 4096);
 }
 
 // While a tile is in flight, run a call on the side lane: swap the stream and
@@ -341,8 +434,7 @@ struct SideLane {
     bnpc_ctx *c;
     bool on;
     explicit SideLane(bnpc_ctx *ctx)
-        : c(ctx), on(ctx->side_stream
-                     && (ctx->tile_pending[0] || ctx->tile_pending[1]))
+        : c(ctx), on(ctx->side_stream && ctx->any_tile_pending())
     {
         if (on) flip();
     }
@@ -1506,7 +1598,9 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
+                      &c->tile_out[0], &c->tile_out[1],
                       &c->chunks, &c->cnt, &c->partial, &c->part,
                       &c->lab_cnt, &c->theta_store, &c->row_idx,
                       &c->side_theta, &c->side_tabs, &c->side_out,
@@ -1516,16 +1610,22 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     for (View &v : c->views)
         if (v.masks.p) (void)hipFree(v.masks.p);
     if (c->rows) (void)hipFree(c->rows);
-    if (c->pin) (void)hipHostFree(c->pin);
+    pinned_free(c->pin, c->pin_cap);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
-    for (int s = 0; s < 2; s++) {
-        if (c->tile_pin[s]) (void)hipHostFree(c->tile_pin[s]);
-        if (c->tile_rows[s]) (void)hipHostFree(c->tile_rows[s]);
+    for (int s = 0; s < BNPC_TILE_SLOTS; s++) {
+        pinned_free(c->tile_pin[s], c->tile_cap[s]);
+        pinned_free(c->tile_rows[s], c->tile_rows_cap[s]);
+        pinned_free(c->tile_cells[s], c->tile_cells_cap[s]);
         if (c->tile_done[s]) (void)hipEventDestroy(c->tile_done[s]);
     }
+    for (int s = 0; s < 2; s++) {
+        if (c->tile_summed[s]) (void)hipEventDestroy(c->tile_summed[s]);
+        if (c->tile_out_free[s]) (void)hipEventDestroy(c->tile_out_free[s]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1583,6 +1683,52 @@ extern "C" int bnpc_view_set(bnpc_ctx *c, int view, const int64_t *cells,
     // the caller's buffer is only borrowed: finish the copy before returning
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+static int ensure_host(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return 0;
+    pinned_free(*p, *cap);
+    *p = nullptr;
+    *cap = 0;
+    // tiles of a sweep are sized to a byte budget: little slack is needed
+    return pinned_alloc(p, cap, bytes + bytes / 16 + 4096);
+}
+
+// bnpc_view_set for a tile of a tiled sweep: the cell list is staged in the
+// tile slot's own pinned buffer (read in place by the gather kernel) and
+// NOTHING is waited for - the stream may hold the sums of the tiles issued
+// before, which a synchronisation here would serialise with the host.  The
+// view is for work issued behind it on the context's stream
+// (bnpc_ll_rows_issue on the same slot).
+extern "C" int bnpc_view_set_slot(bnpc_ctx *c, int view, const int64_t *cells,
+                                  int64_t n, int slot)
+{
+    ARGCHK(c, "ctx is NULL");
+    ARGCHK(view >= 1 && view < BNPC_MAX_VIEWS, "view out of range");
+    ARGCHK(slot >= 0 && slot < BNPC_TILE_SLOTS, "slot out of range");
+    ARGCHK(n > 0 && cells, "empty cell list");
+    ARGCHK(!c->tile_pending[slot], "slot has an unconsumed tile");
+    for (int64_t i = 0; i < n; i++)
+        ARGCHK(cells[i] >= 0 && cells[i] < c->N, "cell index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    if (ensure_host(&c->tile_cells[slot], &c->tile_cells_cap[slot],
+                    n * sizeof(long long)))
+        return 1;
+    memcpy(c->tile_cells[slot], cells, n * sizeof(long long));
+    void *d = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&d, c->tile_cells[slot], 0));
+    // Tiles grow as the clusters die (1024 cells, then 1536, 2048, ...), and
+    // growing a device buffer means hipFree - a device-wide synchronisation
+    // in the middle of the pipeline.  Room for 4 x the first tile, at least
+    // 16384 cells (all cells if there are fewer), is taken at once.
+    View &v = c->views[view];
+    int64_t room = std::max<int64_t>(4 * n, 16384);
+    room = std::min<int64_t>(std::max<int64_t>(room, n), std::max(c->N, n));
+    if (ensure(v.masks, ((size_t)((room + 63) / 64) * c->Mpad + 8)
+                            * sizeof(ulonglong2)))
+        return 1;
+    return build_view(c, view, (const long long *)d, n);
 }
 
 extern "C" int bnpc_view_size(const bnpc_ctx *c, int view, int64_t *n)
@@ -1858,7 +2004,7 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     // kernels straight into pinned host memory (no copy-engine launch)
     void *zc_dev = nullptr;
     void *zc_host = out ? zc_result(c, out_bytes, &zc_dev) : nullptr;
-    if (!zc_host && ensure(c->out, out_bytes)) return 1;
+    if (!zc_host && !c->dst_override && ensure(c->out, out_bytes)) return 1;
     int kw = pick_kw(K);
     // A launch that will be split over the mutations runs the hand-placed
     // 8-cluster kernel whatever K is: its workgroups reduce 4 chunks through
@@ -1974,7 +2120,7 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     if (ldo == 0) ldo = K;
     ARGCHK(ldo >= K, "ldo smaller than K");
     *host = nullptr;
-    ARGCHK(!c->tile_pending[0] && !c->tile_pending[1],
+    ARGCHK(!c->any_tile_pending(),
            "not available while an issued tile is in flight");
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
     if (bytes && ensure_pin(c, bytes)) return 1;
@@ -2034,7 +2180,7 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
     ARGCHK(theta, "theta is NULL");
     ARGCHK(ldo >= K, "ldo smaller than K");
     *host = nullptr;
-    ARGCHK(!c->tile_pending[0] && !c->tile_pending[1],
+    ARGCHK(!c->any_tile_pending(),
            "not available while an issued tile is in flight");
     const size_t bytes = (size_t)n * ldo * sizeof(double);
     if (bytes && ensure_pin(c, bytes)) return 1;
@@ -2149,27 +2295,16 @@ extern "C" int bnpc_ll_rows_pinned(bnpc_ctx *c, int view, const int64_t *rows,
     return 0;
 }
 
-static int ensure_host(void **p, size_t *cap, size_t bytes)
-{
-    if (bytes <= *cap) return 0;
-    if (*p) HIPCHK(hipHostFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    HIPCHK(hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
-    return 0;
-}
-
-// bnpc_ll_rows_pinned without the final wait: everything is enqueued on the
-// context's stream and an event marks the completion of the copy into the
-// slot's own pinned buffer.
+// bnpc_ll_rows_pinned without the final wait.  Tables and sums are enqueued
+// on the context's stream and write the device buffer of this issue's parity;
+// the copy into the slot's own pinned buffer follows on the copy stream, so
+// that it runs under the sums of the next tile; an event marks its completion.
 extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
                                   int64_t K, double FP, double FN, int64_t ldo,
                                   int slot)
 {
     ARGCHK(c && rows, "NULL argument");
-    ARGCHK(slot == 0 || slot == 1, "slot must be 0 or 1");
+    ARGCHK(slot >= 0 && slot < BNPC_TILE_SLOTS, "slot out of range");
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
     ARGCHK(K > 0, "K must be positive");
     ARGCHK(FP > 0.0 && FP < 1.0 && FN > 0.0 && FN < 1.0,
@@ -2183,11 +2318,23 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
     ARGCHK(bytes > 0, "empty view");
+    const int par = (int)(c->tile_seq & 1);
     if (!c->tile_done[slot])
         HIPCHK(hipEventCreateWithFlags(&c->tile_done[slot],
                                        hipEventDisableTiming));
+    if (!c->tile_summed[par]) {
+        HIPCHK(hipEventCreateWithFlags(&c->tile_summed[par],
+                                       hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->tile_out_free[par],
+                                       hipEventDisableTiming));
+        // nothing has read this buffer yet
+        HIPCHK(hipEventRecord(c->tile_out_free[par], c->stream));
+    }
     if (!c->side_stream)
         HIPCHK(hipStreamCreateWithFlags(&c->side_stream,
+                                        hipStreamNonBlocking));
+    if (!c->copy_stream)
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream,
                                         hipStreamNonBlocking));
     if (ensure_host(&c->tile_pin[slot], &c->tile_cap[slot], bytes)) return 1;
     if (ensure_host(&c->tile_rows[slot], &c->tile_rows_cap[slot],
@@ -2195,25 +2342,37 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
         return 1;
     memcpy(c->tile_rows[slot], rows, K * sizeof(long long));
     if (ensure(c->row_idx, K * sizeof(long long))) return 1;
+    // the copy of the tile that used this device buffer two issues ago must
+    // have left it (growing the buffer synchronises the device anyway)
+    HIPCHK(hipStreamWaitEvent(c->stream, c->tile_out_free[par], 0));
+    if (bytes > c->tile_out[par].cap)
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+    if (ensure(c->tile_out[par], bytes)) return 1;
     HIPCHK(hipMemcpyAsync(c->row_idx.p, c->tile_rows[slot],
                           K * sizeof(long long), hipMemcpyHostToDevice,
                           c->stream));
     c->use_rows = (const long long *)c->row_idx.p;
+    c->dst_override = (double *)c->tile_out[par].p;
     int rc = ll_common(c, view, K, ldo, true, FP, FN, nullptr);
+    c->dst_override = nullptr;
     c->use_rows = nullptr;
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->tile_pin[slot], c->out.p, bytes,
-                          hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(c->tile_done[slot], c->stream));
+    HIPCHK(hipEventRecord(c->tile_summed[par], c->stream));
+    HIPCHK(hipStreamWaitEvent(c->copy_stream, c->tile_summed[par], 0));
+    HIPCHK(hipMemcpyAsync(c->tile_pin[slot], c->tile_out[par].p, bytes,
+                          hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(hipEventRecord(c->tile_done[slot], c->copy_stream));
+    HIPCHK(hipEventRecord(c->tile_out_free[par], c->copy_stream));
     c->tile_bytes[slot] = bytes;
     c->tile_pending[slot] = true;
+    c->tile_seq++;
     return 0;
 }
 
 extern "C" int bnpc_ll_rows_wait(bnpc_ctx *c, int slot, double **host)
 {
     ARGCHK(c && host, "NULL argument");
-    ARGCHK(slot == 0 || slot == 1, "slot must be 0 or 1");
+    ARGCHK(slot >= 0 && slot < BNPC_TILE_SLOTS, "slot out of range");
     *host = nullptr;
     ARGCHK(c->tile_pending[slot], "no tile was issued on this slot");
     HIPCHK(hipSetDevice(c->device));

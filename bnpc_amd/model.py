@@ -622,49 +622,73 @@ class CRP:
             opened, tiles = len(born), 1
         else:
             # Tiled sweep.  The parameter rows stay resident on the device
-            # (row = cluster id) and tiles select clusters by index.  Tile
-            # t+1 is ISSUED before the host walks tile t, for the clusters
-            # alive at that moment - a superset of what it will need, minus
-            # the few clusters (re)born while tile t is walked, whose columns
-            # are evaluated when the tile is picked up.
+            # (row = cluster id) and tiles select clusters by index.  Tiles
+            # t+1 and t+2 are in flight while the host walks tile t - the
+            # device sums t+2 while the copy engine moves t+1 - each issued
+            # for the clusters alive at that moment: a superset of what it
+            # will need, minus the clusters (re)born before it is picked up,
+            # whose columns are evaluated then.
             ctx.theta_put(0, self.parameters[:int(ids.max()) + 1])
 
             tile_bytes = min(budget,
                 int(os.environ.get('BNPC_TILE_BYTES', 256 << 20)))
+            ahead_max = max(1, min(_lib.TILE_SLOTS - 1,
+                int(os.environ.get('BNPC_TILES_AHEAD', 2))))
+            born_log = []       # ids born during this sweep, in order
 
-            def issue(start, slot):
+            def issue(start, number):
                 rows = max(64, tile_bytes // (8 * (ids.size + _TILE_SPARE)))
                 # whole workgroups of the likelihood kernel: 8 blocks of 64
                 # cells (measured at 31608 x 5000: 264 rows 6.0e12
                 # element-evals/s, 512 rows 10.6e12, 1024 rows 10.9e12)
                 if rows >= 512:
                     rows -= rows % 512
+                slot = number % _lib.TILE_SLOTS
                 tile = dict(pos=start, end=min(N, start + rows), slot=slot,
-                    view=VIEW_SWEEP + slot, cols=ids.copy(),
-                    ld=ids.size + _TILE_SPARE)
-                ctx.view_set(tile['view'], perm[start:tile['end']])
+                    number=number, view=VIEW_SWEEP + slot, cols=ids.copy(),
+                    ld=ids.size + _TILE_SPARE, born_mark=len(born_log))
+                ctx.view_set_slot(tile['view'], perm[start:tile['end']], slot)
                 ctx.ll_rows_issue(tile['view'], tile['cols'], self.FP,
                     self.FN, tile['ld'], slot)
                 return tile
 
-            opened, tiles, born = 0, 0, ()
-            tile = issue(0, 0)
-            in_flight = [tile]
+            opened, tiles = 0, 0
+            in_flight = []
+            upcoming = [0, 0]           # start position, tile number
+
+            spent = {'issue': 0.0, 'wait': 0.0}
+
+            def fill():
+                while len(in_flight) < ahead_max and upcoming[0] < N:
+                    if timing:
+                        t_0 = time.perf_counter()
+                    tile = issue(upcoming[0], upcoming[1])
+                    in_flight.append(tile)
+                    upcoming[0] = tile['end']
+                    upcoming[1] += 1
+                    if timing:
+                        spent['issue'] += time.perf_counter() - t_0
+
             try:
-                while tile is not None:
+                fill()
+                while in_flight:
+                    tile = in_flight.pop(0)
+                    if timing:
+                        t_0 = time.perf_counter()
                     ll = ctx.ll_rows_wait(tile['slot'],
                         tile['end'] - tile['pos'], tile['ld'])
-                    in_flight.remove(tile)
-                    ahead = None
-                    if tile['end'] < N:
-                        ahead = issue(tile['end'], tile['slot'] ^ 1)
-                        in_flight.append(ahead)
+                    if timing:
+                        spent['wait'] += time.perf_counter() - t_0
+                    # the slot of `tile` stays ours until it has been walked:
+                    # ahead_max tiles in flight + this one <= TILE_SLOTS
+                    fill()
                     ids, sizes, born = self._gibbs_window(perm, tile['pos'],
                         tile['end'], tile['view'], ll, tile['cols'], ids,
-                        sizes, born, assignment, post_new, crp_prior)
+                        sizes, born_log[tile['born_mark']:], assignment,
+                        post_new, crp_prior)
+                    born_log.extend(born)
                     opened += len(born)
                     tiles += 1
-                    tile = ahead
             finally:
                 # an exception must not leave an issued tile behind (the
                 # context refuses to re-use its slot)
@@ -675,9 +699,13 @@ class CRP:
                     except RuntimeError:
                         pass
         if timing:
+            extra = ''
+            if tiles > 1:
+                extra = (f"; issuing {spent['issue']:.3f}s, waiting for the "
+                    f"device {spent['wait']:.3f}s")
             print(f'[bnpc] gibbs N={N} K={K_start}->{ids.size}: '
                 f'{time.perf_counter() - t_start:.3f}s in {tiles} tile(s), '
-                f'{opened} clusters opened', flush=True)
+                f'{opened} clusters opened{extra}', flush=True)
 
         self.assignment = assignment
         self.cells_per_cluster = {

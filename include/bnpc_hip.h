@@ -40,7 +40,8 @@ extern "C" {
 
 typedef struct bnpc_ctx bnpc_ctx;
 
-#define BNPC_MAX_VIEWS 5
+#define BNPC_MAX_VIEWS 6
+#define BNPC_TILE_SLOTS 3    /* tiles in flight (bnpc_ll_rows_issue) */
 #define BNPC_MAX_TRIALS 4
 
 /* ---- library / device ---------------------------------------------------- */
@@ -93,6 +94,12 @@ int bnpc_cell_counts(bnpc_ctx *ctx, int32_t *n1, int32_t *n0);
  * fancy-index gathers `self.data[cells]` of libs/CRP.py:360, 557-560, 636-637,
  * 726-728.  view in 1..BNPC_MAX_VIEWS-1 (view 0 = all cells, built at create). */
 int bnpc_view_set(bnpc_ctx *ctx, int view, const int64_t *cells, int64_t n);
+/* The same for a tile of a tiled sweep (the rows `self.data[cells]` of
+ * libs/CRP.py:270 for a stretch of the permutation): the list is staged in the
+ * pinned buffer of tile slot `slot` and the call returns without waiting; the
+ * view is for bnpc_ll_rows_issue on that slot. */
+int bnpc_view_set_slot(bnpc_ctx *ctx, int view, const int64_t *cells,
+                       int64_t n, int slot);
 int bnpc_view_size(const bnpc_ctx *ctx, int view, int64_t *n);
 
 /* ---- log-likelihood of every slot of a view under K parameter vectors ----
@@ -156,10 +163,13 @@ int bnpc_ll_rows_pinned(bnpc_ctx *ctx, int view, const int64_t *rows,
  * work of tile t+1 with the host's sequential loop over tile t
  * (libs/CRP.py:260-288 is sequential per cell, the likelihood rows are not):
  * bnpc_ll_rows_issue enqueues tables + sums + the copy into pinned buffer
- * `slot` (0 or 1) and returns at once; bnpc_ll_rows_wait blocks until that
- * buffer is complete and returns it (slots x ldo doubles, valid until the next
- * issue on the same slot).  Other calls on the context may be made in between;
- * they queue behind the issued work. */
+ * `slot` (0 .. BNPC_TILE_SLOTS-1) and returns at once; bnpc_ll_rows_wait
+ * blocks until that buffer is complete and returns it (slots x ldo doubles,
+ * valid until the next issue on the same slot).  Several tiles may be in
+ * flight: the sums of consecutive issues alternate between two device buffers
+ * and the copies run on their own stream, so the copy of tile t overlaps the
+ * sums of tile t+1.  Other calls on the context may be made in between; they
+ * run beside the issued work on a side stream. */
 int bnpc_ll_rows_issue(bnpc_ctx *ctx, int view, const int64_t *rows, int64_t K,
                        double FP, double FN, int64_t ldo, int slot);
 int bnpc_ll_rows_wait(bnpc_ctx *ctx, int slot, double **host);

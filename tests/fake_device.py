@@ -32,6 +32,10 @@ class FakeContext:
         self.views[view] = np.asarray(cells, dtype=np.int64).copy()
         return self.views[view].size
 
+    def view_set_slot(self, view, cells, slot):
+        assert slot not in getattr(self, 'tiles', {})
+        return self.view_set(view, cells)
+
     def view_size(self, view):
         return self.views[view].size
 
@@ -102,7 +106,7 @@ class FakeContext:
     def ll_rows_issue(self, view, rows, FP, FN, ld, slot):
         self._count('ll_rows_issue')
         tiles = self.__dict__.setdefault('tiles', {})
-        assert slot in (0, 1) and slot not in tiles
+        assert slot in (0, 1, 2) and slot not in tiles
         tiles[slot] = (np.asarray(rows).copy(),
             self.ll_rows_pinned(view, rows, FP, FN, ld))
 

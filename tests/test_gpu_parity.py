@@ -785,8 +785,9 @@ def test_resident_parameter_rows():
 
 
 def test_issued_tiles_overlap_other_calls():
-    """bnpc_ll_rows_issue / bnpc_ll_rows_wait: two tiles in flight on their
-    own pinned buffers give the bits of the synchronous call; calls made in
+    """bnpc_ll_rows_issue / bnpc_ll_rows_wait: three tiles in flight on their
+    own pinned buffers (two device buffers behind them, copies on their own
+    stream) give the bits of the synchronous call; calls made in
     between (a column for a freshly opened cluster, a parameter row rewritten
     - they run on the side lane) neither disturb them nor wait for them."""
     rng = np.random.RandomState(7)
@@ -796,16 +797,23 @@ def test_issued_tiles_overlap_other_calls():
         .astype(np.float32)
     ctx = _lib.Context(data=data)
     ctx.theta_put(0, params)
-    rows_a = rng.permutation(300)[:250]
-    rows_b = rng.permutation(300)[:120]
+    # (row 299 is rewritten below: no tile reads it)
+    rows_a = rng.permutation(299)[:250]
+    rows_b = rng.permutation(299)[:120]
     cells_a, cells_b = np.arange(0, 500), np.arange(400, 900)
     ctx.view_set(3, cells_a)
     ctx.view_set(4, cells_b)
     want_a = ctx.ll_rows_pinned(3, rows_a, 0.01, 0.2, rows_a.size).copy()
     want_b = ctx.ll_rows_pinned(4, rows_b, 0.02, 0.1, rows_b.size + 5).copy()
 
+    rows_c = rng.permutation(299)[:77]
+    cells_c = rng.permutation(900)[:333]
+    ctx.view_set(5, cells_c)
+    want_c = ctx.ll_rows_pinned(5, rows_c, 0.01, 0.2, rows_c.size).copy()
+
     ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 0)
     ctx.ll_rows_issue(4, rows_b, 0.02, 0.1, rows_b.size + 5, 1)
+    ctx.ll_rows_issue(5, rows_c, 0.01, 0.2, rows_c.size, 2)
     with pytest.raises(RuntimeError, match='unconsumed tile'):
         ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 0)
     # side-lane work while both tiles are in flight
@@ -814,6 +822,13 @@ def test_issued_tiles_overlap_other_calls():
     col = ctx.ll_theta(3, fresh, 0.01, 0.2)
     ctx.theta_put(299, fresh[0])
     got_b = ctx.ll_rows_wait(1, cells_b.size, rows_b.size + 5)
+    got_a = ctx.ll_rows_wait(0, cells_a.size, rows_a.size).copy()
+    # a fourth issue re-uses the device buffer of the second while the third
+    # may still be copying
+    ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 0)
+    got_c = ctx.ll_rows_wait(2, cells_c.size, rows_c.size)
+    assert np.array_equal(got_c, want_c)
+    assert np.array_equal(got_a, want_a)
     got_a = ctx.ll_rows_wait(0, cells_a.size, rows_a.size)
     assert np.array_equal(got_a, want_a)
     assert np.array_equal(got_b[:, :rows_b.size], want_b[:, :rows_b.size])
@@ -822,7 +837,7 @@ def test_issued_tiles_overlap_other_calls():
     with pytest.raises(RuntimeError, match='no tile was issued'):
         ctx.ll_rows_wait(0, cells_a.size, rows_a.size)
     with pytest.raises(RuntimeError, match='slot'):
-        ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, 2)
+        ctx.ll_rows_issue(3, rows_a, 0.01, 0.2, rows_a.size, _lib.TILE_SLOTS)
     ctx.close()
 
 
