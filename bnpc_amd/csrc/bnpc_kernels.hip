@@ -279,7 +279,11 @@ static int pinned_alloc(void **out, size_t *cap, size_t bytes)
             const size_t tail = (size_t)(raw + len + PIN_HUGE_ALIGN - (p + len));
             if (tail) munmap(p + len, tail);
             (void)madvise(p, len, MADV_HUGEPAGE);
-            memset(p, 0, len);              // the pages exist before pinning
+            // fault the huge pages in before pinning: one touch per 2 MiB
+            // (the kernel zeroes them; anything left on small pages is
+            // faulted in by the registration itself)
+            for (size_t off = 0; off < len; off += PIN_HUGE_ALIGN)
+                ((volatile char *)p)[off] = 0;
             if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
                 huge_pins().push_back(p);
                 *out = p;
