@@ -41,6 +41,15 @@ python3 tools/profile_steps.py c3 200 > $out/host_step_breakdown_after.log 2>&1
 python3 tools/gibbs_bench.py > $out/gibbs_bench.log 2>&1
 python3 tools/mh_bench.py > $out/mh_bench.log 2>&1
 python3 tools/msplit_tune_big.py > $out/msplit_big.log 2>&1
+python3 tools/prefetch_ab.py > $out/prefetch_ab.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --stats -d $out/prof_first_sweep -o fs -f csv -- \
+    python3 tools/first_sweep_profile.py c5 > $out/first_sweep_c5_rocprof.log 2>&1
+python3 tools/first_sweep_profile.py c5 > $out/first_sweep_c5.log 2>&1
+python3 tools/first_sweep_profile.py c4 > $out/first_sweep_c4.log 2>&1
+for p in pin_probe sync_probe; do
+    [ -x tools/ubench/$p ] || hipcc --offload-arch=gfx950 -O2 -pthread -o tools/ubench/$p tools/ubench/$p.hip
+    tools/ubench/$p > $out/$p.log 2>&1
+done
 python3 tools/multichain_bench.py c3 2000 1 2 4 8 > $out/multichain_c3.log 2>&1
 python3 tools/multichain_bench.py c2 4000 1 2 4 8 > $out/multichain_c2.log 2>&1
 python3 bench.py --config c2 --steps 200 > $out/bench_config2.json 2> /dev/null
