@@ -826,13 +826,6 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
 #pragma unroll
         for (int j = 0; j < KW; j++) acc[c][j] = 0.0;
 
-    ulonglong2 ma[CB], mb[CB];
-    double ta[16], tb[16];
-#pragma unroll
-    for (int c = 0; c < CB; c++) ma[c] = masks[mo[c]];
-#pragma unroll
-    for (int j = 0; j < 16; j++) ta[j] = tp[j];
-
     // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait
     // for the current stage FIRST, then issue the next stage's loads, then
     // the masked adds run under those loads.
@@ -841,10 +834,13 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     // longer sit in its XCD's L2 - 80 KB of masks per slot block (782 blocks
     // at config 5) or 640 KB of table per cluster group (thousands of groups
     // in a first-sweep tile) - and a scalar load that goes to HBM costs
-    // several stages of adds.  Every 64 mutations the wave touches the masks
-    // and the table of the NEXT 64 with vector loads into a register nobody
-    // reads (never waited for until the wave ends): by the time the scalar
-    // loads get there the lines are in L2.  10 vector loads per 2048 adds.
+    // several stages of adds.  Before its first stage and then every 64
+    // mutations the wave touches the masks and the table of the NEXT 64 with
+    // vector loads into a register nobody reads (never waited for until the
+    // wave ends): by the time the scalar loads get there the lines are in L2.
+    // 10 vector loads per 2048 adds.  A wave of a split launch (a chunk of a
+    // few dozen mutations, its table written a moment ago by another XCD)
+    // gets its whole chunk under way with the first block.
     // (No "memory" clobber on these: it would cost the kernel its scalar
     // loads - the compiler only keeps uniform loads scalar while nothing in
     // the kernel may write memory.)
@@ -854,27 +850,39 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     // depend on m (a lane-dependent induction variable would make the
     // compiler express the SCALAR loads through it, i.e. as vector loads)
     const unsigned pf_lo = (unsigned)lane * 16u, pf_hi = pf_lo + 4096u;
-    for (int m = 0; m < m_len; m += 2) {        // chunks are multiples of 8
-        if (PF && (m & 63) == 0 && m + 64 < m_len) {
-            const int mp = m + 64;
+    // mutations [MP, MP + 64) of this wave's chunk: one load per slot block
+    // for the masks (lanes past the padded row stay out), 8 stages of table
+    // (16 doubles each) per KiB
+#define PF_TAB(MP, I, OFF, IMM)                                               \
+    if ((MP) + 8 * (I) < m_len)                                               \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM            \
+                     : "+v"(pf_sink) : "v"(OFF), "s"(t64_));
+#define PF_BLOCK(MP)                                                          \
+    {                                                                         \
+        if (m_begin + (MP) + lane < Mpad) {                                   \
+            _Pragma("unroll") for (int c = 0; c < CB; c++) {                  \
+                const ulonglong2 *a_ = masks_pf + mo[c] + (MP);               \
+                asm volatile("global_load_dwordx4 %0, %1, %2"                 \
+                             : "+v"(pf_sink) : "v"(pf_lo), "s"(a_));          \
+            }                                                                 \
+        }                                                                     \
+        const double *t64_ = T_pf + t_off + (size_t)(MP) * 16;                \
+        PF_TAB(MP, 0, pf_lo, 0) PF_TAB(MP, 1, pf_lo, 1024)                    \
+        PF_TAB(MP, 2, pf_lo, 2048) PF_TAB(MP, 3, pf_lo, 3072)                 \
+        PF_TAB(MP, 4, pf_hi, 0) PF_TAB(MP, 5, pf_hi, 1024)                    \
+        PF_TAB(MP, 6, pf_hi, 2048) PF_TAB(MP, 7, pf_hi, 3072)                 \
+    }
+    if (PF && m_len > 0) PF_BLOCK(0)
+
+    ulonglong2 ma[CB], mb[CB];
+    double ta[16], tb[16];
 #pragma unroll
-            for (int c = 0; c < CB; c++) {
-                const ulonglong2 *a = masks_pf + mo[c] + mp;
-                asm volatile("global_load_dwordx4 %0, %1, %2"
-                             : "+v"(pf_sink) : "v"(pf_lo), "s"(a));
-            }
-            // 8 stages of table (16 doubles each) per KiB; T keeps 8 stages
-            // of slack behind the last group
-            const double *t64 = T_pf + t_off + (size_t)mp * 16;
-#define PF_TAB(I, OFF, IMM)                                                   \
-            if (m_begin + mp + 8 * (I) < Mt)                                  \
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM    \
-                             : "+v"(pf_sink) : "v"(OFF), "s"(t64));
-            PF_TAB(0, pf_lo, 0) PF_TAB(1, pf_lo, 1024) PF_TAB(2, pf_lo, 2048)
-            PF_TAB(3, pf_lo, 3072) PF_TAB(4, pf_hi, 0) PF_TAB(5, pf_hi, 1024)
-            PF_TAB(6, pf_hi, 2048) PF_TAB(7, pf_hi, 3072)
-#undef PF_TAB
-        }
+    for (int c = 0; c < CB; c++) ma[c] = masks[mo[c]];
+#pragma unroll
+    for (int j = 0; j < 16; j++) ta[j] = tp[j];
+
+    for (int m = 0; m < m_len; m += 2) {        // chunks are multiples of 8
+        if (PF && (m & 63) == 0 && m + 64 < m_len) PF_BLOCK(m + 64)
         __builtin_amdgcn_s_waitcnt(0xC07F);     // stage A landed
 #pragma unroll
         for (int c = 0; c < CB; c++) mb[c] = masks[mo[c] + m + 1];
@@ -891,6 +899,8 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
         for (int c = 0; c < CB; c++) ll_step8(acc[c], mb[c], tb);
         tp += 32;
     }
+#undef PF_BLOCK
+#undef PF_TAB
 
     if (PF)     // the sink stays allocated to the end; nothing in flight
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
@@ -1813,8 +1823,8 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     // one XCD's 4 MiB L2 (BNPC_LL_PREFETCH: 0 never, 1 always, default auto)
     const size_t stream_bytes = (size_t)v.nblk * c->Mpad * 16
         + (size_t)G * c->Mt * 2 * KW * sizeof(double) / 8;
-    const int pf = c->tun.ll_prefetch < 0 ? (stream_bytes > (3u << 20))
-                                           : c->tun.ll_prefetch;
+    const int pf = c->tun.ll_prefetch < 0
+        ? (stream_bytes > (3u << 20) || MS > 1) : c->tun.ll_prefetch;
     double *dst = d_out;
     if (MS > 1) {
         if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double))) return 1;
