@@ -2351,9 +2351,17 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
         // nothing has read this buffer yet
         HIPCHK(hipEventRecord(c->tile_out_free[par], c->stream));
     }
-    if (!c->side_stream)
-        HIPCHK(hipStreamCreateWithFlags(&c->side_stream,
-                                        hipStreamNonBlocking));
+    if (!c->side_stream) {
+        // calls made while tiles are in flight (a column for a cluster just
+        // opened, the columns of clusters born since a tile was issued) run
+        // beside 11 ms kernels that fill the chip: on a stream of the highest
+        // priority their few workgroups get the next free slots instead of
+        // waiting for a whole tile
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->side_stream,
+                                           hipStreamNonBlocking, greatest));
+    }
     if (!c->copy_stream)
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream,
                                         hipStreamNonBlocking));

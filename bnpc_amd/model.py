@@ -91,7 +91,10 @@ def _rowwise(fn, x):
 
 
 # spare columns of an issued tile: clusters (re)born before / while it is walked
-_TILE_SPARE = 48
+# (running out means copying the tile - 256 MiB - into a wider matrix; with two
+# tiles in flight a tile also receives the births of the two walked before it:
+# 50 at config 5's start)
+_TILE_SPARE = 160
 
 VIEW_ALL = 0      # identity view: all cells
 VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
