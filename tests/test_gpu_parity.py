@@ -424,8 +424,12 @@ def test_gibbs_sweeps_match_oracle(kind):
     H.test_gibbs_sweeps_match_oracle(kind)
 
 
-def test_tiled_sweep_on_device(monkeypatch):
+@pytest.mark.parametrize('ahead', ['2', '1'])
+def test_tiled_sweep_on_device(ahead, monkeypatch):
+    """Tiny tiles (dozens per sweep) against the oracle, with two tiles in
+    flight while the host walks one (the default) and with one."""
     monkeypatch.setenv('BNPC_SWEEP_BYTES', '30000')
+    monkeypatch.setenv('BNPC_TILES_AHEAD', ahead)
     H.test_gibbs_sweeps_match_oracle('learn')
     H.test_gibbs_opens_many_clusters_in_one_sweep()
     data = H.synth(0, 1000, 200, 10, 0.10)
