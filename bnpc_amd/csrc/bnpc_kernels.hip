@@ -30,6 +30,7 @@
 #include <string.h>
 #include <math.h>
 #include <sys/mman.h>
+#include <mutex>
 #include <vector>
 #include <algorithm>
 
@@ -263,6 +264,12 @@ static std::vector<void *> &huge_pins()
     return v;
 }
 
+static std::mutex &huge_pins_lock()         // contexts may live on threads
+{
+    static std::mutex m;
+    return m;
+}
+
 static int pinned_alloc(void **out, size_t *cap, size_t bytes)
 {
     *out = nullptr;
@@ -285,6 +292,7 @@ static int pinned_alloc(void **out, size_t *cap, size_t bytes)
             for (size_t off = 0; off < len; off += PIN_HUGE_ALIGN)
                 ((volatile char *)p)[off] = 0;
             if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> hold(huge_pins_lock());
                 huge_pins().push_back(p);
                 *out = p;
                 *cap = len;
@@ -302,10 +310,17 @@ static int pinned_alloc(void **out, size_t *cap, size_t bytes)
 static void pinned_free(void *p, size_t cap)
 {
     if (!p) return;
-    std::vector<void *> &v = huge_pins();
-    auto it = std::find(v.begin(), v.end(), p);
-    if (it != v.end()) {
-        v.erase(it);
+    bool huge = false;
+    {
+        std::lock_guard<std::mutex> hold(huge_pins_lock());
+        std::vector<void *> &v = huge_pins();
+        auto it = std::find(v.begin(), v.end(), p);
+        if (it != v.end()) {
+            v.erase(it);
+            huge = true;
+        }
+    }
+    if (huge) {
         (void)hipHostUnregister(p);
         munmap(p, cap);
     } else {
