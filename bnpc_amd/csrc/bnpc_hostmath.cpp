@@ -184,6 +184,7 @@ inline void uloop(bnpc_uloop f, void *data, const double *in, double *out,
 }
 
 constexpr int BLK = 128;       // elements per task
+constexpr int64_t SMALL_BATCH = 4096;   // elements: draw before the team starts
 
 struct Consts {
     double log_sd[8];          // np.log(sd[i])
@@ -417,7 +418,12 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
 
     for (int64_t g = 0; g < G; g++) a->declined[g] = 0;
-    const int64_t chunks = (M + BLK - 1) / BLK;
+    // tasks of 128 elements; of 64 in a small batch, so that 16 ranks get
+    // three even rounds out of 3 x 1000 elements instead of one and a half
+    // (3 x 1000 on 16 ranks: 72-77 us with tasks of 128, 67-68 us with 64;
+    // 1 x 1000: 45 against 33 us)
+    const int64_t blk = G * M <= SMALL_BATCH ? BLK / 2 : BLK;
+    const int64_t chunks = (M + blk - 1) / blk;
     const int64_t tasks = G * chunks;
     int threads = a->threads;
     if (threads > tasks) threads = (int)tasks;
@@ -436,20 +442,29 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             + (ts.tv_nsec - ts0.tv_nsec);
     };
 
-    auto work = [&](int rank) {
-        if (rank == 0 && rng) {
-            // the draws, cluster by cluster in the reference's order; the
-            // team starts on a cluster as soon as its draws are published
-            for (int64_t g = 0; g < G; g++) {
-                int32_t *si = a->sd_idx + g * M;
-                double *Ug = a->U + g * M, *ug = a->u + g * M;
-                mt_fill_interval32(rng, (uint32_t)(a->n_sd - 1), si, M);
-                mt_fill_double(rng, Ug, M);     // uniform(0, 1) == sample
-                mt_fill_double(rng, ug, M);
-                rows_ready.store(g + 1, std::memory_order_release);
-            }
-            if (trace) t_draws = since();
+    // the draws, cluster by cluster in the reference's order
+    auto draw_rows = [&]() {
+        for (int64_t g = 0; g < G; g++) {
+            int32_t *si = a->sd_idx + g * M;
+            double *Ug = a->U + g * M, *ug = a->u + g * M;
+            mt_fill_interval32(rng, (uint32_t)(a->n_sd - 1), si, M);
+            mt_fill_double(rng, Ug, M);         // uniform(0, 1) == sample
+            mt_fill_double(rng, ug, M);
+            rows_ready.store(g + 1, std::memory_order_release);
         }
+        if (trace) t_draws = since();
+    };
+    // A small batch (the 2-3 rows of a restricted scan: 10 us of draws) is
+    // drawn before the team is started: ranks that wait for rows while rank 0
+    // draws them slow the drawing thread down by more than the overlap gains
+    // (3 x 1000 on 16 ranks: 96 us against 60 us with the draws given).  In a
+    // large batch the team starts on a cluster as soon as its draws are
+    // published.
+    const bool draw_first = rng && G * M <= SMALL_BATCH;
+    if (draw_first) draw_rows();
+
+    auto work = [&](int rank) {
+        if (rank == 0 && rng && !draw_first) draw_rows();
         for (;;) {
             const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
             if (t >= tasks) break;
@@ -468,8 +483,8 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 }
             }
             if (bail.load(std::memory_order_relaxed)) continue;
-            const int64_t m0 = ch * BLK;
-            const int64_t m1 = m0 + BLK < M ? m0 + BLK : M;
+            const int64_t m0 = ch * blk;
+            const int64_t m1 = m0 + blk < M ? m0 + blk : M;
             if (!mh_block(k, a, c, g, m0, m1))
                 bail.store(1, std::memory_order_relaxed);
         }
