@@ -556,10 +556,18 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                     cdf[a] = run;
                 }
             } else {
+                // ... and an entry more than 60 below the runner-up is not
+                // worth its exp() either: the runner-up's term alone is in
+                // the sum, up to 64 such entries together stay below 1e-24
+                // of it, i.e. 1e-8 ulp of any partial sum that contains it -
+                // far inside what libm's exp() and NumPy's differ by (see
+                // the note at the top of this file); before the runner-up
+                // is added they cannot be told from zeros afterwards.
+                const double cut = (second - ptop) - 60.0;
                 for (int64_t a = 0; a <= A; a++) {
                     if (a == top) continue;
                     const double d = post[a] - ptop;
-                    if (d > -746.0) tail += exp(d);
+                    if (d > -746.0 && d >= cut) tail += exp(d);
                 }
                 const double lnorm = log1p(tail);
                 for (int64_t a = 0; a <= A; a++) {
@@ -672,6 +680,14 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
     }
     int64_t ones = 0;
     for (int64_t s = 0; s < S; s++) ones += (rg_assignment[s] == 1);
+    // log(k) of the cluster sizes that can occur: the same libm call, made
+    // once per size instead of twice per cell
+    static thread_local std::vector<double> log_int;
+    if ((int64_t)log_int.size() < n + 1) {
+        const int64_t from = (int64_t)log_int.size();
+        log_int.resize((size_t)n + 1);
+        for (int64_t k = from; k <= n; k++) log_int[k] = log((double)k);
+    }
 
     for (int64_t t = 0; t < S; t++) {
         const int64_t cell = perm[t];
@@ -679,8 +695,8 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
         ones -= (rg_assignment[cell] == 1);
         const int64_t n_j = ones + 1;
         const int64_t n_i = n - n_j - 1;
-        const double p0 = ll[2 * cell] + (log((double)n_i) - lden);
-        const double p1 = ll[2 * cell + 1] + (log((double)n_j) - lden);
+        const double p0 = ll[2 * cell] + (log_int[n_i] - lden);
+        const double p1 = ll[2 * cell + 1] + (log_int[n_j] - lden);
         if (!(p0 == p0) || !(p1 == p1) || (p0 == -INFINITY && p1 == -INFINITY)
             || p0 == INFINITY || p1 == INFINITY) {
             // (the reference's 2-entry fallback, CRP.py:110-114, is for
@@ -689,25 +705,37 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
                            "(cell %lld: %g, %g)", (long long)cell, p0, p1);
             return 4;
         }
-        // _normalize_log for two entries; first maximum wins ties
+        // _normalize_log for two entries; first maximum wins ties.  Where
+        // the smaller entry is more than 40 below the larger one (most cells
+        // once the two clusters have parted), x = exp(small - big) < 2^-54
+        // and the remaining calls are known without being made: log1p(x)
+        // returns x, the larger probability exp(-x) is 1.0, the smaller one
+        // stays below 2^-57, so the cumulative sums are (1, 1) or (tiny, 1)
+        // and every uniform draw but an exact 0.0 picks the larger entry.
+        const int big = p1 > p0 ? 1 : 0;
+        const double d = big ? p0 - p1 : p1 - p0;
+        const bool far = d < -40.0;
+        const double z = far ? exp(d) : log1p(exp(d));
         double l0, l1;
-        if (p1 > p0) {
-            const double z = log1p(exp(p0 - p1));
+        if (big) {
             l0 = p0 - p1 - z;
             l1 = p1 - p1 - z;
         } else {
-            const double z = log1p(exp(p1 - p0));
             l0 = p0 - p0 - z;
             l1 = p1 - p0 - z;
         }
         int64_t pick;
         if (mode == 0) {
             // np.random.choice([0, 1], p=np.exp(log_probs))
-            const double e0 = exp(l0), e1 = exp(l1);
-            const double c0 = e0, c1 = e0 + e1;
             const double u = mt_double(rng);
-            pick = (c0 / c1 > u) ? 0 : 1;
-            if (!(c1 / c1 > u)) pick = 1;
+            if (far && u != 0.0) {
+                pick = big;
+            } else {
+                const double e0 = exp(l0), e1 = exp(l1);
+                const double c0 = e0, c1 = e0 + e1;
+                pick = (c0 / c1 > u) ? 0 : 1;
+                if (!(c1 / c1 > u)) pick = 1;
+            }
         } else {
             pick = target[cell] ? 1 : 0;
         }
