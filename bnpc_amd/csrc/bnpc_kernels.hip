@@ -2373,9 +2373,14 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
         // priority their few workgroups get the next free slots instead of
         // waiting for a whole tile
         int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&c->side_stream,
-                                           hipStreamNonBlocking, greatest));
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess
+            || hipStreamCreateWithPriority(&c->side_stream,
+                   hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();    // no priorities here: a plain stream
+            c->side_stream = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&c->side_stream,
+                                            hipStreamNonBlocking));
+        }
     }
     if (!c->copy_stream)
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream,
