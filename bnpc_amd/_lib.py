@@ -450,13 +450,17 @@ def _mh_buffers(G, M):
 
 
 def threads_for(elements):
-    """Team ranks for a batch of `elements` matrix entries: the configured
-    team; a batch of 100k+ entries (configs 4 and 5: 1.6 ms on 16 threads)
-    takes up to twice as many unless BNPC_HOST_THREADS pins the number
-    (measured at 50 x 5000: 16 threads 2.9 ms, 32 threads 1.6 ms; at 10 x 1000
-    more than 16 gain nothing)."""
+    """Team ranks for a parameter batch of `elements` matrix entries: from
+    2048 entries on (BNPC_MH_WIDE_FROM) up to twice the configured team,
+    unless BNPC_HOST_THREADS pins the number or the node is shared with other
+    chains.  Measured on the 2 x 64-core host, us per bnpc_mh_batch call, 16
+    -> 32 ranks: 3 x 1000 (a restricted scan) 67-76 -> 52-58, 10 x 1000
+    120-133 -> 75-107, 50 x 5000 2.5 ms -> 1.4 ms; config-3 bench, six
+    interleaved pairs: median 826 -> 869 steps/s.  (The sweeps' team scan does
+    not gain from more than 16.)"""
     n = host_threads()
-    if elements >= 100000 and os.environ.get('BNPC_HOST_THREADS') is None:
+    wide_from = int(os.environ.get('BNPC_MH_WIDE_FROM', '2048'))
+    if elements >= wide_from and os.environ.get('BNPC_HOST_THREADS') is None:
         n = max(n, min(_default_team(32), _host_cores() // 2))
     return n
 
@@ -561,7 +565,7 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
     a.known_theta = a.known_prior = a.prior_out = None
     a.new_theta = new.ctypes.data
     a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
-    a.threads = host_threads() if threads is None else threads
+    a.threads = threads_for(G * M) if threads is None else threads
     status = C.c_int(0)
     scan_prob = C.c_double(0.0)
     with NumpyStream() as rng:
