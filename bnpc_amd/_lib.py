@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libbnpc_hip.so')
+# BNPC_LIB: another build of the same library (the sanitizer builds of
+# bnpc_amd/build.py); never a different implementation
+LIB_PATH = os.environ.get('BNPC_LIB') or os.path.join(_PKG, 'libbnpc_hip.so')
 
 MAX_VIEWS = 6
 TILE_SLOTS = 3      # include/bnpc_hip.h: BNPC_TILE_SLOTS
@@ -76,6 +78,9 @@ SIGNATURES = {
     'bnpc_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int,
         C.POINTER(C.c_int)]),
     'bnpc_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    'bnpc_team_stress': (C.c_int, [_i64, C.c_int, C.c_int, C.c_uint64,
+        C.POINTER(_i64), C.POINTER(_i64)]),
+    'bnpc_team_size': (C.c_int, [C.c_int]),
     'bnpc_create': (C.c_int, [C.c_int, _i64, _i64, _pd, C.POINTER(_ctx)]),
     'bnpc_create_codes': (C.c_int, [C.c_int, _i64, _i64,
         C.c_void_p, C.POINTER(_ctx)]),
@@ -256,19 +261,44 @@ def host_share(n_chains, n_devices, nodes=None):
     return max(1, -(-int(n_chains) // groups))
 
 
+_affinity = {'pid': None, 'original': None, 'bound': 0}
+
+
+def _set_affinity_all_threads(cpus):
+    """The affinity mask of EVERY thread of this process (the host thread
+    team may exist already: a new mask on the calling thread alone would
+    leave its workers where they were)."""
+    try:
+        tids = [int(t) for t in os.listdir('/proc/self/task')]
+    except (OSError, ValueError):
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except (OSError, ProcessLookupError):
+            pass            # a thread that has just ended
+    os.sched_setaffinity(0, cpus)
+
+
 def bind_near_device(device, pci_sysfs='/sys/bus/pci/devices',
             node_sysfs='/sys/devices/system/node'):
-    """Keep this process (and the host threads it starts later) on the CPUs
-    of the NUMA node the device hangs off: a chain's sweep walks a matrix the
-    GPU has just written into pinned host memory, which the runtime places on
-    that node; from the other socket every row is a remote access (measured
-    on the 2-socket MI355X host: 200 us against 220-300 us per sweep).
-    Best effort - returns the node, or None if nothing was changed (a
-    single-node host, no sysfs entry, BNPC_NUMA_BIND=0, or an affinity mask
-    that does not reach the node)."""
+    """Keep this process (all its threads, and the host threads it starts
+    later) on the CPUs of the NUMA node the device hangs off: a chain's sweep
+    walks a matrix the GPU has just written into pinned host memory, which
+    the runtime places on that node; from the other socket every row is a
+    remote access (measured on the 2-socket MI355X host: 200 us against
+    220-300 us per sweep).  The mask the process had BEFORE its first binding
+    is remembered: a later context on a GPU of another node re-binds against
+    that, and release_binding() (Context.close) restores it when the last
+    bound context goes.  Best effort - returns the node, or None if nothing
+    was changed (a single-node host, no sysfs entry, BNPC_NUMA_BIND=0, or an
+    affinity mask that does not reach the node)."""
     if os.environ.get('BNPC_NUMA_BIND', '1') == '0':
         return None
     try:
+        if _affinity['pid'] != os.getpid():     # first use / a forked child
+            _affinity.update(pid=os.getpid(),
+                original=os.sched_getaffinity(0), bound=0)
         buf = C.create_string_buffer(32)
         check(load().bnpc_device_pci_bus_id(int(device), buf, 32),
             'device_pci_bus_id')
@@ -277,13 +307,28 @@ def bind_near_device(device, pci_sysfs='/sys/bus/pci/devices',
             node = int(f.read().strip())
         if node < 0:
             return None
-        near = _cpus_of_node(node, node_sysfs) & os.sched_getaffinity(0)
-        if not near or near == os.sched_getaffinity(0):
+        original = _affinity['original']
+        near = _cpus_of_node(node, node_sysfs) & original
+        if not near or near == original:
             return None
-        os.sched_setaffinity(0, near)
+        _set_affinity_all_threads(near)
+        _affinity['bound'] += 1
         return node
     except (OSError, ValueError, RuntimeError, AttributeError):
         return None
+
+
+def release_binding():
+    """Undo bind_near_device when the last context that bound the process is
+    closed: the process gets the affinity mask it started with back."""
+    if _affinity['pid'] != os.getpid() or _affinity['bound'] <= 0:
+        return
+    _affinity['bound'] -= 1
+    if _affinity['bound'] == 0:
+        try:
+            _set_affinity_all_threads(_affinity['original'])
+        except (OSError, AttributeError):
+            pass
 
 
 # ---------------------------------------------------------------------------
@@ -660,6 +705,9 @@ class Context:
         if getattr(self, '_h', None):
             self._lib.bnpc_destroy(self._h)
             self._h = None
+            if getattr(self, 'numa_node', None) is not None:
+                self.numa_node = None
+                release_binding()
 
     def __del__(self):
         try:

@@ -99,11 +99,30 @@ class BitPlanes:
 
     def __getitem__(self, cells):
         """Rows as float64 with NaN - `self.data[cells]` of the reference
-        (libs/CRP.py:360, 557-560).  Row indices only."""
+        (libs/CRP.py:360, 557-560).  Row indices only, with ndarray
+        semantics: integers (negative ones count from the end), integer
+        arrays / lists, slices, boolean masks of length N."""
         if isinstance(cells, tuple):
             raise IndexError('BitPlanes takes row indices only')
+        N = self.shape[0]
+        if isinstance(cells, slice):
+            return self.to_float64(np.arange(N)[cells])
         scalar = np.ndim(cells) == 0
-        rows = self.to_float64(np.atleast_1d(cells))
+        idx = np.atleast_1d(np.asarray(cells))
+        if idx.dtype == np.bool_:
+            if idx.ndim != 1 or idx.size != N:
+                raise IndexError(f'boolean index of length {idx.size} does '
+                    f'not match the {N} rows')
+            idx = np.flatnonzero(idx)
+        elif idx.size == 0:
+            idx = idx.astype(np.int64)
+        elif idx.dtype.kind not in 'iu' or idx.ndim != 1:
+            raise IndexError('BitPlanes rows are indexed by integers, '
+                'integer arrays, slices or boolean masks')
+        idx = idx.astype(np.int64)
+        if idx.size and (idx.min() < -N or idx.max() >= N):
+            raise IndexError(f'row index out of range for {N} rows')
+        rows = self.to_float64(np.where(idx < 0, idx + N, idx))
         return rows[0] if scalar else rows
 
     def __array__(self, dtype=None, copy=None):

@@ -16,6 +16,14 @@ SOURCES = [os.path.join(PKG, 'csrc', 'bnpc_kernels.hip'),
 HEADERS = [os.path.join(ROOT, 'include', 'bnpc_hip.h'),
     os.path.join(PKG, 'csrc', 'bnpc_internal.h')]
 TARGET = os.path.join(PKG, 'libbnpc_hip.so')
+# BNPC_SANITIZE=thread|address,undefined builds the HOST side instrumented
+# into libbnpc_hip.<sanitizer>.so next to the product library (CPU runs only:
+# the GPU pool has no sanitizer support); load it with BNPC_LIB=<path> and the
+# matching runtime in LD_PRELOAD (tools/run_sanitized.sh).
+SANITIZE = os.environ.get('BNPC_SANITIZE', '')
+if SANITIZE:
+    TARGET = os.path.join(PKG,
+        f'libbnpc_hip.{SANITIZE.replace(",", "_")}.so')
 
 
 def find_hipcc():
@@ -44,6 +52,9 @@ def build(force=False, verbose=False):
         '-I' + os.path.join(ROOT, 'include'),
         '-I' + os.path.join(PKG, 'csrc'),
         '-o', TARGET] + SOURCES
+    if SANITIZE:
+        cmd[2:3] = ['-O1', '-g', '-fno-omit-frame-pointer',
+            f'-fsanitize={SANITIZE}', '-shared-libsan']
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
@@ -33,6 +34,8 @@
 #include <atomic>
 #include <functional>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -48,28 +51,56 @@ namespace {
 // wanted); after a job they spin for a short while first, so that the batches
 // of one sampler step (a few hundred microseconds apart) do not pay a kernel
 // wake-up each.  No mutex on the wake-up path: all workers start in parallel.
+//
+// Threading contract (include/bnpc_hip.h): one job at a time.  run() holds
+// the team's job lock from posting to completion, so entry points called from
+// several host threads at once take turns on the team instead of corrupting
+// the job word.  A job must not start another team job (it would wait for
+// itself) - none does.
 class Team {
 public:
-    explicit Team(int workers) : pid_(getpid())
+    Team() : pid_(getpid())
     {
         const char *e = getenv("BNPC_HOST_SPIN_US");
         spin_ns_ = (e ? atol(e) : 50) * 1000L;
-        for (int i = 0; i < workers; i++)
-            threads_.emplace_back([this, i] { loop(i + 1); });
     }
-    int size() const { return (int)threads_.size() + 1; }
+    int size() const { return ranks_.load(std::memory_order_acquire); }
     pid_t pid() const { return pid_; }
 
-    // fn(rank) on `n` ranks (the caller is rank 0); returns when all are done
-    void run(int n, const std::function<void(int)> &fn)
+    // Workers up to `ranks` ranks in all (the caller is rank 0).  The team
+    // grows IN PLACE: a late starter begins with seen = 0 and takes the word
+    // it finds for a job, but its rank is beyond every job posted before it
+    // existed, so it runs nothing old.  A thread the system refuses (EAGAIN
+    // under a pids / ulimit cap) ends the growth: the team keeps the ranks it
+    // has.  Returns the size reached.
+    int grow(int ranks)
     {
+        std::lock_guard<std::mutex> hold(job_mu_);
+        if (ranks > 255) ranks = 255;
+        while (size() < ranks) {
+            const int rank = size();
+            try {
+                threads_.emplace_back([this, rank] { loop(rank); });
+            } catch (const std::system_error &) {
+                break;
+            }
+            ranks_.store(rank + 1, std::memory_order_release);
+        }
+        return size();
+    }
+
+    // fn(rank) on `n` ranks (the caller is rank 0); returns when all are
+    // done, with the number of ranks that ran
+    int run(int n, const std::function<void(int)> &fn)
+    {
+        std::lock_guard<std::mutex> hold(job_mu_);
         if (n > size()) n = size();
         if (n > 255) n = 255;
         if (n <= 1) {
             fn(0);
-            return;
+            return 1;
         }
-        job_ = &fn;
+        job_.store(&fn, std::memory_order_relaxed);
         pending_.store(n - 1, std::memory_order_relaxed);
         gen_ = (gen_ + 1) & 0xffffff;
         // store the word, THEN look for sleepers - in that order for every
@@ -83,7 +114,8 @@ public:
                     nullptr, nullptr, 0);
         fn(0);
         while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
-        job_ = nullptr;
+        job_.store(nullptr, std::memory_order_relaxed);
+        return n;
     }
 
 private:
@@ -120,7 +152,9 @@ private:
             }
             seen = w;
             if (rank < (int)(w & 0xff)) {
-                (*job_)(rank);
+                // (published before the word: the acquire load above pairs
+                // with the seq_cst store in run())
+                (*job_.load(std::memory_order_relaxed))(rank);
                 pending_.fetch_sub(1, std::memory_order_release);
             }
         }
@@ -128,47 +162,106 @@ private:
 
     pid_t pid_;
     long spin_ns_ = 50000;
+    std::mutex job_mu_;
     std::vector<std::thread> threads_;
+    std::atomic<int> ranks_{1};         // the caller + threads_.size()
     std::atomic<uint32_t> word_{0};
     std::atomic<int> pending_{0}, sleepers_{0};
     uint32_t gen_ = 0;
-    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<const std::function<void(int)> *> job_{nullptr};
 };
 
 // The team of this PROCESS.  A forked child inherits the object but not the
 // threads: it abandons the parent's team (never destroyed - its std::threads
-// are not joinable there) and starts its own on first use.
+// are not joinable there, and its job lock may be held by a thread that does
+// not exist in the child) and starts its own on first use.
 Team *g_team = nullptr;
 std::mutex g_team_mu;
 
+void team_after_fork_child()
+{
+    // the registry lock may have been held by another thread of the parent
+    new (&g_team_mu) std::mutex();
+    g_team = nullptr;
+}
+
 Team *team_for(int threads)
 {
-    std::lock_guard<std::mutex> lk(g_team_mu);
-    if (g_team && g_team->pid() != getpid()) g_team = nullptr;
-    if (!g_team || g_team->size() < threads) {
-        // a larger team replaces a smaller one; the old workers stay parked
-        g_team = new Team(threads - 1);
+    static const int hooked = pthread_atfork(nullptr, nullptr,
+                                             team_after_fork_child);
+    (void)hooked;
+    Team *t;
+    {
+        std::lock_guard<std::mutex> lk(g_team_mu);
+        if (g_team && g_team->pid() != getpid()) g_team = nullptr;
+        if (!g_team) g_team = new Team();
+        t = g_team;
     }
-    return g_team;
+    if (t->size() < threads) t->grow(threads);
+    return t;
 }
 
 }  // namespace
 
-// ranks a team of `threads` would really have (the team is capped)
+// ranks a team of `threads` will really have: the team is capped at 255 and
+// keeps what it has when the system refuses a thread (the team is grown here)
 int bnpc_team_ranks(int threads)
 {
     if (threads > 255) threads = 255;
-    return threads < 1 ? 1 : threads;
+    if (threads <= 1) return 1;
+    const int have = team_for(threads)->size();
+    return have < threads ? have : threads;
 }
 
-void bnpc_team_run(int threads, const std::function<void(int)> &fn)
+int bnpc_team_run(int threads, const std::function<void(int)> &fn)
 {
     threads = bnpc_team_ranks(threads);
     if (threads <= 1) {
         fn(0);
-        return;
+        return 1;
     }
-    team_for(threads)->run(threads, fn);
+    return team_for(threads)->run(threads, fn);
+}
+
+extern "C" int bnpc_team_size(int threads)
+{
+    return bnpc_team_ranks(threads);
+}
+
+extern "C" int bnpc_team_stress(int64_t jobs, int max_tasks, int ranks,
+                                uint64_t seed, int64_t *done,
+                                int64_t *expected)
+{
+    if (!done || !expected || jobs < 0 || max_tasks < 1 || ranks < 1) {
+        bnpc_set_error("bad argument: team_stress");
+        return 2;
+    }
+    std::atomic<int64_t> total(0);
+    int64_t want = 0;
+    uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
+    for (int64_t j = 0; j < jobs; j++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        const int64_t tasks = 1 + (int64_t)(x % (uint64_t)max_tasks);
+        const int r = 1 + (int)((x >> 32) % (uint64_t)ranks);
+        std::atomic<int64_t> next(0);
+        int64_t seen_by[256] = {0};
+        bnpc_team_run(r, [&](int rank) {
+            for (;;) {
+                const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
+                if (t >= tasks) break;
+                seen_by[rank]++;        // plain: one writer per rank
+            }
+        });
+        int64_t got = 0;
+        for (int i = 0; i < 256; i++) got += seen_by[i];
+        total.fetch_add(got, std::memory_order_relaxed);
+        want += tasks;
+    }
+    *done = total.load();
+    *expected = want;
+    return 0;
 }
 
 namespace {

@@ -13,9 +13,11 @@ void bnpc_set_error(const char *fmt, ...);
 #include <functional>
 // fn(rank) for every rank 0..n-1, n = bnpc_team_ranks(threads), on this
 // process's host thread team (the caller is rank 0; the team grows to n if it
-// is smaller); returns when all ranks are done.
+// is smaller - bnpc_team_ranks does that and returns fewer when the system
+// refuses threads); returns n when all ranks are done.  One job at a time:
+// concurrent callers take turns (the team's job lock).
 int bnpc_team_ranks(int threads);
-void bnpc_team_run(int threads, const std::function<void(int)> &fn);
+int bnpc_team_run(int threads, const std::function<void(int)> &fn);
 #endif
 
 // ---------------------------------------------------------------------------

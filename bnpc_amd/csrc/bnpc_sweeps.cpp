@@ -94,6 +94,16 @@ extern "C" int bnpc_log_diff_pi(const double *log_p, const double *log_q,
     return 0;
 }
 
+// BNPC_LOOP_SHORTCUTS=0 makes the two loops below evaluate every exp() /
+// log1p() the plain way (no "60 below the runner-up" cut in the sweep, no
+// "pair 40 apart" short cut in the restricted scan): the old-vs-new
+// comparison of tests/test_native_sweeps.py.  Read per call, not per cell.
+static bool loop_shortcuts()
+{
+    const char *e = getenv("BNPC_LOOP_SHORTCUTS");
+    return !(e && e[0] == '0');
+}
+
 // ---------------------------------------------------------------------------
 // Gibbs sweep
 // ---------------------------------------------------------------------------
@@ -287,6 +297,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     // largest cluster count this call can see (at most ld live columns)
     const double *fs = floor_sums(ld + 1);
     const double *dom_bound = dominated_bounds(ld + 1);
+    const bool shortcuts = loop_shortcuts();
     static const int64_t ahead_by = [] {
         const char *e = getenv("BNPC_SWEEP_PREFETCH");
         const long v = e ? atol(e) : 16;
@@ -563,7 +574,8 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 // far inside what libm's exp() and NumPy's differ by (see
                 // the note at the top of this file); before the runner-up
                 // is added they cannot be told from zeros afterwards.
-                const double cut = (second - ptop) - 60.0;
+                const double cut = shortcuts ? (second - ptop) - 60.0
+                                             : -INFINITY;
                 for (int64_t a = 0; a <= A; a++) {
                     if (a == top) continue;
                     const double d = post[a] - ptop;
@@ -630,6 +642,8 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     if (par_min < 2) par_min = 2;
     int T = (int)st->threads;
     if (T > ParScan::MAXT) T = ParScan::MAXT;
+    // (the ranks the team really has: every rank of the scan has a range)
+    if (T >= 2 && st->n_active >= par_min) T = bnpc_team_ranks(T);
     if (T < 2 || st->n_active < par_min)
         return sweep_window(st, rng, perm, ll, post_new, crp_prior,
                             assignment, col_of_id, col_id, col_size, order,
@@ -680,6 +694,7 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
     }
     int64_t ones = 0;
     for (int64_t s = 0; s < S; s++) ones += (rg_assignment[s] == 1);
+    const bool shortcuts = loop_shortcuts();
     // log(k) of the cluster sizes that can occur: the same libm call, made
     // once per size instead of twice per cell
     static thread_local std::vector<double> log_int;
@@ -714,7 +729,7 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
         // and every uniform draw but an exact 0.0 picks the larger entry.
         const int big = p1 > p0 ? 1 : 0;
         const double d = big ? p0 - p1 : p1 - p0;
-        const bool far = d < -40.0;
+        const bool far = shortcuts && d < -40.0;
         const double z = far ? exp(d) : log1p(exp(d));
         double l0, l1;
         if (big) {

@@ -23,8 +23,13 @@ the workers are spawned instead (the model then travels by pickle, once).
 """
 import multiprocessing as mp
 from multiprocessing import connection, resource_tracker, shared_memory
+import os
 import pickle
 import traceback
+
+# blocks are named bnpc_<pid of the creating worker>_<random>: what a crashed
+# run leaves in /dev/shm can be recognised (and swept) by the prefix
+SHM_PREFIX = 'bnpc_'
 
 
 def pack(obj):
@@ -33,7 +38,18 @@ def pack(obj):
     data = pickle.dumps(obj, protocol=5, buffer_callback=buffers.append)
     raws = [b.raw() for b in buffers]
     sizes = [r.nbytes for r in raws]
-    block = shared_memory.SharedMemory(create=True, size=max(1, sum(sizes)))
+    block = None
+    for _ in range(8):
+        try:
+            block = shared_memory.SharedMemory(create=True,
+                size=max(1, sum(sizes)),
+                name=f'{SHM_PREFIX}{os.getpid()}_{os.urandom(6).hex()}')
+            break
+        except FileExistsError:
+            continue
+    if block is None:
+        block = shared_memory.SharedMemory(create=True,
+            size=max(1, sum(sizes)))
     at = 0
     for raw, size in zip(raws, sizes):
         block.buf[at:at + size] = raw
@@ -66,12 +82,34 @@ def unpack(packed):
         block.unlink()
 
 
-def _worker(fn, job, conn):
+def discard(packed):
+    """Release the shared-memory block of a `pack` nobody will unpack."""
     try:
-        conn.send(('ok', pack(fn(*job))))
+        block = shared_memory.SharedMemory(name=packed[1])
+    except (FileNotFoundError, OSError):
+        return
+    block.close()
+    try:
+        block.unlink()
+    except (FileNotFoundError, OSError):
+        pass
+
+
+def _worker(fn, job, conn):
+    packed = None
+    try:
+        packed = pack(fn(*job))
+        conn.send(('ok', packed))
+        packed = None               # the parent owns the block now
     except BaseException as err:     # noqa: B902 - reported, then re-raised
-        conn.send(('error', f'{type(err).__name__}: {err}\n'
-            + traceback.format_exc()))
+        if packed is not None:      # the name never reached the parent
+            discard(packed)
+            packed = None
+        try:
+            conn.send(('error', f'{type(err).__name__}: {err}\n'
+                + traceback.format_exc()))
+        except (OSError, ValueError):   # the parent is gone
+            pass
         raise
     finally:
         conn.close()
@@ -92,22 +130,41 @@ def run_jobs(fn, jobs, on_done):
         waiting[recv_end] = proc
     failures = []
     procs = list(waiting.values())
-    while waiting:
-        for conn in connection.wait(list(waiting)):
-            proc = waiting.pop(conn)
+    try:
+        while waiting:
+            for conn in connection.wait(list(waiting)):
+                proc = waiting.pop(conn)
+                try:
+                    kind, payload = conn.recv()
+                except (EOFError, OSError):
+                    proc.join()
+                    failures.append(f'worker pid {proc.pid} ended with exit '
+                        f'code {proc.exitcode} without a result')
+                    continue
+                finally:
+                    conn.close()
+                if kind == 'ok':
+                    on_done(unpack(payload))    # (unpack unlinks the block)
+                else:
+                    failures.append(payload)
+    finally:
+        # on_done / unpack raised (or the caller was interrupted): the other
+        # workers may have packed - or be about to pack - results nobody will
+        # read.  Drain their pipes, release those blocks (GBs at config 4/5,
+        # otherwise left in /dev/shm until reboot), leave no process behind.
+        for conn, proc in waiting.items():
             try:
-                kind, payload = conn.recv()
+                if conn.poll(30):
+                    kind, payload = conn.recv()
+                    if kind == 'ok':
+                        discard(payload)
             except (EOFError, OSError):
-                proc.join()
-                failures.append(f'worker pid {proc.pid} ended with exit code '
-                    f'{proc.exitcode} without a result')
-                continue
+                pass
             finally:
                 conn.close()
-            if kind == 'ok':
-                on_done(unpack(payload))
-            else:
-                failures.append(payload)
-    for proc in procs:
-        proc.join()
+        for proc in procs:
+            proc.join(30 if waiting else None)
+            if proc.is_alive():
+                proc.terminate()
+                proc.join()
     return failures

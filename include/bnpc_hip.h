@@ -17,6 +17,13 @@
  *   - all host buffers are caller-allocated, C-contiguous and only borrowed
  *     for the duration of the call; the context owns all device memory.
  *   - one context per process/chain; calls on one context must not overlap.
+ *   - threading: the library keeps ONE host thread team per process (the
+ *     parameter batches, the team scan of a first sweep).  Entry points that
+ *     use it - bnpc_mh_batch, bnpc_log_accept, bnpc_beta_logpdf_f32,
+ *     bnpc_gibbs_sweep, bnpc_rg_scan_step - may be called from several host
+ *     threads at once (each on its own context / buffers): they take turns
+ *     on the team, one job at a time.  The team is rebuilt in a fork()ed
+ *     child on first use; a child must not be forked WHILE a call is running.
  *   - floating point: tables, accumulators and outputs are float64; theta is
  *     float32 and (1 - theta) is evaluated in float32, as in the reference.
  *
@@ -55,6 +62,16 @@ int bnpc_device_info(int device, char *name, int len, int *cus);
  * node from sysfs with it and keeps the chain's host threads on that node
  * (the sweep walks a matrix the GPU has just written to host memory there). */
 int bnpc_device_pci_bus_id(int device, char *bus_id, int len);
+
+/* Diagnostic: `jobs` team jobs of 1..max_tasks counted tasks each on up to
+ * `ranks` ranks (tests/test_native_sweeps.py stress test; the ThreadSanitizer
+ * build runs it).  *done receives the number of tasks executed, which must
+ * equal *expected. */
+int bnpc_team_stress(int64_t jobs, int max_tasks, int ranks, uint64_t seed,
+                     int64_t *done, int64_t *expected);
+/* ranks the host thread team has after growing it to `threads` (fewer when
+ * the system refuses threads; capped at 255) */
+int bnpc_team_size(int threads);
 
 /* ---- context: data of one chain ------------------------------------------
  * Replaces the float64 N x M `self.data` (NaN = missing) of libs/CRP.py:30-31

@@ -259,3 +259,23 @@ def test_model_on_bit_planes_walks_the_same_chain(monkeypatch):
         assert isinstance(clone.data, B.BitPlanes)
         assert np.array_equal(clone.data.planes, planes.planes)
         assert np.array_equal(clone.parameters, m.parameters)
+
+
+def test_bit_planes_index_like_an_ndarray():
+    """BitPlanes stands in for the float64 matrix, so bp[idx] must
+    be np.asarray(bp)[idx] for integers (negative ones too), integer arrays,
+    slices and boolean masks - and raise IndexError otherwise."""
+    from bnpc_amd.bitplanes import BitPlanes
+    rng = np.random.RandomState(2)
+    data = (rng.random_sample((7, 70)) < 0.4).astype(np.float64)
+    data[rng.random_sample(data.shape) < 0.2] = np.nan
+    bp = BitPlanes.from_data(data)
+    mask = np.array([True, False, True, False, False, True, False])
+    for idx in (3, -1, -7, np.int64(2), [0, 6, 3], np.array([-1, 0, -7]),
+            mask, slice(1, 6, 2), slice(None), np.array([], dtype=int),
+            ~mask):
+        np.testing.assert_array_equal(bp[idx], data[idx])
+    assert bp[mask].shape == (3, 70)
+    for bad in (7, -8, [0, 9], np.array([True, False]), 1.5, (1, 2)):
+        with pytest.raises(IndexError):
+            bp[bad]

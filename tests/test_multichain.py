@@ -304,8 +304,37 @@ def test_host_threads_are_kept_on_the_devices_numa_node(monkeypatch, tmp_path):
         # no sysfs entry for the device: nothing changes
         assert _lib.bind_near_device(0, str(tmp_path / 'nope'),
             str(tmp_path / 'node')) is None
+        # a second context on a GPU of the OTHER node re-binds
+        # against the mask the process started with (not against the first
+        # binding, whose intersection with the other node is empty) ...
+        (pci / 'numa_node').write_text('0\n')
+        assert _lib.bind_near_device(0, str(tmp_path / 'pci'),
+            str(tmp_path / 'node')) == 0
+        assert sorted(os.sched_getaffinity(0)) == have[len(have) // 2:]
+        # ... threads that exist already (the host thread team) move along ...
+        import threading
+        seen, go = [], threading.Event()
+
+        def parked():
+            go.wait(10)
+            seen.append(sorted(os.sched_getaffinity(0)))
+        t = threading.Thread(target=parked)
+        t.start()
+        (pci / 'numa_node').write_text('1\n')
+        assert _lib.bind_near_device(0, str(tmp_path / 'pci'),
+            str(tmp_path / 'node')) == 1
+        go.set()
+        t.join()
+        assert seen == [half]
+        # ... and closing the last bound context restores the original mask
+        _lib.release_binding()
+        _lib.release_binding()
+        assert sorted(os.sched_getaffinity(0)) == half
+        _lib.release_binding()
+        assert sorted(os.sched_getaffinity(0)) == have
     finally:
         os.sched_setaffinity(0, have)
+        _lib._affinity.update(pid=None, original=None, bound=0)
 
 
 def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
@@ -340,3 +369,31 @@ def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
     assert _lib.host_threads() == 5
     monkeypatch.delenv('BNPC_HOST_SHARE')
     monkeypatch.delenv('BNPC_DEVICE', raising=False)
+
+
+def test_results_nobody_reads_leave_no_shared_memory(tmp_path):
+    """when the parent fails on an early result (on_done raises),
+    the blocks the other workers packed are released and the workers are
+    joined - nothing of this run stays in /dev/shm."""
+    import glob
+    from bnpc_amd import handoff
+
+    def before():
+        return set(glob.glob(f'/dev/shm/{handoff.SHM_PREFIX}*'))
+    start = before()
+
+    def boom(result):
+        raise ValueError('parent failed on a result')
+    with pytest.raises(ValueError):
+        handoff.run_jobs(_unread_result, [(i,) for i in range(3)], boom)
+    assert before() == start
+    # a worker whose parent end is gone releases its own block
+    recv_end, send_end = __import__('multiprocessing').Pipe(duplex=False)
+    recv_end.close()
+    with pytest.raises(OSError):
+        handoff._worker(_unread_result, (7,), send_end)
+    assert before() == start
+
+
+def _unread_result(i):
+    return {'i': i, 'samples': np.full((64, 1024), i, dtype=np.int64)}
