@@ -129,6 +129,11 @@ SIGNATURES = {
     'bnpc_mt_permutation': (C.c_int, [C.POINTER(MT19937), _i64, _pi64]),
     'bnpc_mt_mh_draws': (C.c_int, [C.POINTER(MT19937), _i64, _i64, _i64,
         _pi32, _pd, _pd]),
+    'bnpc_mt_beta': (C.c_int, [C.POINTER(MT19937), C.c_void_p, _i64, _pd,
+        _pd, _pd]),
+    'bnpc_mt_beta_theta': (C.c_int, [C.POINTER(MT19937), C.c_void_p, _i64,
+        C.c_double, C.c_double, _pi32, _pi32, C.c_double, C.c_double,
+        C.c_double, _pf]),
     'bnpc_log_diff_pi': (C.c_int, [_pd, _pd, _i64, _pd]),
     'bnpc_mh_batch': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
         C.POINTER(MHArgs),
@@ -389,6 +394,119 @@ def rng_live():
         except Exception:
             _live['ptr'] = None
     return _live['ptr']
+
+
+class LegacyGauss(C.Structure):
+    """bnpc_legacy_gauss (include/bnpc_hip.h) = the (has_gauss, gauss) part of
+    NumPy's aug_bitgen_t"""
+    _fields_ = [('has_gauss', C.c_int32), ('pad_', C.c_int32),
+        ('gauss', C.c_double)]
+
+
+_gauss_live = {}
+
+
+def gauss_live():
+    """Pointer to the cached Gaussian (has_gauss, gauss) of NumPy's global
+    legacy RandomState, for native draws that use the polar method (the
+    legacy gamma / beta samplers), or None.  NumPy has no accessor for it:
+    the pair sits in the RandomState object itself (its aug_bitgen_t), so it
+    is LOCATED once per process - set_state() plants two different marker
+    values, the object's memory is searched for the (int, double) pair that
+    follows them, the candidate must be unique, must read back (0, 0.0) after
+    a reset and a value written through the pointer must come back out of
+    get_state().  Anything unexpected: None, and the callers exchange the
+    pair through get_state / set_state instead."""
+    pid = os.getpid()
+    if _gauss_live.get('pid') == pid:
+        return _gauss_live['ptr']
+    _gauss_live.clear()
+    _gauss_live.update(pid=pid, ptr=None)
+    if os.environ.get('BNPC_GAUSS_LIVE', '1') == '0':
+        return None
+    saved = np.random.get_state()
+    try:
+        rs = np.random.mtrand._rand
+        base, size = id(rs), type(rs).__basicsize__
+        if not 64 <= size <= 1 << 16:
+            return None
+        kind, key, pos = saved[:3]
+
+        def hits(marker):
+            np.random.set_state((kind, key, pos, 1, marker))
+            raw = C.string_at(base, size)
+            found = set()
+            for off in range(0, size - 15, 8):
+                if int.from_bytes(raw[off:off + 4], 'little') == 1 and \
+                        np.frombuffer(raw, np.float64, 1, off + 8)[0] == marker:
+                    found.add(off)
+            return found
+        cand = hits(0.7421875123) & hits(-3.1403125456)
+        if len(cand) != 1:
+            return None
+        ptr = C.cast(base + cand.pop(), C.POINTER(LegacyGauss))
+        np.random.set_state((kind, key, pos, 0, 0.0))
+        if ptr.contents.has_gauss != 0 or ptr.contents.gauss != 0.0:
+            return None
+        ptr.contents.has_gauss, ptr.contents.gauss = 1, 1.2509765625
+        back = np.random.get_state()
+        if back[3] != 1 or back[4] != 1.2509765625:
+            return None
+        _gauss_live['ptr'] = ptr
+        _gauss_live['owner'] = rs
+    except Exception:       # noqa: BLE001 - any surprise means "not live"
+        _gauss_live['ptr'] = None
+    finally:
+        np.random.set_state(saved)
+    return _gauss_live['ptr']
+
+
+class NumpyGaussStream:
+    """`with NumpyGaussStream() as (rng, gauss):` - the global legacy stream
+    AND its cached Gaussian for native draws: both in place when they can be
+    located, else copies that are written back on exit."""
+
+    def __enter__(self):
+        self._rng = rng_live()
+        self._gauss = gauss_live() if self._rng is not None else None
+        if self._gauss is not None:
+            return self._rng, C.cast(self._gauss, C.c_void_p)
+        self._copy, extra = rng_export()
+        self._g = LegacyGauss(int(extra[0]), 0, float(extra[1]))
+        return C.pointer(self._copy), C.cast(C.pointer(self._g), C.c_void_p)
+
+    def __exit__(self, *exc):
+        if self._gauss is None:
+            rng_import(self._copy, (int(self._g.has_gauss),
+                float(self._g.gauss)))
+        return False
+
+
+def beta(a, b):
+    """np.random.beta(a, b) for equal-shaped float64 arrays, natively on the
+    global stream (bnpc_mt_beta)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    out = np.empty(a.shape)
+    with NumpyGaussStream() as (rng, g):
+        check(load().bnpc_mt_beta(rng, g, a.size, ptr(a), ptr(b), ptr(out)),
+            'mt_beta')
+    return out
+
+
+def beta_theta(p, q, n1, n0, fkt, tmin, tmax):
+    """float32 profile row clip(Beta(p + n1 * fkt, q + n0 * fkt)) from int32
+    column counts, natively on the global stream (bnpc_mt_beta_theta)."""
+    n1 = np.ascontiguousarray(n1, dtype=np.int32)
+    n0 = np.ascontiguousarray(n0, dtype=np.int32)
+    assert n1.shape == n0.shape and n1.ndim == 1
+    out = np.empty(n1.size, dtype=np.float32)
+    with NumpyGaussStream() as (rng, g):
+        check(load().bnpc_mt_beta_theta(rng, g, n1.size, float(p), float(q),
+            ptr(n1), ptr(n0), float(fkt), float(tmin), float(tmax),
+            ptr(out)), 'mt_beta_theta')
+    return out
 
 
 class NumpyStream:

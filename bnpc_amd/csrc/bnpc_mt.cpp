@@ -117,3 +117,164 @@ void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max, int32_t *out, int64_t n)
         s->pos += j;
     }
 }
+
+// ---------------------------------------------------------------------------
+// NumPy's LEGACY Beta / Gamma samplers on the same stream: the draws behind
+// CRP._init_cl_params_new (/root/reference/libs/CRP.py:183-188: one Beta per
+// mutation with shapes p + #ones, q + #zeros of the cells), _init_cl_params
+// (:155-180) and the restricted-Gibbs launch states (:563-567).  NumPy
+// (unpinned dependency of the reference) implements np.random.beta with
+// numpy/random/src/legacy/legacy-distributions.c; what is restated here is
+// that file's published algorithm:
+//   legacy_beta            Johnk's algorithm when both shapes are <= 1, else
+//                          Ga / (Ga + Gb) from two standard gammas;
+//   legacy_standard_gamma  shape == 1: -log(1 - U); shape < 1: the
+//                          Ahrens-Dieter style rejection with U, an
+//                          exponential and pow(); shape > 1: Marsaglia-Tsang
+//                          with the squeeze 1 - 0.0331 x^4;
+//   legacy_gauss           polar Box-Muller, the second variate cached in
+//                          (has_gauss, gauss) - state that lives in NumPy's
+//                          RandomState next to the bit generator and is
+//                          shared with every other normal / gamma draw of the
+//                          stream, so it is read and written here in place;
+// with libm's pow / log / exp / sqrt, as NumPy calls them.  Pinned by
+// tests/golden/rng_beta.npz (vectors drawn by NumPy itself on the reference's
+// stack) and against the NumPy this process runs (tests/test_native_sweeps.py).
+// ---------------------------------------------------------------------------
+#include <math.h>
+
+namespace {
+
+inline double lg_gauss(bnpc_mt19937 *s, bnpc_legacy_gauss *g)
+{
+    if (g->has_gauss) {
+        const double t = g->gauss;
+        g->has_gauss = 0;
+        g->gauss = 0.0;
+        return t;
+    }
+    double x1, x2, r2;
+    do {
+        x1 = 2.0 * mt_double(s) - 1.0;
+        x2 = 2.0 * mt_double(s) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    g->gauss = f * x1;
+    g->has_gauss = 1;
+    return f * x2;
+}
+
+inline double lg_exponential(bnpc_mt19937 *s)
+{
+    return -log(1.0 - mt_double(s));
+}
+
+double lg_standard_gamma(bnpc_mt19937 *s, bnpc_legacy_gauss *g, double shape)
+{
+    if (shape == 1.0) return lg_exponential(s);
+    if (shape == 0.0) return 0.0;
+    if (shape < 1.0) {
+        for (;;) {
+            const double U = mt_double(s);
+            const double V = lg_exponential(s);
+            if (U <= 1.0 - shape) {
+                const double X = pow(U, 1. / shape);
+                if (X <= V) return X;
+            } else {
+                const double Y = -log((1 - U) / shape);
+                const double X = pow(1.0 - shape + shape * Y, 1. / shape);
+                if (X <= (V + Y)) return X;
+            }
+        }
+    }
+    const double b = shape - 1. / 3.;
+    const double c = 1. / sqrt(9 * b);
+    for (;;) {
+        double X, V;
+        do {
+            X = lg_gauss(s, g);
+            V = 1.0 + c * X;
+        } while (V <= 0.0);
+        V = V * V * V;
+        const double U = mt_double(s);
+        if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return (b * V);
+        if (log(U) < 0.5 * X * X + b * (1. - V + log(V))) return (b * V);
+    }
+}
+
+inline double lg_beta(bnpc_mt19937 *s, bnpc_legacy_gauss *g, double a,
+                      double b)
+{
+    if ((a <= 1.0) && (b <= 1.0)) {
+        for (;;) {                              // Johnk
+            const double U = mt_double(s);
+            const double V = mt_double(s);
+            const double X = pow(U, 1.0 / a);
+            const double Y = pow(V, 1.0 / b);
+            const double XpY = X + Y;
+            // (U + V == 0 has probability 2^-106: NumPy rejects it too)
+            if ((XpY <= 1.0) && (U + V > 0.0)) {
+                if (XpY > 0) return X / XpY;
+                double logX = log(U) / a;
+                double logY = log(V) / b;
+                const double logM = logX > logY ? logX : logY;
+                logX -= logM;
+                logY -= logM;
+                return exp(logX - log(exp(logX) + exp(logY)));
+            }
+        }
+    }
+    const double Ga = lg_standard_gamma(s, g, a);
+    const double Gb = lg_standard_gamma(s, g, b);
+    return Ga / (Ga + Gb);
+}
+
+}  // namespace
+
+extern "C" int bnpc_mt_beta(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t n,
+                            const double *a, const double *b, double *out)
+{
+    if (!rng || !g || n < 0 || (n > 0 && (!a || !b || !out))) {
+        bnpc_set_error("bad argument: mt_beta");
+        return 2;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        if (!(a[i] > 0.0) || !(b[i] > 0.0)) {       // NumPy: ValueError
+            bnpc_set_error("bad argument: Beta shape %lld is not positive",
+                           (long long)i);
+            return 2;
+        }
+    }
+    for (int64_t i = 0; i < n; i++) out[i] = lg_beta(rng, g, a[i], b[i]);
+    return 0;
+}
+
+// One profile row: theta[m] = float32(clip(Beta(p + n1[m] * fkt,
+// q + n0[m] * fkt), tmin, tmax)) - np.clip(np.random.beta(...), TMIN, TMAX)
+// .astype(np.float32) of libs/CRP.py:183-188 from integer column counts.
+extern "C" int bnpc_mt_beta_theta(bnpc_mt19937 *rng, bnpc_legacy_gauss *g,
+                                  int64_t M, double p, double q,
+                                  const int32_t *n1, const int32_t *n0,
+                                  double fkt, double tmin, double tmax,
+                                  float *theta)
+{
+    if (!rng || !g || M < 0 || (M > 0 && (!n1 || !n0 || !theta))
+        || !(p > 0.0) || !(q > 0.0) || !(fkt >= 0.0)) {
+        bnpc_set_error("bad argument: mt_beta_theta");
+        return 2;
+    }
+    for (int64_t m = 0; m < M; m++) {
+        if (n1[m] < 0 || n0[m] < 0) {
+            bnpc_set_error("bad argument: negative count");
+            return 2;
+        }
+    }
+    for (int64_t m = 0; m < M; m++) {
+        double v = lg_beta(rng, g, p + (double)n1[m] * fkt,
+                           q + (double)n0[m] * fkt);
+        v = v < tmin ? tmin : (v > tmax ? tmax : v);
+        theta[m] = (float)v;
+    }
+    return 0;
+}

@@ -213,6 +213,49 @@ def _native_batch_is_exact(table):
         return False
 
 
+_BETA = {}
+
+
+def _native_beta():
+    """Whether np.random.beta may be drawn natively (bnpc_mt_beta: NumPy's
+    legacy sampler restated on NumPy's own stream): BNPC_NATIVE_BETA != 0 and
+    a draw over every branch of the sampler - Johnk, the shape < 1 and
+    shape > 1 gammas, shape == 1, with and without a cached Gaussian - came
+    out bit-identical to NumPy's from the same state and left the stream and
+    the cached Gaussian where NumPy leaves them.  Checked once per process;
+    the stream is put back as it was."""
+    pid = os.getpid()
+    if _BETA.get('pid') != pid:
+        _BETA.clear()
+        _BETA.update(pid=pid, ok=False)
+        if os.environ.get('BNPC_NATIVE_BETA', '1') != '0':
+            saved = np.random.get_state()
+            try:
+                a = np.array([.25, 1.25, 7.25, .25, 1., 1., .999, 400.5, .5,
+                    3., 1e5, .25, 1.25] * 5)
+                b = np.array([.25, .25, 3.25, 9.25, 1., 2., 1., .75, .5, 1.,
+                    2e5, 1e4, 1.25] * 5)
+                ok = True
+                for pre in (0, 1):
+                    np.random.seed(917 + pre)
+                    if pre:
+                        np.random.normal()
+                    start = np.random.get_state()
+                    want = np.random.beta(a, b)
+                    end = np.random.get_state()
+                    np.random.set_state(start)
+                    got = _lib.beta(a, b)
+                    now = np.random.get_state()
+                    ok &= np.array_equal(want, got) and now[2:] == end[2:] \
+                        and np.array_equal(now[1], end[1])
+                _BETA['ok'] = bool(ok)
+            except Exception:       # noqa: BLE001
+                _BETA['ok'] = False
+            finally:
+                np.random.set_state(saved)
+    return _BETA['ok']
+
+
 def _tn_rvs_scalar(a, b, loc, scale):
     """truncnorm.rvs(a, b, loc=loc, scale=scale), one draw: one uniform of the
     global stream through the ppf - natively when allowed, else SciPy."""
@@ -478,7 +521,13 @@ class CRP:
         return params
 
     def _beta_draw(self, n1, n0):
-        draw = np.random.beta(self.p + n1, self.q + n0)
+        """clip(Beta(p + n1, q + n0)) as float32, one draw per mutation in
+        order (libs/CRP.py:183-188): NumPy's legacy sampler, natively on the
+        same stream when the start-up comparison allows."""
+        if _native_beta():
+            draw = _lib.beta(self.p + n1, self.q + n0)
+        else:
+            draw = np.random.beta(self.p + n1, self.q + n0)
         return np.clip(draw, TMIN, TMAX).astype(np.float32)
 
     def _init_cl_params_new(self, i, fkt=1):

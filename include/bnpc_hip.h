@@ -287,6 +287,30 @@ int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out);
 int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
                      int32_t *sd_idx, double *U, double *u);
 
+/* NumPy's legacy Beta sampler on the same stream (np.random.beta of
+ * libs/CRP.py:183-188, 155-180, 563-567): Johnk's algorithm for shapes <= 1,
+ * else two legacy standard gammas (Marsaglia-Tsang on the polar-method
+ * Gaussian / the shape < 1 rejection), libm pow / log / exp / sqrt.  The
+ * polar method caches its second variate in NumPy's RandomState
+ * (has_gauss, gauss), state every normal / gamma draw of the stream shares:
+ * `g` points at it (in place when the binding can locate it, else a copy the
+ * binding writes back). */
+typedef struct bnpc_legacy_gauss {
+    int32_t has_gauss;
+    int32_t pad_;
+    double gauss;
+} bnpc_legacy_gauss;
+/* out[i] = Beta(a[i], b[i]), i in order (the element order of NumPy's
+ * broadcast loop) */
+int bnpc_mt_beta(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t n,
+                 const double *a, const double *b, double *out);
+/* theta[m] = float32(clip(Beta(p + n1[m] * fkt, q + n0[m] * fkt), tmin,
+ * tmax)): a profile row from column counts (CRP._init_cl_params_new) */
+int bnpc_mt_beta_theta(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t M,
+                       double p, double q, const int32_t *n1,
+                       const int32_t *n0, double fkt, double tmin,
+                       double tmax, float *theta);
+
 /* log(exp(log_p[i]) - exp(log_q[i])) for log_q <= log_p, evaluated with the
  * arithmetic of scipy.special.logsumexp([log_p, log_q + pi*1j], axis=0).real
  * - which is how scipy.stats.truncnorm computes the Gaussian mass of an

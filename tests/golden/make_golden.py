@@ -304,6 +304,49 @@ def gold_rng():
     save('rng.npz', **out)
 
 
+def gold_rng_beta():
+    """Legacy Beta / Gamma sampler of the global stream (the draws behind
+    CRP._init_cl_params_new, libs/CRP.py:183-188, _init_cl_params :155-180 and
+    update_DP_alpha :386-410): array arguments over every branch - Johnk
+    (both shapes <= 1), Marsaglia-Tsang for shapes > 1, the shape < 1 gamma,
+    shape == 1 (exponential) - with the cached Gaussian of the polar method
+    set and unset on entry, and the stream position checked afterwards."""
+    out = {}
+    rng = np.random.RandomState(5)
+    M = 257
+    # the shapes a single cell gives (p + x, q + 1 - x; NaN -> mixture)
+    x = (rng.random_sample(M) < 0.3).astype(float)
+    x[rng.random_sample(M) < 0.2] = np.nan
+    shapes = {
+        'cell_q': (np.nan_to_num(.25 + x, nan=.25),
+            np.nan_to_num(.25 + (1 - x), nan=.25)),
+        'cell_u': (np.nan_to_num(1 + x, nan=1.), np.nan_to_num(1 + (1 - x),
+            nan=1.)),
+        'cluster': (.25 + rng.randint(0, 900, M), .25 + rng.randint(0, 900, M)),
+        'mixed': (np.array([.25, 1.25, 7.25, .25, 1., 1., .999, 1e-3, 400.5,
+                1.0000001, .5, 3., 1e5, .25] * 8),
+            np.array([.25, .25, 3.25, 9.25, 1., 2., 1., 1e-3, .75,
+                .9999999, .5, 1., 2e5, 1e4] * 8)),
+    }
+    for name, (a, b) in shapes.items():
+        out[name + '_a'], out[name + '_b'] = a, b
+    for seed in (3, 42):
+        for pre_gauss in (0, 1):
+            np.random.seed(seed)
+            if pre_gauss:       # leaves a cached Gaussian behind
+                np.random.normal()
+            key = f's{seed}_g{pre_gauss}_'
+            for name, (a, b) in shapes.items():
+                out[key + name] = np.random.beta(a, b)
+            out[key + 'gamma'] = np.array([np.random.gamma(3.5, 0.7),
+                np.random.gamma(0.4, 2.0), np.random.gamma(1.0, 1.5)])
+            st = np.random.get_state()
+            out[key + 'has_gauss'] = np.array([st[3]])
+            out[key + 'gauss'] = np.array([st[4]])
+            out[key + 'tail'] = np.random.random(3)
+    save('rng_beta.npz', **out)
+
+
 # -------------------------------------------------------------- trajectories
 def run_traj(kind, data, steps, seed, pb=(.25, .25), sm_prob=.33, sm_steps=3):
     if kind == 'fixed':
@@ -354,10 +397,14 @@ def gold_trajectories():
 
 
 if __name__ == '__main__':
+    if sys.argv[1:] == ['rng_beta']:    # added in round 3: only this file
+        gold_rng_beta()
+        sys.exit(0)
     gold_calc_ll()
     gold_state_functions()
     gold_normalisers()
     gold_rng()
+    gold_rng_beta()
     gold_trajectories()
     meta = {
         'python': sys.version.split()[0],

@@ -562,3 +562,67 @@ def test_team_entry_points_from_two_threads():
         w.join(timeout=120)
     assert not any(w.is_alive() for w in workers), 'team calls hang'
     assert not errors, errors
+
+
+# ------------------------------------------------- legacy Beta / Gamma sampler
+@pytest.mark.parametrize('live', ['1', '0'])
+def test_native_beta_equals_numpy_golden(golden_dir, live, monkeypatch):
+    """bnpc_mt_beta against vectors NumPy itself drew on the reference's
+    stack (tests/golden/rng_beta.npz: single-cell shapes under two priors,
+    cluster-sized shapes, a mix over every branch of the legacy sampler),
+    with and without a cached Gaussian on entry; the gamma draws NumPy makes
+    AFTERWARDS (they share the cached Gaussian), the cache itself and the
+    stream position must come out as in the capture - through the located
+    in-place pointer and through the get_state / set_state fallback."""
+    monkeypatch.setenv('BNPC_GAUSS_LIVE', live)
+    _lib._gauss_live.clear()
+    try:
+        assert (_lib.gauss_live() is not None) == (live == '1')
+        t = np.load(os.path.join(golden_dir, 'rng_beta.npz'))
+        for seed in (3, 42):
+            for pre_gauss in (0, 1):
+                np.random.seed(seed)
+                if pre_gauss:
+                    np.random.normal()
+                key = f's{seed}_g{pre_gauss}_'
+                for name in ('cell_q', 'cell_u', 'cluster', 'mixed'):
+                    got = _lib.beta(t[name + '_a'], t[name + '_b'])
+                    assert np.array_equal(got, t[key + name]), (key, name)
+                gam = [np.random.gamma(3.5, 0.7), np.random.gamma(0.4, 2.0),
+                    np.random.gamma(1.0, 1.5)]
+                assert np.array_equal(gam, t[key + 'gamma'])
+                st = np.random.get_state()
+                assert st[3] == t[key + 'has_gauss'][0]
+                assert st[4] == t[key + 'gauss'][0]
+                assert np.array_equal(np.random.random(3), t[key + 'tail'])
+    finally:
+        _lib._gauss_live.clear()
+
+
+def test_native_beta_theta_and_this_numpy():
+    """The profile-row form (counts -> clipped float32 row) against the NumPy
+    of THIS process on random counts incl. empty columns, interleaved with
+    NumPy's own normal / gamma draws; bad shapes are errors, not draws."""
+    rng = np.random.RandomState(8)
+    for M, hi in ((1, 2), (130, 2), (1000, 900), (5000, 40)):
+        n1 = rng.randint(0, hi, M).astype(np.int32)
+        n0 = rng.randint(0, hi, M).astype(np.int32)
+        for p, q in ((.25, .25), (1., 1.), (.75, 2.)):
+            np.random.seed(M)
+            np.random.normal(size=3)
+            want = np.clip(np.random.beta(p + n1, q + n0), 1e-5, 1 - 1e-5) \
+                .astype(np.float32)
+            w_tail = (np.random.gamma(2.5), np.random.normal(),
+                np.random.random())
+            np.random.seed(M)
+            np.random.normal(size=3)
+            got = _lib.beta_theta(p, q, n1, n0, 1, 1e-5, 1 - 1e-5)
+            g_tail = (np.random.gamma(2.5), np.random.normal(),
+                np.random.random())
+            assert np.array_equal(want, got) and w_tail == g_tail
+    pos = np.random.get_state()[2]
+    with pytest.raises(RuntimeError):
+        _lib.beta(np.array([1., 0.]), np.array([1., 1.]))
+    with pytest.raises(RuntimeError):
+        _lib.beta(np.array([1., np.nan]), np.array([1., 1.]))
+    assert np.random.get_state()[2] == pos      # nothing was drawn
