@@ -56,7 +56,7 @@ class MHArgs(C.Structure):
         ('U', C.c_void_p), ('u', C.c_void_p), ('new_theta', C.c_void_p),
         ('prior_out', C.c_void_p), ('A', C.c_void_p),
         ('log_prob', C.c_void_p), ('declined', C.c_void_p),
-        ('threads', C.c_int)]
+        ('threads', C.c_int), ('screen', C.c_void_p)]
 
 
 class LogAArgs(C.Structure):
@@ -138,6 +138,12 @@ SIGNATURES = {
     'bnpc_mh_batch': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
         C.POINTER(MHArgs),
         C.POINTER(C.c_int)]),
+    'bnpc_mh_screen': (C.c_int, [_ctx, C.c_int, C.POINTER(MHArgs),
+        C.c_void_p]),
+    'bnpc_mh_batch_dev': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
+        C.POINTER(MHArgs), C.c_int, C.POINTER(C.c_int)]),
+    'bnpc_mh_screen_stats': (C.c_int, [_ctx, C.POINTER(_i64),
+        C.POINTER(_i64)]),
     'bnpc_rg_scan_step': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
         C.c_int, _i64, _pi64, C.c_double, C.POINTER(MHArgs), _pi32, _pi32,
         C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -630,13 +636,16 @@ def threads_for(elements):
 
 def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
             trans_prob, known=None, want_prior=False, draws=None,
-            threads=None):
+            threads=None, ctx=None, counts_src=0):
     """bnpc_mh_batch: the draws and the arithmetic of MH_cluster_params for
     the G rows of `old` (float32 G x M).  `draws` = (sd_idx, U, u) evaluates
-    given draws instead of taking them from the global stream.  Returns
-    (status, new, log_prob, declined, prior, (sd_idx, U, u)); status 1: only
-    the draws are valid - they are views of scratch that the next call
-    overwrites."""
+    given draws instead of taking them from the global stream.  With `ctx`
+    (a device Context whose resident counts - counts_src 0: by label, 1: the
+    last view counts - are those of n1 / n0) the device screens the batch
+    first and the host evaluates only what it leaves (bnpc_mh_batch_dev).
+    Returns (status, new, log_prob, declined, prior, (sd_idx, U, u)); status
+    1: only the draws are valid - they are views of scratch that the next
+    call overwrites."""
     old = np.ascontiguousarray(old, dtype=np.float32)
     G, M = old.shape
     n1 = np.ascontiguousarray(n1, dtype=np.int32)
@@ -667,9 +676,19 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
     a.prior_out = prior.ctypes.data if prior is not None else None
     a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
     a.threads = threads_for(G * M) if threads is None else threads
+    a.screen = None
     status = C.c_int(0)
     lib = load()
-    if draws is None:
+    handle = getattr(ctx, '_h', None)
+    if handle and not trans_prob:
+        if draws is None:
+            with NumpyStream() as rng:
+                check(lib.bnpc_mh_batch_dev(handle, C.addressof(kernels), rng,
+                    C.byref(a), counts_src, C.byref(status)), 'mh_batch_dev')
+        else:
+            check(lib.bnpc_mh_batch_dev(handle, C.addressof(kernels), None,
+                C.byref(a), counts_src, C.byref(status)), 'mh_batch_dev')
+    elif draws is None:
         with NumpyStream() as rng:
             check(lib.bnpc_mh_batch(C.addressof(kernels), rng, C.byref(a),
                 C.byref(status)), 'mh_batch')
@@ -729,6 +748,7 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
     a.new_theta = new.ctypes.data
     a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
     a.threads = threads_for(G * M) if threads is None else threads
+    a.screen = None
     status = C.c_int(0)
     scan_prob = C.c_double(0.0)
     with NumpyStream() as rng:
@@ -1012,6 +1032,34 @@ class Context:
         check(self._lib.bnpc_view_counts(self._h, view, ptr(labels, C.c_int64),
             G, ptr(n1, C.c_int32), ptr(n0, C.c_int32)), 'view_counts')
         return n1, n0
+
+    def mh_screen(self, counts_src, old, sd, draws, tmin, tmax, FP, FN, p, q,
+                uniform):
+        """bnpc_mh_screen: uint8 (G, M), 0 where the proposal is declined for
+        certain under the resident counts (tests)."""
+        old = np.ascontiguousarray(old, dtype=np.float32)
+        G, M = old.shape
+        sd = np.ascontiguousarray(sd, dtype=np.float64)
+        sd_idx = np.ascontiguousarray(draws[0], dtype=np.int32)
+        U = np.ascontiguousarray(draws[1], dtype=np.float64)
+        u = np.ascontiguousarray(draws[2], dtype=np.float64)
+        a = MHArgs()
+        a.G, a.M = G, M
+        a.old_theta, a.sd, a.n_sd = old.ctypes.data, sd.ctypes.data, sd.size
+        a.tmin, a.tmax, a.FP, a.FN, a.p, a.q = tmin, tmax, FP, FN, p, q
+        a.uniform_prior, a.trans_prob = int(bool(uniform)), 0
+        a.sd_idx, a.U, a.u = sd_idx.ctypes.data, U.ctypes.data, u.ctypes.data
+        flags = np.empty((G, M), dtype=np.uint8)
+        check(self._lib.bnpc_mh_screen(self._h, counts_src, C.byref(a),
+            flags.ctypes.data), 'mh_screen')
+        return flags
+
+    def mh_screen_stats(self):
+        """(elements screened so far, of those left to the host)"""
+        seen, kept = _i64(0), _i64(0)
+        check(self._lib.bnpc_mh_screen_stats(self._h, C.byref(seen),
+            C.byref(kept)), 'mh_screen_stats')
+        return seen.value, kept.value
 
     def reload_options(self):
         check(self._lib.bnpc_reload_options(self._h), 'reload_options')

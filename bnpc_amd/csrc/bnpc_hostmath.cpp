@@ -31,6 +31,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <functional>
 #include <mutex>
@@ -312,16 +313,27 @@ inline double beta_logpdf1(const bnpc_host_kernels *k, float x32, double p,
     return l;
 }
 
-// elements [m0, m1) of cluster g; false: an element needs SciPy's own path
+// n elements of cluster g - positions idx[0..n) of its row, or, idx == NULL,
+// the run [m0, m0 + n); false: an element needs SciPy's own path
 bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
-              const Consts &c, int64_t g, int64_t m0, int64_t m1)
+              const Consts &c, int64_t g, const int32_t *idx, int64_t m0,
+              int n)
 {
-    const int n = (int)(m1 - m0);
-    const size_t off = (size_t)g * a->M + m0;
-    const float *old = a->old_theta + off;
-    const int32_t *n1 = a->n1 + off, *n0 = a->n0 + off;
-    const int32_t *si = a->sd_idx + off;
-    const double *U = a->U + off, *lu = a->u + off;
+    const size_t row = (size_t)g * a->M;
+    // gathered inputs (a dense run is gathered too: one code path)
+    float old[BLK];
+    int32_t n1[BLK], n0[BLK], si[BLK], at[BLK];
+    double U[BLK], lu[BLK];
+    for (int i = 0; i < n; i++) {
+        const int32_t m = idx ? idx[i] : (int32_t)(m0 + i);
+        at[i] = m;
+        old[i] = a->old_theta[row + m];
+        n1[i] = a->n1[row + m];
+        n0[i] = a->n0[row + m];
+        si[i] = a->sd_idx[row + m];
+        U[i] = a->U[row + m];
+        lu[i] = a->u[row + m];
+    }
 
     double std_[BLK], lsd[BLK], lo[BLK], hi[BLK], lgm[BLK];
     double t0[BLK], t1[BLK], t2[BLK], t3[BLK];
@@ -417,15 +429,16 @@ bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
 
     // A = new_ll + new_prior - old_ll - old_prior + rev - fwd
     double pr_new[BLK], pr_old[BLK];
-    double *A = a->A + off;
+    double A[BLK];
     for (int i = 0; i < n; i++) {
         if (a->uniform_prior) {
             pr_new[i] = pr_old[i] = 0.0;
         } else {
             pr_new[i] = beta_logpdf1(k, nw[i], a->p, a->q, c.betaln_pq);
             if (a->known_theta
-                && !memcmp(a->known_theta + off + i, old + i, sizeof(float)))
-                pr_old[i] = a->known_prior[off + i];
+                && !memcmp(a->known_theta + row + at[i], old + i,
+                           sizeof(float)))
+                pr_old[i] = a->known_prior[row + at[i]];
             else
                 pr_old[i] = beta_logpdf1(k, old[i], a->p, a->q, c.betaln_pq);
         }
@@ -442,12 +455,12 @@ bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
     uloop(k->np_log, k->np_log_data, lu, t0, n);
     int nd = 0;
     int didx[BLK];
-    float *out = a->new_theta + off;
-    double *prior_out = a->prior_out ? a->prior_out + off : nullptr;
+    float *out = a->new_theta + row;
+    double *prior_out = a->prior_out ? a->prior_out + row : nullptr;
     for (int i = 0; i < n; i++) {
         const bool decline = t0[i] >= A[i];
-        out[i] = decline ? old[i] : nw[i];
-        if (prior_out) prior_out[i] = decline ? pr_old[i] : pr_new[i];
+        out[at[i]] = decline ? old[i] : nw[i];
+        if (prior_out) prior_out[at[i]] = decline ? pr_old[i] : pr_new[i];
         if (decline) {
             didx[nd] = i;
             t1[nd++] = A[i];
@@ -463,6 +476,8 @@ bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
         uloop(k->np_log, k->np_log_data, t2, t3, nd);
         for (int j = 0; j < nd; j++) A[didx[j]] = t3[j];
     }
+    double *A_out = a->A + row;
+    for (int i = 0; i < n; i++) A_out[at[i]] = A[i];
     __atomic_fetch_add(&a->declined[g], (int64_t)nd, __ATOMIC_RELAXED);
     return true;
 }
@@ -511,19 +526,6 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
 
     for (int64_t g = 0; g < G; g++) a->declined[g] = 0;
-    // tasks of 128 elements; of 64 in a small batch, so that 16 ranks get
-    // three even rounds out of 3 x 1000 elements instead of one and a half
-    // (3 x 1000 on 16 ranks: 72-77 us with tasks of 128, 67-68 us with 64;
-    // 1 x 1000: 45 against 33 us)
-    const int64_t blk = G * M <= SMALL_BATCH ? BLK / 2 : BLK;
-    const int64_t chunks = (M + blk - 1) / blk;
-    const int64_t tasks = G * chunks;
-    int threads = a->threads;
-    if (threads > tasks) threads = (int)tasks;
-    if (threads < 1) threads = 1;
-
-    std::atomic<int64_t> next(0), rows_ready(rng ? 0 : G);
-    std::atomic<int> bail(0);
     static const bool trace = getenv("BNPC_MH_TRACE") != nullptr;
     timespec ts0;
     long t_draws = 0;
@@ -534,6 +536,128 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         return (ts.tv_sec - ts0.tv_sec) * 1000000000L
             + (ts.tv_nsec - ts0.tv_nsec);
     };
+    std::atomic<int> bail(0);
+    int threads = a->threads;
+
+    if (a->screen && !a->trans_prob) {
+        // The device has screened the batch (bnpc_mh_screen): screen[g, m]
+        // == 0 means "declined for certain" - the approximate log acceptance
+        // ratio lies below log(u) by more than every error it can carry - so
+        // the element keeps its old value and none of its transcendentals is
+        // evaluated; everything else (likely accepted, in doubt, exotic) goes
+        // through the exact arithmetic below, a few per cent of the batch.
+        if (rng) {
+            bnpc_set_error("bad argument: a screened batch brings its draws");
+            return 2;
+        }
+        static thread_local std::vector<int32_t> todo, miss;
+        static thread_local std::vector<int64_t> todo_at, miss_at;
+        todo.clear();
+        miss.clear();
+        todo_at.assign(G + 1, 0);
+        miss_at.assign(G + 1, 0);
+        const bool want_prior = a->prior_out && !a->uniform_prior;
+        for (int64_t g = 0; g < G; g++) {
+            const size_t row = (size_t)g * M;
+            const uint8_t *sc = a->screen + row;
+            const float *old = a->old_theta + row;
+            float *out = a->new_theta + row;
+            int64_t kept = 0;
+            for (int64_t m = 0; m < M; m++) {
+                if (sc[m]) {
+                    todo.push_back((int32_t)m);
+                    continue;
+                }
+                kept++;
+                out[m] = old[m];
+                if (want_prior) {
+                    if (a->known_theta
+                        && !memcmp(a->known_theta + row + m, old + m,
+                                   sizeof(float)))
+                        a->prior_out[row + m] = a->known_prior[row + m];
+                    else
+                        miss.push_back((int32_t)m);
+                }
+            }
+            if (a->prior_out && a->uniform_prior)
+                for (int64_t m = 0; m < M; m++)
+                    if (!sc[m]) a->prior_out[row + m] = 0.0;
+            a->declined[g] = kept;
+            todo_at[g + 1] = (int64_t)todo.size();
+            miss_at[g + 1] = (int64_t)miss.size();
+        }
+        // tasks: runs of <= 64 flagged elements of one row, then runs of
+        // <= 256 prior-cache misses of one row
+        struct Task {
+            int64_t g, lo, hi;
+            bool prior;
+        };
+        static thread_local std::vector<Task> tasks;
+        tasks.clear();
+        for (int64_t g = 0; g < G; g++)
+            for (int64_t lo = todo_at[g]; lo < todo_at[g + 1]; lo += BLK / 2)
+                tasks.push_back({g, lo, std::min(lo + BLK / 2,
+                                                 todo_at[g + 1]), false});
+        for (int64_t g = 0; g < G; g++)
+            for (int64_t lo = miss_at[g]; lo < miss_at[g + 1]; lo += 2 * BLK)
+                tasks.push_back({g, lo, std::min(lo + 2 * BLK,
+                                                 miss_at[g + 1]), true});
+        const int64_t n_tasks = (int64_t)tasks.size();
+        const Task *tk = tasks.data();
+        const int32_t *todo_p = todo.data(), *miss_p = miss.data();
+        // a thread per ~8 tasks: waking the team costs more than a few
+        // hundred elements
+        if (threads > (n_tasks + 7) / 8) threads = (int)((n_tasks + 7) / 8);
+        if (threads < 1) threads = 1;
+        std::atomic<int64_t> next(0);
+        auto work = [&](int) {
+            for (;;) {
+                const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
+                if (t >= n_tasks) break;
+                if (bail.load(std::memory_order_relaxed)) continue;
+                const Task &q = tk[t];
+                if (q.prior) {
+                    const size_t row = (size_t)q.g * M;
+                    for (int64_t j = q.lo; j < q.hi; j++) {
+                        const int32_t m = miss_p[j];
+                        a->prior_out[row + m] = beta_logpdf1(k,
+                            a->old_theta[row + m], a->p, a->q, c.betaln_pq);
+                    }
+                } else if (!mh_block(k, a, c, q.g, todo_p + q.lo, 0,
+                                     (int)(q.hi - q.lo))) {
+                    bail.store(1, std::memory_order_relaxed);
+                }
+            }
+        };
+        if (threads > 1)
+            team_for(threads)->run(threads, work);
+        else
+            work(0);
+        if (trace)
+            fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld of %lld "
+                    "elements exact, %lld prior misses, threads=%d, %.1f us\n",
+                    (long long)G, (long long)M, (long long)todo.size(),
+                    (long long)(G * M), (long long)miss.size(), threads,
+                    since() / 1e3);
+        if (bail.load()) {
+            *status = 1;
+            return 0;
+        }
+        for (int64_t g = 0; g < G; g++) a->log_prob[g] = NAN;
+        return 0;
+    }
+
+    // tasks of 128 elements; of 64 in a small batch, so that 16 ranks get
+    // three even rounds out of 3 x 1000 elements instead of one and a half
+    // (3 x 1000 on 16 ranks: 72-77 us with tasks of 128, 67-68 us with 64;
+    // 1 x 1000: 45 against 33 us)
+    const int64_t blk = G * M <= SMALL_BATCH ? BLK / 2 : BLK;
+    const int64_t chunks = (M + blk - 1) / blk;
+    const int64_t tasks = G * chunks;
+    if (threads > tasks) threads = (int)tasks;
+    if (threads < 1) threads = 1;
+
+    std::atomic<int64_t> next(0), rows_ready(rng ? 0 : G);
 
     // the draws, cluster by cluster in the reference's order
     auto draw_rows = [&]() {
@@ -578,7 +702,7 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             if (bail.load(std::memory_order_relaxed)) continue;
             const int64_t m0 = ch * blk;
             const int64_t m1 = m0 + blk < M ? m0 + blk : M;
-            if (!mh_block(k, a, c, g, m0, m1))
+            if (!mh_block(k, a, c, g, nullptr, m0, (int)(m1 - m0)))
                 bail.store(1, std::memory_order_relaxed);
         }
     };

@@ -51,7 +51,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 3; }
+extern "C" int bnpc_abi_version(void) { return 4; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -102,6 +102,8 @@ struct Tunables {
     int seq_stage = 1;              // k_ll_seqp: tables copied to the device
     int seq_kc = 1;                 // clusters per wave in k_ll_seq
     int lazy_matrix = 1;            // sweep matrix copied behind the hints
+    int mh_screen = 1;              // device screen of the parameter batches
+    int mh_screen_min = 512;        // ... from this many elements on
 };
 
 static int env_int(const char *name, int dflt)
@@ -133,6 +135,8 @@ static void read_tunables(Tunables &t)
     t.seq_stage = env_int("BNPC_SEQ_STAGE", 1);
     t.seq_kc = env_int("BNPC_SEQ_KC", 1);
     t.lazy_matrix = env_int("BNPC_LAZY_MATRIX", 1);
+    t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
+    t.mh_screen_min = env_int("BNPC_MH_SCREEN_MIN", 512);
 }
 
 struct bnpc_ctx {
@@ -155,6 +159,7 @@ struct bnpc_ctx {
     // resident per-cluster counts of the last bnpc_colcounts_by_label
     DevBuf lab_cnt;
     int64_t lab_K = 0;
+    int64_t cnt_rows = 0;       // segments of the last bnpc_view_counts (c->cnt)
     // pinned host buffers: the sweep's ll matrix / small reductions
     void *pin = nullptr;
     size_t pin_cap = 0;
@@ -177,6 +182,13 @@ struct bnpc_ctx {
     char *zc_out_dev = nullptr;
     void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
     size_t hint_cap = 0;
+    // pinned block of a screened parameter batch (bnpc_mh_batch_dev): the
+    // draws, the old parameter rows and the screen's verdicts, read / written
+    // in place by k_mh_screen
+    void *mh_pin = nullptr;
+    char *mh_dev = nullptr;
+    size_t mh_cap = 0;
+    int64_t screened = 0, screen_kept = 0;  // elements seen / left to the host
     size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
     bool total_pending = false;     // a deferred bnpc_ll_total_issue
     int total_blocks = 0, total_E = 0;
@@ -1449,6 +1461,123 @@ __global__ __launch_bounds__(256) void k_ll_total(
         red[threadIdx.x][0];
 }
 
+
+// ---------------------------------------------------------------------------
+// K7: screen of a parameter batch - which proposals of CRP.MH_cluster_params
+// (libs/CRP.py:314-344) are declined FOR CERTAIN.
+//
+// The host evaluates the MH update of a cluster profile bit for bit as SciPy
+// does (bnpc_hostmath.cpp: ~10 scalar special-function calls per element,
+// 127 ns each on one core) although nine proposals in ten end up declined
+// and leave nothing behind but `old`.  What decides an element is
+//     log(u) >= A,   A = ll(new) - ll(old) + prior(new) - prior(old)
+//                        + rev - fwd                      (libs/CRP.py:347-383)
+// and the decision does not need A's bits, only its value to within the gap
+// to log(u), which is typically tens of units.  So every element is
+// evaluated HERE first, in plain float64 with the device's own erfc / log /
+// inverse normal (a few ulp), together with a bound on everything that can
+// separate this A from the host's:
+//   * the proposal new = float32(old + sd * ppf(U)) may differ from the
+//     host's by float32 ulps (the host's ppf goes through SciPy's log-space
+//     formulas): |dA / dtheta| * 4 ulp, with the derivative bounded term by
+//     term (likelihood: n1 c / P1 + n0 c / P0, prior: |p-1| / t + |q-1| /
+//     (1-t), truncation mass: 1 / (sd Z));
+//   * rounding of the sums: 1e-12 of the terms' magnitudes, + 1e-7.
+// An element whose log(u) exceeds A by more than that is flagged 0: declined
+// whatever the exact arithmetic says.  Everything else - likely accepted, in
+// doubt, or on a branch this kernel does not model (an interval that does
+// not straddle zero, a proposal within ulps of the truncation bounds, a draw
+// that is exactly 0) - is flagged 1 and evaluated by the host exactly as
+// before.  The chain's bits do not change (tests: screen vs exact decisions
+// on random and adversarial batches; every chain test runs through it).
+// rev - fwd = log Z(old) - log Z(new): the quadratic terms are equal because
+// float32(new - old) == -float32(old - new), the log(sd) terms cancel.
+// ---------------------------------------------------------------------------
+struct MHScreenConst {
+    double sd[8];
+    double FP, FN, p, q;
+    float tmin32, tmax32;
+    int uniform_prior;
+};
+
+__global__ __launch_bounds__(256) void k_mh_screen(
+    const float *__restrict__ theta, const int *__restrict__ n1,
+    const int *__restrict__ n0, const int *__restrict__ sd_idx,
+    const double *__restrict__ U, const double *__restrict__ u, long long GM,
+    int M, int sum_row, MHScreenConst k, unsigned char *__restrict__ flags)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= GM) return;
+    const int g = (int)(i / M);
+    const int m = (int)(i - (long long)g * M);
+    int c1, c0;
+    if (g == sum_row) {             // the merged cluster of a restricted scan
+        c1 = n1[m] + n1[M + m];
+        c0 = n0[m] + n0[M + m];
+    } else {
+        c1 = n1[(size_t)g * M + m];
+        c0 = n0[(size_t)g * M + m];
+    }
+    const float old = theta[i];
+    const double Ui = U[i], ui = u[i];
+    const int si = sd_idx[i];
+    unsigned char flag = 1;
+    if (si >= 0 && si < 8 && Ui > 0.0 && Ui < 1.0 && ui > 0.0 && ui < 1.0
+        && old >= k.tmin32 && old <= k.tmax32 && c1 >= 0 && c0 >= 0) {
+        const double sd = k.sd[si];
+        const double lo = (double)(k.tmin32 - old) / sd;
+        const double hi = (double)(k.tmax32 - old) / sd;
+        if (lo <= 0.0 && hi > 0.0) {
+            const double Pa = normcdf(lo), Qb = normcdf(-hi);
+            const double Z = 1.0 - Pa - Qb;
+            const double pl = Pa + Ui * Z;
+            double x;
+            if (pl <= 0.5)
+                x = normcdfinv(pl);
+            else
+                x = -normcdfinv(Qb + (1.0 - Ui) * Z);
+            const double xv = x * sd + (double)old;
+            const float nw = (float)xv;
+            // four float32 steps inside the bounds: the host's proposal may
+            // sit an ulp or two away and must still be inside
+            const float in_lo = k.tmin32 * (1.0f + 6e-7f);
+            const float in_hi = k.tmax32 * (1.0f - 6e-7f);
+            if (nw > in_lo && nw < in_hi) {
+                const double ar = (double)(k.tmin32 - nw) / sd;
+                const double br = (double)(k.tmax32 - nw) / sd;
+                const double Zr = 1.0 - normcdf(ar) - normcdf(-br);
+                const double pFN1 = 1.0 - k.FN, pFP0 = 1.0 - k.FP;
+                const double tn = (double)nw, on = (double)(1.0f - nw);
+                const double to = (double)old, oo = (double)(1.0f - old);
+                const double P1n = tn * pFN1 + on * k.FP;
+                const double P0n = tn * k.FN + on * pFP0;
+                const double P1o = to * pFN1 + oo * k.FP;
+                const double P0o = to * k.FN + oo * pFP0;
+                const double lln = (double)c1 * log(P1n) + (double)c0 * log(P0n);
+                const double llo = (double)c1 * log(P1o) + (double)c0 * log(P0o);
+                double prn = 0.0, pro = 0.0, prs = 0.0;
+                if (!k.uniform_prior) {
+                    prn = (k.q - 1.0) * log1p(-tn) + (k.p - 1.0) * log(tn);
+                    pro = (k.q - 1.0) * log1p(-to) + (k.p - 1.0) * log(to);
+                    prs = fabs(k.p - 1.0) / tn + fabs(k.q - 1.0) / (1.0 - tn);
+                }
+                const double A = (lln - llo) + (prn - pro) + (log(Z) - log(Zr));
+                const double cc = fabs(1.0 - k.FN - k.FP);
+                const double sens = (double)c1 * cc / P1n + (double)c0 * cc / P0n
+                    + prs + 1.0 / (sd * Zr);
+                const double dtheta = 4.0 * 1.2e-7 * tn + 1e-13;
+                const double margin = sens * dtheta + 1e-7
+                    + 1e-12 * (fabs(lln) + fabs(llo) + fabs(prn) + fabs(pro));
+                const double gap = log(ui) - A;
+                if (Z > 0.0 && Zr > 0.0 && gap == gap && gap > margin
+                    && gap < INFINITY)
+                    flag = 0;
+            }
+        }
+    }
+    flags[i] = flag;
+}
+
 // ---------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------
@@ -1647,6 +1776,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
+    if (c->mh_pin) (void)hipHostFree(c->mh_pin);
     for (int s = 0; s < BNPC_TILE_SLOTS; s++) {
         pinned_free(c->tile_pin[s], c->tile_cap[s]);
         pinned_free(c->tile_rows[s], c->tile_rows_cap[s]);
@@ -2609,8 +2739,11 @@ extern "C" int bnpc_view_counts(bnpc_ctx *c, int view, const int64_t *labels,
     ARGCHK(c->views[view].n == 0 || labels, "labels is NULL");
     HIPCHK(hipSetDevice(c->device));
     SideLane lane(c);
-    return counts_from_masks(c, view,
+    c->cnt_rows = 0;
+    int rc = counts_from_masks(c, view,
         [=](int64_t s) -> int64_t { return labels[s]; }, G, c->cnt, n1, n0);
+    if (rc == 0) c->cnt_rows = G;
+    return rc;
 }
 
 extern "C" int bnpc_colcounts(bnpc_ctx *c, const int64_t *cells,
@@ -2628,6 +2761,7 @@ extern "C" int bnpc_colcounts(bnpc_ctx *c, const int64_t *cells,
     for (int64_t i = 0; i < n; i++)
         ARGCHK(cells[i] >= 0 && cells[i] < c->N, "cell index out of range");
     HIPCHK(hipSetDevice(c->device));
+    c->cnt_rows = 0;
     if (colcounts_device(c, cells, n, seg_offsets, G, c->cnt)) return 1;
     const size_t half = (size_t)G * c->M * sizeof(int32_t);
     D2H a, b;
@@ -2690,6 +2824,188 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
         d2h_finish(a);
         d2h_finish(b);
     }
+    return 0;
+}
+
+
+// ---- device screen of a parameter batch -----------------------------------
+// layout of the pinned block for G x M = E elements (all 16-byte aligned):
+//   U[E] f64 | u[E] f64 | sd_idx[E] i32 | theta[E] f32 | flags[E] u8
+struct MHPin {
+    double *U, *u;
+    int32_t *sd_idx;
+    float *theta;
+    uint8_t *flags;
+};
+
+static size_t mh_pin_offsets(size_t E, size_t off[5])
+{
+    const size_t Ea = (E + 15) & ~(size_t)15;
+    off[0] = 0;
+    off[1] = off[0] + Ea * 8;
+    off[2] = off[1] + Ea * 8;
+    off[3] = off[2] + Ea * 4;
+    off[4] = off[3] + Ea * 4;
+    return off[4] + Ea;
+}
+
+static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
+{
+    size_t off[5];
+    const size_t need = mh_pin_offsets(E, off);
+    if (need > c->mh_cap) {
+        // the screen of a batch in flight reads this block: nothing is in
+        // flight here (every screened call ends with a synchronisation)
+        if (c->mh_pin) HIPCHK(hipHostFree(c->mh_pin));
+        c->mh_pin = nullptr;
+        c->mh_dev = nullptr;
+        c->mh_cap = 0;
+        const size_t cap = need + need / 4 + 4096;
+        HIPCHK(hipHostMalloc(&c->mh_pin, cap, hipHostMallocDefault));
+        void *d = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&d, c->mh_pin, 0));
+        c->mh_dev = (char *)d;
+        c->mh_cap = cap;
+    }
+    char *h = (char *)c->mh_pin, *d = c->mh_dev;
+    host = {(double *)(h + off[0]), (double *)(h + off[1]),
+            (int32_t *)(h + off[2]), (float *)(h + off[3]),
+            (uint8_t *)(h + off[4])};
+    dev = {(double *)(d + off[0]), (double *)(d + off[1]),
+           (int32_t *)(d + off[2]), (float *)(d + off[3]),
+           (uint8_t *)(d + off[4])};
+    return 0;
+}
+
+// counts of the batch's rows on the device: src 0 = the per-cluster counts of
+// the last bnpc_colcounts_by_label (G rows), src 1 = the two segments of the
+// last bnpc_view_counts (rows 0, 1; a third row of the batch is their sum)
+static int mh_counts(bnpc_ctx *c, int src, int64_t G, const int **n1,
+                     const int **n0, int *sum_row)
+{
+    *sum_row = -1;
+    if (src == 0) {
+        ARGCHK(c->lab_cnt.p && c->lab_K == G,
+               "the batch does not match the resident per-cluster counts");
+        *n1 = (const int *)c->lab_cnt.p;
+        *n0 = *n1 + (size_t)G * c->M;
+    } else {
+        ARGCHK(c->cnt.p && c->cnt_rows == 2 && (G == 2 || G == 3),
+               "the batch does not match the last view counts");
+        *n1 = (const int *)c->cnt.p;
+        *n0 = *n1 + (size_t)2 * c->M;
+        if (G == 3) *sum_row = 2;
+    }
+    return 0;
+}
+
+static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
+                            const MHPin &dev)
+{
+    const int *n1, *n0;
+    int sum_row;
+    if (int rc = mh_counts(c, src, a->G, &n1, &n0, &sum_row)) return rc;
+    MHScreenConst k;
+    for (int i = 0; i < 8; i++) k.sd[i] = i < a->n_sd ? a->sd[i] : 1.0;
+    k.FP = a->FP;
+    k.FN = a->FN;
+    k.p = a->p;
+    k.q = a->q;
+    k.tmin32 = (float)a->tmin;
+    k.tmax32 = (float)a->tmax;
+    k.uniform_prior = a->uniform_prior;
+    const long long GM = (long long)a->G * a->M;
+    hipLaunchKernelGGL(k_mh_screen, dim3((unsigned)((GM + 255) / 256)),
+                       dim3(256), 0, c->stream, dev.theta, n1, n0, dev.sd_idx,
+                       dev.U, dev.u, GM, (int)a->M, sum_row, k, dev.flags);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int mh_screen_argchk(const bnpc_ctx *c, const bnpc_mh_args *a)
+{
+    ARGCHK(c && a, "NULL argument");
+    ARGCHK(a->G > 0 && a->M == c->M, "batch shape does not match the context");
+    ARGCHK(a->old_theta && a->sd && a->n_sd >= 1 && a->n_sd <= 8 && a->sd_idx
+           && a->U && a->u, "NULL argument");
+    ARGCHK(a->FP > 0.0 && a->FP < 1.0 && a->FN > 0.0 && a->FN < 1.0,
+           "error rates must lie in (0, 1)");
+    return 0;
+}
+
+extern "C" int bnpc_mh_screen(bnpc_ctx *c, int counts_src,
+                              const bnpc_mh_args *a, uint8_t *flags)
+{
+    if (int rc = mh_screen_argchk(c, a)) return rc;
+    ARGCHK(flags, "flags is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t E = (size_t)a->G * a->M;
+    MHPin h, d;
+    if (mh_pin_get(c, E, h, d)) return 1;
+    memcpy(h.U, a->U, E * 8);
+    memcpy(h.u, a->u, E * 8);
+    memcpy(h.sd_idx, a->sd_idx, E * 4);
+    memcpy(h.theta, a->old_theta, E * 4);
+    if (int rc = mh_screen_launch(c, counts_src, a, d)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(flags, h.flags, E);
+    return 0;
+}
+
+// bnpc_mh_batch with the device screen in front (include/bnpc_hip.h)
+extern "C" int bnpc_mh_batch_dev(bnpc_ctx *c, const bnpc_host_kernels *k,
+                                 bnpc_mt19937 *rng, const bnpc_mh_args *a,
+                                 int counts_src, int *status)
+{
+    ARGCHK(c && a && status, "NULL argument");
+    if (a->trans_prob || !c->tun.mh_screen || a->screen
+        || a->G * a->M < c->tun.mh_screen_min)
+        return bnpc_mh_batch(k, rng, a, status);
+    if (int rc = mh_screen_argchk(c, a)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t E = (size_t)a->G * a->M;
+    MHPin h, d;
+    if (mh_pin_get(c, E, h, d)) return 1;
+    if (rng) {
+        if (int rc = bnpc_mt_mh_draws(rng, a->G, a->M, a->n_sd, h.sd_idx, h.U,
+                                      h.u))
+            return rc;
+    } else {
+        memcpy(h.U, a->U, E * 8);
+        memcpy(h.u, a->u, E * 8);
+        memcpy(h.sd_idx, a->sd_idx, E * 4);
+    }
+    memcpy(h.theta, a->old_theta, E * 4);
+    SideLane lane(c);
+    if (int rc = mh_screen_launch(c, counts_src, a, d)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bnpc_mh_args b = *a;
+    b.sd_idx = h.sd_idx;
+    b.U = h.U;
+    b.u = h.u;
+    b.screen = h.flags;
+    int rc = bnpc_mh_batch(k, nullptr, &b, status);
+    if (rc) return rc;
+    int64_t kept = 0;
+    for (size_t i = 0; i < E; i++) kept += h.flags[i] != 0;
+    c->screened += (int64_t)E;
+    c->screen_kept += kept;
+    if (*status != 0) {
+        // the caller's view of the draws (the SciPy-level twin evaluates the
+        // batch from them when the library hands an element back)
+        memcpy(a->sd_idx, h.sd_idx, E * 4);
+        memcpy(a->U, h.U, E * 8);
+        memcpy(a->u, h.u, E * 8);
+    }
+    return 0;
+}
+
+extern "C" int bnpc_mh_screen_stats(bnpc_ctx *c, int64_t *screened,
+                                    int64_t *kept)
+{
+    ARGCHK(c && screened && kept, "NULL argument");
+    *screened = c->screened;
+    *kept = c->screen_kept;
     return 0;
 }
 

@@ -816,5 +816,7 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
             n1[2 * M + m] = n1[m] + n1[M + m];
             n0[2 * M + m] = n0[m] + n0[M + m];
         }
-    return bnpc_mh_batch(k, rng, mh, status);
+    // (the device screens the rows of an unscored scan against the counts it
+    // has just made: the host evaluates what is left)
+    return bnpc_mh_batch_dev(ctx, k, rng, mh, 1, status);
 }

@@ -901,8 +901,11 @@ class CRP:
         lab = self._label_counts()
         ids = lab['ids']
         old = self.parameters[ids]
+        # (the device holds these very counts: it screens the batch and the
+        # host evaluates only the proposals it cannot rule out)
         new, _, declined = self._mh_batch(old, (lab['n1'], lab['n0']), False,
-            known=self._known_prior(ids), keep_prior=ids)
+            known=self._known_prior(ids), keep_prior=ids,
+            device=(self._dev(), 0))
         self.parameters[ids] = new
         return declined.sum(), (self.muts_total - declined).sum()
 
@@ -958,7 +961,7 @@ class CRP:
         return np.cumsum(density.ravel())[-1]
 
     def _mh_batch(self, old, counts, trans_prob, known=None, keep_prior=None,
-                draws=None):
+                draws=None, device=None):
         """MH_cluster_params (libs/CRP.py:314-344) for G clusters at once.
 
         old: (G, M) float32; counts: (n1, n0) each (G, M).  RNG order per
@@ -976,7 +979,9 @@ class CRP:
             status, new, prob, declined, prior, draws = _lib.mh_batch(
                 table, old, n1, n0, self.param_proposal_sd, TMIN, TMAX,
                 self.FP, self.FN, self.p, self.q, self.beta_prior_uniform,
-                trans_prob, known=known, want_prior=keep_prior is not None)
+                trans_prob, known=known, want_prior=keep_prior is not None,
+                ctx=device[0] if device else None,
+                counts_src=device[1] if device else 0)
             if status == 0:
                 if keep_prior is not None and prior is not None:
                     self._remember_prior(keep_prior, new, prior)

@@ -385,6 +385,11 @@ typedef struct bnpc_mh_args {
     double *log_prob;           /* G: sum of A in index order (trans_prob) */
     int64_t *declined;          /* G */
     int threads;                /* <= 1: the calling thread only */
+    /* optional verdicts of the device screen (bnpc_mh_screen), G x M bytes:
+     * 0 = declined for certain (the element keeps old_theta and is not
+     * evaluated), anything else = evaluate.  Needs rng == NULL (the screen
+     * saw the draws) and trans_prob == 0 (scored batches need every A). */
+    const uint8_t *screen;
 } bnpc_mh_args;
 
 /* *status = 0: done.  *status = 1: the draws were taken (sd_idx, U, u are
@@ -394,6 +399,32 @@ typedef struct bnpc_mh_args {
  * rng == NULL: the caller has filled sd_idx / U / u already. */
 int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                   const bnpc_mh_args *a, int *status);
+
+/* The device screen of a parameter batch (libs/CRP.py:314-383, decision
+ * only): flags[g, m] = 0 where the proposal of element (g, m) is declined
+ * FOR CERTAIN - its log acceptance ratio, evaluated on the device in plain
+ * float64 with an explicit bound on everything that can separate it from the
+ * host's SciPy-exact value, lies below log(u) - and 1 where the host has to
+ * evaluate the element (likely accepted, in doubt, or on a branch the kernel
+ * does not model).  The counts come from the device: counts_src 0 = the
+ * resident per-cluster counts of the last bnpc_colcounts_by_label (G = its
+ * K), 1 = the two segments of the last bnpc_view_counts (G = 2, or 3 with
+ * row 2 = their sum: the merged cluster of a restricted scan).  a->sd_idx /
+ * U / u hold the draws; a->trans_prob must be 0. */
+int bnpc_mh_screen(bnpc_ctx *ctx, int counts_src, const bnpc_mh_args *a,
+                   uint8_t *flags);
+/* bnpc_mh_batch with that screen in front: the draws are taken (rng != NULL)
+ * straight into pinned memory, the device screens them against the resident
+ * counts, the host evaluates what is left (a few per cent) exactly as
+ * bnpc_mh_batch does - same results bit for bit, a tenth of the host work.
+ * Scored batches (trans_prob), small ones and BNPC_MH_SCREEN=0 go to
+ * bnpc_mh_batch directly.  On return the caller's sd_idx / U / u hold the
+ * draws. */
+int bnpc_mh_batch_dev(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                      bnpc_mt19937 *rng, const bnpc_mh_args *a,
+                      int counts_src, int *status);
+/* elements screened so far on this context / of those, left to the host */
+int bnpc_mh_screen_stats(bnpc_ctx *ctx, int64_t *screened, int64_t *kept);
 
 /* CRP._get_log_A (libs/CRP.py:347-383) for GIVEN rows: the log acceptance
  * ratio of moving old -> new under proposal standard deviations std, forward

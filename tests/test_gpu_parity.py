@@ -936,3 +936,113 @@ def test_fused_restricted_scan_changes_nothing(monkeypatch):
         np.testing.assert_allclose(r['ML'], ro['ML'], rtol=1e-9)
         assert np.array_equal(r['params'], ro['params'])
     assert np.array_equal(runs[0]['ML'], runs[1]['ML'])
+
+
+# ------------------------------------------- device screen of the MH batches
+def _screen_case(rng, ctx, data, K, theta_mode, prior, FP, FN, u_mode):
+    """One batch: K clusters by label on `data`, old parameters by mode, the
+    exact decisions from the SciPy-level arithmetic (CRP._mh_math)."""
+    N, M = data.shape
+    assign = rng.randint(0, K, N)
+    assign[:K] = np.arange(K)
+    n1, n0 = ctx.colcounts_by_label(assign, np.arange(K))
+    if theta_mode == 'uniform':
+        old = rng.uniform(size=(K, M))
+    elif theta_mode == 'posterior':     # where a converged chain sits
+        old = (n1 + .25) / (n1 + n0 + .5) + rng.normal(size=(K, M)) * 0.01
+    else:                               # 'edges': at and next to the bounds
+        old = rng.choice([P.TMIN, P.TMAX, 2e-5, 1 - 2e-5, 1e-4, .5], (K, M))
+    old = np.clip(old, P.TMIN, P.TMAX).astype(np.float32)
+    sd = np.array([0.1, 0.25, 0.5])
+    sd_idx = rng.randint(0, 3, (K, M)).astype(np.int32)
+    U = rng.uniform(size=(K, M))
+    u = rng.uniform(size=(K, M))
+    probe = P.CRP.__new__(P.CRP)
+    probe.param_proposal_sd = sd
+    probe.p, probe.q = prior
+    probe.beta_prior_uniform = bool(prior[0] == prior[1] == 1)
+    probe.FP, probe.FN = FP, FN
+    std = sd[sd_idx]
+
+    def exact(u_):
+        with np.errstate(all='ignore'):
+            return probe._mh_math(old, std, U, u_, n1, n0, False, None)
+    new, A, decline, _ = exact(u)
+    if u_mode == 'knife':
+        # the uniform that sits ON the decision: exp(A) nudged both ways
+        with np.errstate(all='ignore'):
+            near = np.exp(np.clip(A, -700, -1e-300))
+        eps = rng.choice([1e-15, 1e-12, 1e-9, 1e-6], (K, M)) \
+            * rng.choice([-1, 1], (K, M))
+        u = np.clip(near * (1 + eps), 1e-300, 1 - 1e-16)
+        new, A, decline, _ = exact(u)
+    flags = ctx.mh_screen(0, old, sd, (sd_idx, U, u), P.TMIN, P.TMAX, FP, FN,
+        prior[0], prior[1], probe.beta_prior_uniform)
+    return flags, decline, A, u
+
+
+def test_mh_screen_never_rules_out_a_proposal_the_exact_arithmetic_accepts():
+    """k_mh_screen (flag 0 = declined for certain) against the SciPy-level
+    arithmetic on batches a chain meets and on adversarial ones: clusters of
+    a few to thousands of cells, parameters drawn uniformly / sitting at
+    their posterior / on the truncation bounds, both priors, mild and
+    extreme error rates, and uniforms placed within 1e-15 .. 1e-6 of the
+    decision itself.  Every flag-0 element is declined by the exact path;
+    away from the knife edge the screen rules out nearly all declined ones."""
+    rng = np.random.RandomState(77)
+    data = H.synth(4, 3000, 257, 5, 0.2)
+    ctx = _lib.Context(data=data)
+    ruled, declined_total = 0, 0
+    try:
+        for K in (2, 9, 40):
+            for theta_mode in ('uniform', 'posterior', 'edges'):
+                for prior in ((.25, .25), (1, 1), (.75, 2.)):
+                    for FP, FN in ((.01, .2), (1e-4, .45), (.3, 1e-3)):
+                        for u_mode in ('random', 'knife'):
+                            flags, decline, A, u = _screen_case(rng, ctx,
+                                data, K, theta_mode, prior, FP, FN, u_mode)
+                            bad = (flags == 0) & ~decline
+                            assert not bad.any(), (K, theta_mode, prior, FP,
+                                FN, u_mode, np.argwhere(bad)[:3])
+                            if u_mode == 'random':
+                                ruled += int((flags == 0).sum())
+                                declined_total += int(decline.sum())
+        assert ruled > 0.97 * declined_total, (ruled, declined_total)
+    finally:
+        ctx.close()
+
+
+def test_screened_batch_on_the_device_equals_the_plain_batch():
+    """_lib.mh_batch through bnpc_mh_batch_dev (draws into pinned memory ->
+    k_mh_screen against the resident counts -> exact arithmetic on what is
+    left) against the plain host batch from the same stream position: same
+    parameters, declined counts, prior densities, stream position; the
+    screen leaves the host a small share of the batch."""
+    table = P._native_kernels()
+    if table is None:
+        pytest.skip('native parameter batch not available')
+    rng = np.random.RandomState(5)
+    data = H.synth(2, 2000, 300, 6, 0.2)
+    ctx = _lib.Context(data=data)
+    try:
+        K = 7
+        assign = rng.randint(0, K, 2000)
+        n1, n0 = ctx.colcounts_by_label(assign, np.arange(K))
+        old = np.clip((n1 + .25) / (n1 + n0 + .5), P.TMIN, P.TMAX) \
+            .astype(np.float32)
+        sd = np.array([0.1, 0.25, 0.5])
+        outs = []
+        for dev in (None, ctx):
+            np.random.seed(11)
+            outs.append(_lib.mh_batch(table, old, n1, n0, sd, P.TMIN, P.TMAX,
+                .01, .2, .25, .25, False, False, want_prior=True, ctx=dev,
+                counts_src=0) + (np.random.random(),))
+        a, b = outs
+        assert a[0] == b[0] == 0
+        for i in (1, 3, 4):
+            assert np.array_equal(a[i], b[i]), i
+        assert a[6] == b[6]
+        seen, kept = ctx.mh_screen_stats()
+        assert seen == K * 300 and kept < 0.4 * seen, (seen, kept)
+    finally:
+        ctx.close()

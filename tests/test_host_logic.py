@@ -756,3 +756,73 @@ def test_given_row_acceptance_ratios_equal_the_array_path(monkeypatch):
         assert np.array_equal(m._log_A_sum(new, old, std, counts, fmin, fmax),
             want)
     P._NATIVE.clear()
+
+
+def test_screened_parameter_batch_equals_the_plain_batch():
+    """bnpc_mh_batch with screen verdicts (include/bnpc_hip.h: 0 = declined
+    for certain): any screen that only rules out proposals the exact
+    arithmetic declines gives the plain batch's results bit for bit - new
+    parameters, declined counts, the prior densities of the result with and
+    without the prior cache - whatever subset it rules out (none, some, all
+    of the declined ones), on 1 and 3 threads."""
+    table = P._native_kernels()
+    if table is None:
+        pytest.skip('native parameter batch not available')
+    rng = np.random.RandomState(12)
+    G, M = 4, 333
+    sd = np.array([0.1, 0.25, 0.5])
+    for (p, q), uniform in (((.25, .25), False), ((1, 1), True)):
+        old = np.clip(rng.uniform(size=(G, M)), P.TMIN, P.TMAX) \
+            .astype(np.float32)
+        n1 = rng.randint(0, 40, (G, M)).astype(np.int32)
+        n0 = rng.randint(0, 40, (G, M)).astype(np.int32)
+        draws = (rng.randint(0, 3, (G, M)).astype(np.int32),
+            rng.uniform(size=(G, M)), rng.uniform(size=(G, M)))
+        known = None
+        if not uniform:
+            from bnpc_amd import fastdist
+            known = (old.copy(), fastdist.beta_logpdf(old, p, q))
+            known[0][:, ::3] = np.float32(0.321)    # a third are misses
+        plain = _lib.mh_batch(table, old, n1, n0, sd, P.TMIN, P.TMAX, .01, .2,
+            p, q, uniform, False, known=known, want_prior=True, draws=draws,
+            threads=1)
+        assert plain[0] == 0
+        declined = plain[1].view(np.int32) == old.view(np.int32)
+        assert 0 < declined.sum() < G * M
+        for frac in (0.0, 0.6, 1.0):
+            screen = np.ones((G, M), dtype=np.uint8)
+            screen[declined & (rng.uniform(size=(G, M)) < frac)] = 0
+            for threads in (1, 3):
+                a = _lib.MHArgs()
+                new = np.empty((G, M), np.float32)
+                prior = np.empty((G, M))
+                A = np.empty((G, M))
+                lp, dec = np.empty(G), np.empty(G, np.int64)
+                a.G, a.M = G, M
+                a.old_theta, a.n1, a.n0 = (x.ctypes.data
+                    for x in (old, n1, n0))
+                a.sd, a.n_sd = sd.ctypes.data, 3
+                a.tmin, a.tmax, a.FP, a.FN = P.TMIN, P.TMAX, .01, .2
+                a.p, a.q, a.uniform_prior, a.trans_prob = p, q, int(uniform), 0
+                if known is not None:
+                    a.known_theta = known[0].ctypes.data
+                    a.known_prior = known[1].ctypes.data
+                a.sd_idx, a.U, a.u = (x.ctypes.data for x in draws)
+                a.new_theta, a.A = new.ctypes.data, A.ctypes.data
+                a.prior_out = None if uniform else prior.ctypes.data
+                a.log_prob, a.declined = lp.ctypes.data, dec.ctypes.data
+                a.threads = threads
+                a.screen = screen.ctypes.data
+                status = C.c_int(0)
+                _lib.check(_lib.load().bnpc_mh_batch(C.addressof(table), None,
+                    C.byref(a), C.byref(status)), 'mh_batch')
+                assert status.value == 0
+                assert np.array_equal(new, plain[1])
+                assert np.array_equal(dec, plain[3])
+                if not uniform:
+                    assert np.array_equal(prior, plain[4])
+    # a screened batch cannot take draws itself, nor be scored
+    a.trans_prob = 0
+    st, _ = _lib.rng_export()
+    assert _lib.load().bnpc_mh_batch(C.addressof(table), C.byref(st),
+        C.byref(a), C.byref(status)) != 0
