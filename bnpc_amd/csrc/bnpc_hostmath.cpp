@@ -315,9 +315,12 @@ inline double beta_logpdf1(const bnpc_host_kernels *k, float x32, double p,
 
 // n elements of cluster g - positions idx[0..n) of its row, or, idx == NULL,
 // the run [m0, m0 + n); false: an element needs SciPy's own path
+// accept_known: the device screen has established that these proposals are
+// accepted (include/bnpc_hip.h, screen == 2): the proposal's bits and the
+// prior density of the result are all that is evaluated
 bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
               const Consts &c, int64_t g, const int32_t *idx, int64_t m0,
-              int n)
+              int n, bool accept_known = false)
 {
     const size_t row = (size_t)g * a->M;
     // gathered inputs (a dense run is gathered too: one code path)
@@ -386,6 +389,17 @@ bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
         if (!(lo[i] < 0.0)) x = -x;
         x = x * std_[i] + (double)old[i];
         nw[i] = (float)x;                                   // astype(float32)
+    }
+    if (accept_known) {
+        float *out = a->new_theta + row;
+        double *prior_out = a->prior_out ? a->prior_out + row : nullptr;
+        for (int i = 0; i < n; i++) {
+            out[at[i]] = nw[i];
+            if (prior_out)
+                prior_out[at[i]] = a->uniform_prior ? 0.0
+                    : beta_logpdf1(k, nw[i], a->p, a->q, c.betaln_pq);
+        }
+        return true;
     }
 
     // forward and reverse proposal log-densities (truncnorm._logpdf around
@@ -550,11 +564,13 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             bnpc_set_error("bad argument: a screened batch brings its draws");
             return 2;
         }
-        static thread_local std::vector<int32_t> todo, miss;
-        static thread_local std::vector<int64_t> todo_at, miss_at;
+        static thread_local std::vector<int32_t> todo, sure, miss;
+        static thread_local std::vector<int64_t> todo_at, sure_at, miss_at;
         todo.clear();
+        sure.clear();
         miss.clear();
         todo_at.assign(G + 1, 0);
+        sure_at.assign(G + 1, 0);
         miss_at.assign(G + 1, 0);
         const bool want_prior = a->prior_out && !a->uniform_prior;
         for (int64_t g = 0; g < G; g++) {
@@ -565,7 +581,7 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             int64_t kept = 0;
             for (int64_t m = 0; m < M; m++) {
                 if (sc[m]) {
-                    todo.push_back((int32_t)m);
+                    (sc[m] == 2 ? sure : todo).push_back((int32_t)m);
                     continue;
                 }
                 kept++;
@@ -584,30 +600,37 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                     if (!sc[m]) a->prior_out[row + m] = 0.0;
             a->declined[g] = kept;
             todo_at[g + 1] = (int64_t)todo.size();
+            sure_at[g + 1] = (int64_t)sure.size();
             miss_at[g + 1] = (int64_t)miss.size();
         }
         // tasks: runs of <= 64 flagged elements of one row, then runs of
         // <= 256 prior-cache misses of one row
         struct Task {
             int64_t g, lo, hi;
-            bool prior;
+            int kind;           // 0 in doubt, 1 accepted for certain, 2 prior
         };
         static thread_local std::vector<Task> tasks;
         tasks.clear();
         for (int64_t g = 0; g < G; g++)
             for (int64_t lo = todo_at[g]; lo < todo_at[g + 1]; lo += BLK / 2)
                 tasks.push_back({g, lo, std::min(lo + BLK / 2,
-                                                 todo_at[g + 1]), false});
+                                                 todo_at[g + 1]), 0});
+        for (int64_t g = 0; g < G; g++)
+            for (int64_t lo = sure_at[g]; lo < sure_at[g + 1]; lo += BLK / 2)
+                tasks.push_back({g, lo, std::min(lo + BLK / 2,
+                                                 sure_at[g + 1]), 1});
         for (int64_t g = 0; g < G; g++)
             for (int64_t lo = miss_at[g]; lo < miss_at[g + 1]; lo += 2 * BLK)
                 tasks.push_back({g, lo, std::min(lo + 2 * BLK,
-                                                 miss_at[g + 1]), true});
+                                                 miss_at[g + 1]), 2});
         const int64_t n_tasks = (int64_t)tasks.size();
         const Task *tk = tasks.data();
         const int32_t *todo_p = todo.data(), *miss_p = miss.data();
-        // a thread per ~8 tasks: waking the team costs more than a few
-        // hundred elements
-        if (threads > (n_tasks + 7) / 8) threads = (int)((n_tasks + 7) / 8);
+        const int32_t *sure_p = sure.data();
+        // a thread per ~12 tasks: waking a parked team costs more than
+        // several hundred elements
+        if (threads > (n_tasks + 11) / 12)
+            threads = (int)((n_tasks + 11) / 12);
         if (threads < 1) threads = 1;
         std::atomic<int64_t> next(0);
         auto work = [&](int) {
@@ -616,15 +639,16 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 if (t >= n_tasks) break;
                 if (bail.load(std::memory_order_relaxed)) continue;
                 const Task &q = tk[t];
-                if (q.prior) {
+                if (q.kind == 2) {
                     const size_t row = (size_t)q.g * M;
                     for (int64_t j = q.lo; j < q.hi; j++) {
                         const int32_t m = miss_p[j];
                         a->prior_out[row + m] = beta_logpdf1(k,
                             a->old_theta[row + m], a->p, a->q, c.betaln_pq);
                     }
-                } else if (!mh_block(k, a, c, q.g, todo_p + q.lo, 0,
-                                     (int)(q.hi - q.lo))) {
+                } else if (!mh_block(k, a, c, q.g,
+                                     (q.kind ? sure_p : todo_p) + q.lo, 0,
+                                     (int)(q.hi - q.lo), q.kind == 1)) {
                     bail.store(1, std::memory_order_relaxed);
                 }
             }
@@ -634,9 +658,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         else
             work(0);
         if (trace)
-            fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld of %lld "
-                    "elements exact, %lld prior misses, threads=%d, %.1f us\n",
+            fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld in doubt, "
+                    "%lld accepted of %lld elements, %lld prior misses, "
+                    "threads=%d, %.1f us\n",
                     (long long)G, (long long)M, (long long)todo.size(),
+                    (long long)sure.size(),
                     (long long)(G * M), (long long)miss.size(), threads,
                     since() / 1e3);
         if (bail.load()) {

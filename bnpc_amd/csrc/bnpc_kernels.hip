@@ -30,6 +30,7 @@
 #include <string.h>
 #include <math.h>
 #include <sys/mman.h>
+#include <time.h>
 #include <mutex>
 #include <vector>
 #include <algorithm>
@@ -188,6 +189,7 @@ struct bnpc_ctx {
     void *mh_pin = nullptr;
     char *mh_dev = nullptr;
     size_t mh_cap = 0;
+    hipEvent_t mh_ev[2] = {};
     int64_t screened = 0, screen_kept = 0;  // elements seen / left to the host
     size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
     bool total_pending = false;     // a deferred bnpc_ll_total_issue
@@ -1484,10 +1486,13 @@ __global__ __launch_bounds__(256) void k_ll_total(
 //     (1-t), truncation mass: 1 / (sd Z));
 //   * rounding of the sums: 1e-12 of the terms' magnitudes, + 1e-7.
 // An element whose log(u) exceeds A by more than that is flagged 0: declined
-// whatever the exact arithmetic says.  Everything else - likely accepted, in
+// whatever the exact arithmetic says; one whose A exceeds log(u) by more than
+// that is flagged 2: accepted for certain - the host still has to produce the
+// proposal's exact bits (SciPy's ppf) and its prior density, but none of the
+// acceptance ratio's terms.  Everything else - in
 // doubt, or on a branch this kernel does not model (an interval that does
 // not straddle zero, a proposal within ulps of the truncation bounds, a draw
-// that is exactly 0) - is flagged 1 and evaluated by the host exactly as
+// that is exactly 0) - is flagged 1 and evaluated by the host in full, exactly as
 // before.  The chain's bits do not change (tests: screen vs exact decisions
 // on random and adversarial batches; every chain test runs through it).
 // rev - fwd = log Z(old) - log Z(new): the quadratic terms are equal because
@@ -1569,9 +1574,11 @@ __global__ __launch_bounds__(256) void k_mh_screen(
                 const double margin = sens * dtheta + 1e-7
                     + 1e-12 * (fabs(lln) + fabs(llo) + fabs(prn) + fabs(pro));
                 const double gap = log(ui) - A;
-                if (Z > 0.0 && Zr > 0.0 && gap == gap && gap > margin
-                    && gap < INFINITY)
-                    flag = 0;
+                if (Z > 0.0 && Zr > 0.0 && gap == gap && gap < INFINITY
+                    && gap > -INFINITY) {
+                    if (gap > margin) flag = 0;         // declined for certain
+                    else if (-gap > margin) flag = 2;   // accepted for certain
+                }
             }
         }
     }
@@ -1777,6 +1784,8 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
     if (c->mh_pin) (void)hipHostFree(c->mh_pin);
+    for (int p = 0; p < 2; p++)
+        if (c->mh_ev[p]) (void)hipEventDestroy(c->mh_ev[p]);
     for (int s = 0; s < BNPC_TILE_SLOTS; s++) {
         pinned_free(c->tile_pin[s], c->tile_cap[s]);
         pinned_free(c->tile_rows[s], c->tile_rows_cap[s]);
@@ -2899,12 +2908,17 @@ static int mh_counts(bnpc_ctx *c, int src, int64_t G, const int **n1,
     return 0;
 }
 
+// rows [g0, g0 + Gp) of the batch
 static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
-                            const MHPin &dev)
+                            const MHPin &dev, int64_t g0 = 0, int64_t Gp = -1)
 {
     const int *n1, *n0;
     int sum_row;
     if (int rc = mh_counts(c, src, a->G, &n1, &n0, &sum_row)) return rc;
+    if (Gp < 0) Gp = a->G;
+    const size_t at = (size_t)g0 * a->M;
+    ARGCHK(sum_row < 0 || (g0 == 0 && Gp == a->G),
+           "a batch with a summed row is screened whole");
     MHScreenConst k;
     for (int i = 0; i < 8; i++) k.sd[i] = i < a->n_sd ? a->sd[i] : 1.0;
     k.FP = a->FP;
@@ -2914,10 +2928,11 @@ static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
     k.tmin32 = (float)a->tmin;
     k.tmax32 = (float)a->tmax;
     k.uniform_prior = a->uniform_prior;
-    const long long GM = (long long)a->G * a->M;
+    const long long GM = (long long)Gp * a->M;
     hipLaunchKernelGGL(k_mh_screen, dim3((unsigned)((GM + 255) / 256)),
-                       dim3(256), 0, c->stream, dev.theta, n1, n0, dev.sd_idx,
-                       dev.U, dev.u, GM, (int)a->M, sum_row, k, dev.flags);
+                       dim3(256), 0, c->stream, dev.theta + at, n1 + at,
+                       n0 + at, dev.sd_idx + at, dev.U + at, dev.u + at, GM,
+                       (int)a->M, sum_row, k, dev.flags + at);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2963,33 +2978,87 @@ extern "C" int bnpc_mh_batch_dev(bnpc_ctx *c, const bnpc_host_kernels *k,
         return bnpc_mh_batch(k, rng, a, status);
     if (int rc = mh_screen_argchk(c, a)) return rc;
     HIPCHK(hipSetDevice(c->device));
-    const size_t E = (size_t)a->G * a->M;
+    static const bool trace = getenv("BNPC_MH_TRACE") != nullptr;
+    timespec ts0, ts1;
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
+    const int64_t G = a->G, M = a->M;
+    const size_t E = (size_t)G * M;
     MHPin h, d;
     if (mh_pin_get(c, E, h, d)) return 1;
-    if (rng) {
-        if (int rc = bnpc_mt_mh_draws(rng, a->G, a->M, a->n_sd, h.sd_idx, h.U,
-                                      h.u))
-            return rc;
-    } else {
-        memcpy(h.U, a->U, E * 8);
-        memcpy(h.u, a->u, E * 8);
-        memcpy(h.sd_idx, a->sd_idx, E * 4);
-    }
-    memcpy(h.theta, a->old_theta, E * 4);
+    // Two halves in a pipeline (batches of 4 rows and more): the draws of the
+    // second half are taken while the device screens the first, and the host
+    // evaluates what the first screen left while the second one runs.
+    const int parts = (G >= 4 && counts_src == 0) ? 2 : 1;
+    const int64_t cut[3] = {0, parts == 2 ? (G + 1) / 2 : G, G};
+    for (int p = 0; p < 2; p++)
+        if (!c->mh_ev[p])
+            HIPCHK(hipEventCreateWithFlags(&c->mh_ev[p],
+                                           hipEventDisableTiming));
     SideLane lane(c);
-    if (int rc = mh_screen_launch(c, counts_src, a, d)) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    bnpc_mh_args b = *a;
-    b.sd_idx = h.sd_idx;
-    b.U = h.U;
-    b.u = h.u;
-    b.screen = h.flags;
-    int rc = bnpc_mh_batch(k, nullptr, &b, status);
-    if (rc) return rc;
+    for (int p = 0; p < parts; p++) {
+        const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
+        const size_t at = (size_t)g0 * M, n = (size_t)Gp * M;
+        if (rng) {
+            if (int rc = bnpc_mt_mh_draws(rng, Gp, M, a->n_sd, h.sd_idx + at,
+                                          h.U + at, h.u + at))
+                return rc;
+        } else {
+            memcpy(h.U + at, a->U + at, n * 8);
+            memcpy(h.u + at, a->u + at, n * 8);
+            memcpy(h.sd_idx + at, a->sd_idx + at, n * 4);
+        }
+        memcpy(h.theta + at, a->old_theta + at, n * 4);
+        if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp)) return rc;
+        HIPCHK(hipEventRecord(c->mh_ev[p], c->stream));
+    }
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
     int64_t kept = 0;
-    for (size_t i = 0; i < E; i++) kept += h.flags[i] != 0;
+    *status = 0;
+    for (int p = 0; p < parts; p++) {
+        const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
+        const size_t at = (size_t)g0 * M;
+        HIPCHK(hipEventSynchronize(c->mh_ev[p]));
+        bnpc_mh_args b = *a;
+        b.G = Gp;
+        b.old_theta += at;
+        b.n1 += at;
+        b.n0 += at;
+        if (b.known_theta) {
+            b.known_theta += at;
+            b.known_prior += at;
+        }
+        b.sd_idx = h.sd_idx + at;
+        b.U = h.U + at;
+        b.u = h.u + at;
+        b.new_theta += at;
+        if (b.prior_out) b.prior_out += at;
+        b.A += at;
+        b.log_prob += g0;
+        b.declined += g0;
+        b.screen = h.flags + at;
+        int st = 0;
+        int rc = bnpc_mh_batch(k, nullptr, &b, &st);
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+        if (st) *status = 1;
+        for (size_t i = 0; i < (size_t)Gp * M; i++)
+            kept += h.flags[at + i] != 0;
+    }
     c->screened += (int64_t)E;
     c->screen_kept += kept;
+    if (trace) {
+        timespec ts3;
+        clock_gettime(CLOCK_MONOTONIC, &ts3);
+        auto us = [](const timespec &x, const timespec &y) {
+            return (y.tv_sec - x.tv_sec) * 1e6 + (y.tv_nsec - x.tv_nsec) / 1e3;
+        };
+        fprintf(stderr, "[mh_batch_dev] %lld x %lld in %d part(s): draws + "
+                "staging + launches %.1f us, waits + host %.1f us (%lld left)\n",
+                (long long)G, (long long)M, parts, us(ts0, ts1), us(ts1, ts3),
+                (long long)kept);
+    }
     if (*status != 0) {
         // the caller's view of the draws (the SciPy-level twin evaluates the
         // batch from them when the library hands an element back)

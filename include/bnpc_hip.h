@@ -387,7 +387,8 @@ typedef struct bnpc_mh_args {
     int threads;                /* <= 1: the calling thread only */
     /* optional verdicts of the device screen (bnpc_mh_screen), G x M bytes:
      * 0 = declined for certain (the element keeps old_theta and is not
-     * evaluated), anything else = evaluate.  Needs rng == NULL (the screen
+     * evaluated), 2 = accepted for certain (only the proposal's bits and
+     * its prior density are evaluated), anything else = evaluate in full.  Needs rng == NULL (the screen
      * saw the draws) and trans_prob == 0 (scored batches need every A). */
     const uint8_t *screen;
 } bnpc_mh_args;
@@ -404,9 +405,10 @@ int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
  * only): flags[g, m] = 0 where the proposal of element (g, m) is declined
  * FOR CERTAIN - its log acceptance ratio, evaluated on the device in plain
  * float64 with an explicit bound on everything that can separate it from the
- * host's SciPy-exact value, lies below log(u) - and 1 where the host has to
- * evaluate the element (likely accepted, in doubt, or on a branch the kernel
- * does not model).  The counts come from the device: counts_src 0 = the
+ * host's SciPy-exact value, lies below log(u) - 2 where it is accepted for
+ * certain (the same bound the other way), and 1 where the host has to
+ * evaluate the element in full (in doubt, or on a branch the kernel does not
+ * model).  The counts come from the device: counts_src 0 = the
  * resident per-cluster counts of the last bnpc_colcounts_by_label (G = its
  * K), 1 = the two segments of the last bnpc_view_counts (G = 2, or 3 with
  * row 2 = their sum: the merged cluster of a restricted scan).  a->sd_idx /

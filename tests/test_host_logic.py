@@ -792,6 +792,8 @@ def test_screened_parameter_batch_equals_the_plain_batch():
         for frac in (0.0, 0.6, 1.0):
             screen = np.ones((G, M), dtype=np.uint8)
             screen[declined & (rng.uniform(size=(G, M)) < frac)] = 0
+            # ... and "accepted for certain" for some of the accepted ones
+            screen[~declined & (rng.uniform(size=(G, M)) < frac)] = 2
             for threads in (1, 3):
                 a = _lib.MHArgs()
                 new = np.empty((G, M), np.float32)

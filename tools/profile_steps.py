@@ -44,6 +44,25 @@ for n in names:
         return inner
     setattr(model, n, wrap())
 
+# wall time inside every entry point of the library (ctypes drops into C:
+# cProfile books that time on the calling Python function)
+from bnpc_amd import _lib  # noqa: E402
+lib = _lib.load()
+c_acc = {}
+for name in _lib.SIGNATURES:
+    if name == 'bnpc_matrix_wait':      # its address goes to the C loop
+        continue
+    fn = getattr(lib, name)
+
+    def timed(*a, _fn=fn, _n=name):
+        t0 = time.perf_counter()
+        r = _fn(*a)
+        e = c_acc.setdefault(_n, [0.0, 0])
+        e[0] += time.perf_counter() - t0
+        e[1] += 1
+        return r
+    setattr(lib, name, timed)
+
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
@@ -57,6 +76,14 @@ for n, (t, c) in acc.items():
     if c:
         print(f'  {n:34s} calls {c:4d}  total {1e3 * t:8.1f} ms  '
             f'per call {1e3 * t / c:7.2f} ms  per step {1e3 * t / steps:6.2f}')
+print('  -- inside the library, per entry point --')
+tot = 0.0
+for n, (t, c) in sorted(c_acc.items(), key=lambda kv: -kv[1][0]):
+    tot += t
+    print(f'  {n:34s} calls {c:5d}  total {1e3 * t:8.1f} ms  '
+        f'per call {1e6 * t / c:7.1f} us  per step {1e3 * t / steps:6.3f}')
+print(f'  library total {1e3 * tot / steps:.3f} ms/step, everything else '
+    f'{1e3 * (el - tot) / steps:.3f} ms/step')
 if len(sys.argv) > 3:
     pr.dump_stats(sys.argv[3])
 st = pstats.Stats(pr)
