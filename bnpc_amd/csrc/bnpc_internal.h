@@ -20,6 +20,13 @@ int bnpc_team_ranks(int threads);
 int bnpc_team_run(int threads, const std::function<void(int)> &fn);
 #endif
 
+// bnpc_kernels.hip: counts of the two launch clusters of a restricted scan +
+// the (screened) parameter batch on one stream synchronisation
+int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
+                             bnpc_mt19937 *rng, int view,
+                             const int64_t *labels, const bnpc_mh_args *a,
+                             int32_t *n1, int32_t *n0, int *status);
+
 // ---------------------------------------------------------------------------
 // MT19937 (Matsumoto & Nishimura), state layout of np.random.get_state()
 // ---------------------------------------------------------------------------

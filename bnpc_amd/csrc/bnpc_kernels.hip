@@ -2646,10 +2646,17 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
 // Column counts of G segments of a view from its lane masks (K3b).
 // label_of(s) = segment of slot s, or < 0 for none.  The counts land in `cnt`
 // on the device ([n1: G x M][n0: G x M]) and in n1 / n0 on the host.
+// `defer` (optional): if the results can be written in place into pinned
+// memory, return right after the launch - *defer receives where they will
+// appear, and the caller synchronises the stream and copies them out (it has
+// more work to put on the stream first); else *defer stays NULL and the
+// call completes here as usual.
 template <typename LabelOf>
 static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
-                             int64_t G, DevBuf &cnt, int32_t *n1, int32_t *n0)
+                             int64_t G, DevBuf &cnt, int32_t *n1, int32_t *n0,
+                             const int **defer = nullptr)
 {
+    if (defer) *defer = nullptr;
     const View &v = c->views[view];
     const size_t half = (size_t)G * c->M * sizeof(int32_t);
     if (ensure(cnt, 2 * half)) return 1;
@@ -2712,7 +2719,9 @@ static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.nblk, d_mem, (int)G, d1, d0, h1, h0);
     HIPCHK(hipGetLastError());
-    if (zc_host) {
+    if (zc_host && defer) {
+        *defer = zc_host;
+    } else if (zc_host) {
         HIPCHK(hipStreamSynchronize(c->stream));
         memcpy(n1, zc_host, half);
         memcpy(n0, zc_host + (size_t)G * c->M, half);
@@ -3062,6 +3071,76 @@ extern "C" int bnpc_mh_batch_dev(bnpc_ctx *c, const bnpc_host_kernels *k,
     if (*status != 0) {
         // the caller's view of the draws (the SciPy-level twin evaluates the
         // batch from them when the library hands an element back)
+        memcpy(a->sd_idx, h.sd_idx, E * 4);
+        memcpy(a->U, h.U, E * 8);
+        memcpy(a->u, h.u, E * 8);
+    }
+    return 0;
+}
+
+// The second half of a restricted-Gibbs scan (bnpc_rg_scan_step,
+// bnpc_sweeps.cpp) on ONE stream synchronisation: the column counts of the two
+// launch clusters for the new assignment (labels: one per slot of the view),
+// the draws of the parameter batch, its device screen - queued behind the
+// counts it reads - then the counts are copied out and the host evaluates what
+// the screen left.  Scored batches and contexts without the screen take the
+// two calls one after the other.
+int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
+                             bnpc_mt19937 *rng, int view,
+                             const int64_t *labels, const bnpc_mh_args *a,
+                             int32_t *n1, int32_t *n0, int *status)
+{
+    ARGCHK(c && a && labels && n1 && n0 && status && rng, "NULL argument");
+    const int64_t M = a->M;
+    auto finish_rows = [&]() {
+        if (a->G == 3)
+            for (int64_t m = 0; m < M; m++) {       // the merged cluster
+                n1[2 * M + m] = n1[m] + n1[M + m];
+                n0[2 * M + m] = n0[m] + n0[M + m];
+            }
+    };
+    const bool fused = !a->trans_prob && c->tun.mh_screen
+        && a->G * M >= c->tun.mh_screen_min && !c->any_tile_pending();
+    if (!fused) {
+        if (int rc = bnpc_view_counts(c, view, labels, 2, n1, n0)) return rc;
+        finish_rows();
+        return bnpc_mh_batch_dev(c, k, rng, a, 1, status);
+    }
+    if (int rc = mh_screen_argchk(c, a)) return rc;
+    ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
+    HIPCHK(hipSetDevice(c->device));
+    c->cnt_rows = 0;
+    const int *pending = nullptr;
+    if (int rc = counts_from_masks(c, view,
+            [=](int64_t s) -> int64_t { return labels[s]; }, 2, c->cnt, n1, n0,
+            &pending))
+        return rc;
+    c->cnt_rows = 2;
+    const size_t E = (size_t)a->G * M;
+    MHPin h, d;
+    if (mh_pin_get(c, E, h, d)) return 1;
+    if (int rc = bnpc_mt_mh_draws(rng, a->G, M, a->n_sd, h.sd_idx, h.U, h.u))
+        return rc;
+    memcpy(h.theta, a->old_theta, E * 4);
+    if (int rc = mh_screen_launch(c, 1, a, d)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (pending) {
+        const size_t half = (size_t)2 * M * sizeof(int32_t);
+        memcpy(n1, pending, half);
+        memcpy(n0, pending + (size_t)2 * M, half);
+    }
+    finish_rows();
+    bnpc_mh_args b = *a;
+    b.sd_idx = h.sd_idx;
+    b.U = h.U;
+    b.u = h.u;
+    b.screen = h.flags;
+    if (int rc = bnpc_mh_batch(k, nullptr, &b, status)) return rc;
+    int64_t kept = 0;
+    for (size_t i = 0; i < E; i++) kept += h.flags[i] != 0;
+    c->screened += (int64_t)E;
+    c->screen_kept += kept;
+    if (*status != 0) {
         memcpy(a->sd_idx, h.sd_idx, E * 4);
         memcpy(a->U, h.U, E * 8);
         memcpy(a->u, h.u, E * 8);

@@ -808,15 +808,11 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     labels[0] = 0;
     for (int64_t s = 0; s < S; s++) labels[s + 1] = rg_assignment[s] ? 1 : 0;
     labels[n - 1] = 1;
-    rc = bnpc_view_counts(ctx, view, labels.data(), 2, n1, n0);
-    if (rc) return rc;
     if (scan_log_prob) *scan_log_prob = log_prob;
-    if (mh->G == 3)
-        for (int64_t m = 0; m < M; m++) {       // the merged cluster
-            n1[2 * M + m] = n1[m] + n1[M + m];
-            n0[2 * M + m] = n0[m] + n0[M + m];
-        }
-    // (the device screens the rows of an unscored scan against the counts it
-    // has just made: the host evaluates what is left)
-    return bnpc_mh_batch_dev(ctx, k, rng, mh, 1, status);
+    // counts of the two launch clusters (the merged cluster's are their sum)
+    // and the parameter batch: the device counts, then screens the rows of an
+    // unscored scan against those counts, one wait for both; the host
+    // evaluates what the screen leaves
+    return bnpc_rg_counts_and_batch(ctx, k, rng, view, labels.data(), mh, n1,
+                                    n0, status);
 }

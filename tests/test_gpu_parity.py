@@ -702,6 +702,41 @@ def test_config5_moves_chain_matches_oracle():
     assert np.array_equal(ro['params'], rp['params'])
 
 
+def test_config5_steady_state_at_full_size_matches_oracle_fixture(golden_dir):
+    """Config 5 at FULL size (50000 x 5000, 20 % missing, learned errors,
+    -smp 0.5 -sms 5) in its steady state, step for step against the CPU
+    oracle (tests/golden/c5_schedule.py + make_c5_trajectory.py: 38 CPU
+    minutes): init(assign=near-truth labels), 6 scheduled steps (Gibbs sweeps
+    over 50 000 cells x ~50 clusters, parameter batches of 50 x 5000 entries
+    through the device screen, error-rate updates), a forced split and a
+    forced merge - restricted scans on views of 955 - 1972 cells x 5000
+    mutations, `k_counts_masks` with 50 segments, the 4-chunk split of
+    `k_ll8_asm`.  Identical assignments, restricted-Gibbs log (move, cells,
+    accepted), parameter rows (digests + a sample), stream position; traces
+    to 1e-9."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import bench
+    import c5_schedule as S
+    import libs.CRP_learning_errors as dev
+    t = np.load(os.path.join(golden_dir, 'c5_trajectory.npz'))
+    N, M, C_, miss, learned = bench.CONFIGS['c5']
+    data = H.synth(0, N, M, C_, miss)
+    res = S.drive(dev, data)
+    assert np.array_equal(res['moves'], t['moves'])
+    assert (res['moves'][:, 1] >= 900).all() and set(res['moves'][:, 0]) \
+        == {0, 1}
+    assert np.array_equal(res['assignments'], t['assignments'])
+    assert list(res['K']) == list(t['K'])
+    for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
+        np.testing.assert_allclose(res[key], t[key], rtol=1e-9, err_msg=key)
+    assert list(res['digest']) == list(t['digest'])
+    assert np.array_equal(
+        res['last_params'].ravel()[t['last_params_index']],
+        t['last_params_sample'])
+    assert res['stream_check'] == float(t['stream_check'])
+
+
 def test_first_sweep_at_config5_size_does_not_depend_on_the_tiling(
         monkeypatch):
     """The first sweep of config 5 at FULL size (50000 x 5000 from K0 ~ 31600

@@ -87,4 +87,4 @@ print(f'  library total {1e3 * tot / steps:.3f} ms/step, everything else '
 if len(sys.argv) > 3:
     pr.dump_stats(sys.argv[3])
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats("tottime").print_stats(45)
