@@ -20,7 +20,9 @@ collective in the data path); torch.distributed (gloo) is used only for the
 barrier and the max-reduction of the timings.
 
 roofline: the cells x clusters x mutations kernel (k_ll) at the workload's
-first-sweep shape, timed live with HIP events on the library's stream.
+first-sweep shape, timed live with HIP events on the library's stream; the
+binding roof is the FP64 vector pipe (bound "valu": N K M adds against
+39.3e12 adds/s), the HBM fraction rides along.
 cpu_baseline: the CPU oracle (NumPy restatement of the reference, 1 core)
 stepping from the SAME post-warm-up state, on rank 0 at N = 1 only.
 """
@@ -87,6 +89,57 @@ def new_chain(model, learned, total_steps, config=None):
 def step(chain, i, burn_in):
     chain.do_step()
     chain.update_results(i, i < burn_in)
+
+
+class MoveClock:
+    """Wall time of the timed window by move: light wrappers around the
+    model's move methods (the driver calls them through the instance), so
+    that windows of different lengths can be reconciled - what a step costs
+    depends on which moves it drew."""
+
+    MOVES = ('update_assignments_Gibbs', 'update_assignments_split_merge',
+        'update_DP_alpha', 'update_parameters', 'update_error_rates',
+        'get_lprior_full', 'get_ll_full_deferred')
+
+    def __init__(self, model):
+        self.acc = {}
+        self.on = False
+        for name in self.MOVES:
+            fn = getattr(model, name, None)
+            if fn is None:
+                continue
+
+            def timed(*a, _fn=fn, _n=name, **k):
+                if not self.on:
+                    return _fn(*a, **k)
+                t0 = time.perf_counter()
+                out = _fn(*a, **k)
+                dt = time.perf_counter() - t0
+                key = _n
+                if _n == 'update_assignments_split_merge':
+                    key = 'split' if out[1] == 0 else 'merge'
+                    key += '_accepted' if out[0][0] else '_rejected'
+                e = self.acc.setdefault(key, [0.0, 0])
+                e[0] += dt
+                e[1] += 1
+                return out
+            setattr(model, name, timed)
+
+    def report(self, steps, elapsed):
+        short = {'update_assignments_Gibbs': 'gibbs',
+            'update_DP_alpha': 'dp_alpha', 'update_parameters': 'parameters',
+            'update_error_rates': 'error_rates',
+            'get_lprior_full': 'record_prior',
+            'get_ll_full_deferred': 'record_ll_issue'}
+        out, total = {}, 0.0
+        for key, (t, n) in sorted(self.acc.items()):
+            out[short.get(key, key)] = {'calls': n,
+                'ms_per_call': round(1e3 * t / n, 4),
+                'ms_per_step': round(1e3 * t / steps, 4)}
+            total += t
+        out['other'] = {'ms_per_step':
+            round(1e3 * (elapsed - total) / steps, 4)}
+        return out
 
 
 class Ranks:
@@ -160,20 +213,25 @@ def timed_steps(ranks, step_fn, first, last):
 
 
 def load_pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units; the
-    fetch counter was calibrated on this kernel's scalar-load streams, see
-    profiles/r01/fetch_calibration.md), or None.  The counters cannot be read
-    from inside this process."""
-    for rel in (('profiles', 'r02', 'pmc_final.json'),
-            ('profiles', 'r01', 'pmc_v11_final.json')):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC
+    passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or None.
+    The counters cannot be read from inside this process.  gfx950 correction
+    (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-byte requests of a
+    wide coalesced read at 64 bytes; this kernel's misses are taken by its
+    16-byte-per-lane L2 prefetch stream (the scalar loads behind it hit), so
+    the fetch counter is doubled - which also reproduces the 68 MiB the same
+    launch fetched through scalar loads alone before the prefetch existed
+    (profiles/r03/README.md).  WRITE_SIZE is taken as it reads."""
+    for rel in (('profiles', 'r03', 'pmc_final.json'),
+            ('profiles', 'r02', 'pmc_final.json')):
         path = os.path.join(ROOT, *rel)
         try:
             with open(path) as f:
                 pmc = json.load(f)
             for name, ctr in pmc.items():
                 if kernel_substr in name:
-                    kib = ctr['FETCH_SIZE']['mean'] + ctr['WRITE_SIZE']['mean']
+                    kib = 2 * ctr['FETCH_SIZE']['mean'] \
+                        + ctr['WRITE_SIZE']['mean']
                     return int(kib * 1024), os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
@@ -199,25 +257,31 @@ def ll_roofline(ctx, rng, N, M, K, reps, traffic=None, traffic_src=None):
     alg_bytes = N * M / 4 + 4 * K * M + 8 * N * K
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     evals = N * K / (ms * 1e-3)
+    adds = evals * M            # algorithmic FP64 adds/s: one per element
     return {
-        'kernel': kernel, 'bound': 'hbm',
-        'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(gbs / HBM_PEAK_GBS, 5), 'traffic': traffic,
-        'traffic_source': traffic_src,
-        'note': 'arithmetic intensity ~4K FP64 adds/byte: for K >= 2 the '
-            'kernel is FP64-VALU-bound, not HBM-bound (SURVEY.md 8(d)); '
-            'the binding roof is in `valu`',
+        'kernel': kernel, 'bound': 'valu',
+        # N K M FP64 adds per launch against the
+        # FP64 vector rate (39.3e12 adds/s = half the 78.6 TFLOP/s FMA peak)
+        'achieved': round(adds / 1e12, 4), 'peak': FP64_ADDS_PEAK / 1e12,
+        'unit': 'TFLOP/s', 'frac': round(adds / FP64_ADDS_PEAK, 4),
+        'traffic': traffic, 'traffic_source': traffic_src,
+        'note': 'FP64 adds, one per cell x cluster x mutation (arithmetic '
+            'intensity ~4K adds/byte: VALU-bound for K >= 2, SURVEY.md 8(d));'
+            ' the exec-mask formulation ISSUES two masked v_add_f64 per '
+            'element, so the issue-limited ceiling is 0.5 (`issue`); the HBM '
+            'roof is in `hbm`',
         'shape': {'N': N, 'M': M, 'K': K, 'mutation_chunks': chunks},
         'launch_ms': round(ms, 5),
         'eval_ms': round(ms_full, 5),
+        'algorithmic_flops': int(N) * int(K) * int(M),
         'algorithmic_bytes': int(alg_bytes),
-        # the exec-mask formulation issues 2 masked v_add_f64 per cell x
-        # cluster x mutation; BASELINE.md section 3 prices 1 add per element
-        'valu': {
-            'achieved_elem_evals_per_s': evals * M,
-            'peak_elem_evals_per_s': FP64_ADDS_PEAK / 2,
-            'frac': round(evals * M / (FP64_ADDS_PEAK / 2), 4),
-            'frac_1add': round(evals * M / FP64_ADDS_PEAK, 4),
+        'issue': {
+            'issued_adds_per_element': 2,
+            'frac_of_issue_peak': round(2 * adds / FP64_ADDS_PEAK, 4),
+        },
+        'hbm': {
+            'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 5),
         },
     }, evals
 
@@ -278,8 +342,11 @@ def main():
     # ---- timed region: exactly K steps -----------------------------------
     import gc
     gc.collect()
+    clock = MoveClock(model)
+    clock.on = True
     elapsed = timed_steps(ranks, lambda i: step(chain, i, burn),
         args.warmup + 1, total)
+    clock.on = False
     K_end = len(model.cells_per_cluster)
     ml_end = float(chain.results['ML'][total])
 
@@ -348,11 +415,23 @@ def main():
 
     if rank == 0:
         from bnpc_amd import _lib, model as pmodel
+        seen, kept = model._dev().mh_screen_stats()
         host_info = {
             'threads': _lib.host_threads(),
+            'threads_wide_batches': _lib.threads_for(K_end * M),
             'native_mh_batch': pmodel._native_kernels() is not None,
+            'native_beta': pmodel._native_beta(),
             'numa_node': getattr(model._dev(), 'numa_node', None),
             'cpus': len(os.sched_getaffinity(0)),
+            # parameter-batch entries screened on the device / share of them
+            # the host still had to evaluate (accepted or in doubt)
+            # cells of all sweeps so far / decided from the device's hint
+            # without a scan / of those, between the row's two best columns
+            'sweep_cells': getattr(model, '_swept', 0),
+            'sweep_hinted': getattr(model, '_hint_used', 0),
+            'sweep_pairs': getattr(model, '_pair_used', 0),
+            'mh_screened': seen,
+            'mh_left_to_host': round(kept / seen, 4) if seen else None,
         }
         value = world * args.steps / elapsed
         line = {
@@ -378,6 +457,9 @@ def main():
             'host': host_info,
             'first_step_s': None if first_step_s is None
                 else round(first_step_s, 4),
+            # what the timed window was made of (rank 0): a window's value
+            # depends on its move mix - split/merge steps cost ~3x a Gibbs step
+            'window': clock.report(args.steps, elapsed),
             'ML_end': ml_end,
             'roofline': roofline,
             'roofline_converged': roofline_converged,

@@ -32,7 +32,8 @@ class MT19937(C.Structure):
 
 # bnpc_top2 (include/bnpc_hip.h) as a NumPy record
 TOP2 = np.dtype([('best', np.float64), ('second', np.float64),
-    ('col', np.int64)])
+    ('third', np.float64), ('ll_best', np.float64), ('ll_second', np.float64),
+    ('col', np.int32), ('col2', np.int32)])
 
 
 class GibbsState(C.Structure):
@@ -41,7 +42,7 @@ class GibbsState(C.Structure):
         ('pos_end', _i64), ('row_base', _i64), ('threads', _i64),
         ('hint', C.c_void_p), ('hint_prior', C.c_void_p), ('hint_cols', _i64),
         ('hint_used', _i64), ('matrix_wait', C.c_void_p),
-        ('matrix_wait_arg', C.c_void_p)]
+        ('matrix_wait_arg', C.c_void_p), ('pair_used', _i64)]
 
 
 class MHArgs(C.Structure):

@@ -1251,8 +1251,9 @@ __global__ __launch_bounds__(256) void k_stage_copy(
 }
 
 // ---------------------------------------------------------------------------
-// K2t: per slot the two largest entries of out[s][k] + prior[k], k < K <= 64,
-// and the column of the largest (first on ties): the sweep's hint.  The
+// K2t: per slot the three largest entries of out[s][k] + prior[k], k < K <= 64,
+// the columns of the two largest (first on ties) and their log-likelihoods:
+// the sweep's hint.  The
 // priors travel as kernel arguments (no memory to fetch them from); the matrix
 // was just written and is read from L2.
 // ---------------------------------------------------------------------------
@@ -1267,22 +1268,37 @@ __global__ __launch_bounds__(256) void k_row_top2(
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
     if (slot >= n) return;
     const double *__restrict__ r = ll + (size_t)slot * ldo;
-    double best = -INFINITY, second = -INFINITY;
-    long long col = 0;
+    double best = -INFINITY, second = -INFINITY, third = -INFINITY;
+    double lb = 0.0, ls = 0.0;
+    int col = 0, col2 = -1;
     for (int k = 0; k < K; k++) {
-        const double v = r[k] + prior.v[k];
+        const double l = r[k];
+        const double v = l + prior.v[k];
         if (v > best) {
+            third = second;
             second = best;
+            ls = lb;
+            col2 = best > -INFINITY ? col : -1;
             best = v;
+            lb = l;
             col = k;
         } else if (v > second) {
+            third = second;
             second = v;
+            ls = l;
+            col2 = k;
+        } else if (v > third) {
+            third = v;
         }
     }
     bnpc_top2 t;
     t.best = best;
     t.second = second;
+    t.third = third;
+    t.ll_best = lb;
+    t.ll_second = ls;
     t.col = col;
+    t.col2 = col2;
     out[slot] = t;
 }
 

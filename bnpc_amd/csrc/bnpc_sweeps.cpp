@@ -445,9 +445,53 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
-        if (!hinted) NEED_MATRIX()
-        if (hinted) {
-            // `top` is known and dominates: nothing else is needed below
+        // Not dominated - typically a cell torn between the two halves of a
+        // freshly split cluster, which are close to each other and far above
+        // everything else.  If the row's two best columns, re-scored under
+        // the CURRENT priors exactly as the scan would (ll + prior), leave
+        // everything else - the third entry at launch widened by the drift,
+        // the new-cluster entry, columns born since - more than 61 below the
+        // lower of the two, the scan below would give every other entry no
+        // exp() (the 60-below-the-runner-up rule) and the floor probability:
+        // the cell is decided from the two entries, bit for bit as the scan
+        // decides it, without reading its row.
+        bool pair = false;
+        int64_t pair_second = 0;
+        if (hint && !hinted && A <= 64 && shortcuts) {
+            const bnpc_top2 &h = hint[cell];
+            const int64_t c1 = h.col, c2 = h.col2;
+            if (c1 >= 0 && c1 < hint_cols && c2 >= 0 && c2 < hint_cols
+                && c1 != c2 && col_size[c1] > 0 && col_size[c2] > 0
+                && pos_of_col[c1] >= 0 && pos_of_col[c2] >= 0) {
+                const double q1 = h.ll_best + cpr[c1];
+                const double q2 = h.ll_second + cpr[c2];
+                double other = h.third + drift;
+                const double pn = post_new[cell];
+                if (pn > other) other = pn;
+                for (int64_t a = A - 1; a >= 0 && order[a] >= hint_cols; a--) {
+                    NEED_MATRIX()
+                    const double v = row[order[a]] + cpr[order[a]];
+                    if (v > other) other = v;
+                }
+                const double low = q1 < q2 ? q1 : q2;
+                if (q1 > -INFINITY && q1 < INFINITY && q2 > -INFINITY
+                    && q2 < INFINITY && other < low - 61.0) {
+                    const int64_t a1 = pos_of_col[c1], a2 = pos_of_col[c2];
+                    // first maximum in list order wins a tie, as in the scan
+                    const bool first = q1 > q2 || (q1 == q2 && a1 < a2);
+                    top = first ? a1 : a2;
+                    pair_second = first ? a2 : a1;
+                    best = first ? q1 : q2;
+                    second = first ? q2 : q1;
+                    pair = true;
+                    st->hint_used++;
+                    st->pair_used++;
+                }
+            }
+        }
+        if (!hinted && !pair) NEED_MATRIX()
+        if (hinted || pair) {
+            // `top` is known: nothing else is needed from the row
         } else if (par && A >= par_min) {
             par->row = row;
             par->A = A;
@@ -491,7 +535,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
-        if (!hinted) {
+        if (!hinted && !pair) {
             const double v = post_new[cell];
             post[A] = v;
             const bool gt = v > best;
@@ -505,7 +549,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // -inf) has no counterpart here: the reference would go through its
         // FloatingPointError branches (CRP.py:94-98).  Nothing has been drawn
         // for this cell yet; fail loudly instead of opening a cluster.
-        if (!hinted && !(best > -INFINITY && best < INFINITY)) {
+        if (!hinted && !pair && !(best > -INFINITY && best < INFINITY)) {
             bnpc_set_error("non-finite log posterior for cell %lld "
                            "(maximum %g over %lld clusters)",
                            (long long)cell, best, (long long)A);
@@ -553,7 +597,25 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // every entry clipped at log(1e-15) contributes exp(LOG_EPS).
             double run = 0.0;
             double tail = 0.0;
-            if (par && A >= par_min) {
+            if (pair) {
+                // the scan's arithmetic with every entry but `top` and the
+                // runner-up at the floor: one term in the tail sum, two
+                // exponentials in the running sum
+                const double d2 = second - ptop;
+                if (d2 > -746.0) tail += exp(d2);
+                const double lnorm = log1p(tail);
+                const double v_top = (ptop - ptop) - lnorm;
+                const double v_sec = d2 - lnorm;
+                const double e_top = (v_top <= LOG_EPS) ? EXP_LOG_EPS
+                    : exp(v_top > 0.0 ? 0.0 : v_top);
+                const double e_sec = (v_sec <= LOG_EPS) ? EXP_LOG_EPS
+                    : exp(v_sec > 0.0 ? 0.0 : v_sec);
+                for (int64_t a = 0; a <= A; a++) {
+                    run += a == top ? e_top
+                        : (a == pair_second ? e_sec : EXP_LOG_EPS);
+                    cdf[a] = run;
+                }
+            } else if (par && A >= par_min) {
                 // the exponentials on the team, the sums here in index order
                 par->top = top;
                 par->ptop = ptop;

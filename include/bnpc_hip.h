@@ -152,7 +152,15 @@ int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
  * into pinned host memory, valid until the next call on the context. */
 typedef struct bnpc_top2 {
     double best, second;    /* largest / second largest entry of the row */
-    int64_t col;            /* column of the largest (first one on ties) */
+    double third;           /* third largest (-inf with fewer than 3 columns) */
+    /* the log-likelihoods (no prior) behind best / second: with them the
+     * loop re-scores the row's two candidates under the CURRENT priors
+     * exactly as a scan would (row[c] + prior[c]) - a cell torn between two
+     * close clusters (the halves of a fresh split), everything else far
+     * below, is decided from these two entries alone */
+    double ll_best, ll_second;
+    int32_t col;            /* column of the largest (first one on ties) */
+    int32_t col2;           /* column of the second largest, -1 if none */
 } bnpc_top2;
 int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
                               int64_t K, double FP, double FN, int64_t ldo,
@@ -541,6 +549,8 @@ typedef struct bnpc_gibbs_state {
      * of ll, e.g. bnpc_matrix_wait with its context */
     int (*matrix_wait)(void *);
     void *matrix_wait_arg;
+    int64_t pair_used;  /* out: of hint_used, cells decided between the row's
+                         * two best columns (accumulated) */
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

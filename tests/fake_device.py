@@ -73,13 +73,23 @@ class FakeContext:
         if K > 64:
             return mat, None
         post = mat[:, :K] + np.asarray(col_prior)[None, :]
-        hint = np.empty(post.shape[0], dtype=[('best', np.float64),
-            ('second', np.float64), ('col', np.int64)])
+        from bnpc_amd._lib import TOP2
+        n = post.shape[0]
+        rows = np.arange(n)
+        hint = np.zeros(n, dtype=TOP2)
         hint['col'] = np.argmax(post, axis=1)
-        hint['best'] = post[np.arange(post.shape[0]), hint['col']]
+        hint['best'] = post[rows, hint['col']]
+        hint['ll_best'] = mat[rows, hint['col']]
         rest = post.copy()
-        rest[np.arange(post.shape[0]), hint['col']] = -np.inf
-        hint['second'] = rest.max(axis=1) if K > 1 else -np.inf
+        rest[rows, hint['col']] = -np.inf
+        hint['second'], hint['third'], hint['col2'] = -np.inf, -np.inf, -1
+        if K > 1:
+            hint['col2'] = np.argmax(rest, axis=1)
+            hint['second'] = rest[rows, hint['col2']]
+            hint['ll_second'] = mat[rows, hint['col2']]
+            rest[rows, hint['col2']] = -np.inf
+            if K > 2:
+                hint['third'] = rest.max(axis=1)
         return mat, hint
 
     def matrix_wait(self):

@@ -691,6 +691,8 @@ def test_sweep_hint_is_used_and_falls_back():
     hint['best'] = -100.0 + col_prior[truth]
     hint['second'] = -500.0 + col_prior.max()
     hint['col'] = truth
+    hint['col2'] = -1
+    hint['third'] = -np.inf
     post_new = np.full(N, -800.0)
 
     def sweep(mat, hints):
@@ -714,8 +716,10 @@ def test_sweep_hint_is_used_and_falls_back():
                 _lib.ptr(assignment), _lib.ptr(col_of_id), _lib.ptr(col_id),
                 _lib.ptr(col_size), _lib.ptr(order), _lib.ptr(scratch)),
                 'sweep')
+        used.append(int(st.hint_used))
         return assignment, np.random.random()
 
+    used = []
     want = sweep(ll, None)
     assert np.array_equal(want[0], truth)
     poisoned = np.full_like(ll, np.nan)
@@ -725,6 +729,30 @@ def test_sweep_hint_is_used_and_falls_back():
     close['second'] = close['best'] - 1.0   # a runner-up 1 nat away: scan
     got = sweep(ll, close)
     assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+
+    # a cell torn between TWO columns, the third far below: decided from the
+    # two entries of the hint under the current priors - same draws, same
+    # picks as the full scan of the matrix, which is never read
+    rival = (truth + 1) % K
+    torn = ll.copy()
+    torn[np.arange(N), rival] = -100.7
+    pair = np.zeros(N, dtype=_lib.TOP2)
+    pair['col'], pair['col2'] = truth, rival
+    pair['ll_best'], pair['ll_second'] = -100.0, -100.7
+    pair['best'] = -100.0 + col_prior[truth]
+    pair['second'] = -100.7 + col_prior[rival]
+    pair['third'] = -500.0 + col_prior.max()
+    want = sweep(torn, None)
+    assert not np.array_equal(want[0], truth)       # some cells do move
+    got = sweep(torn, pair)
+    assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+    assert used[-1] >= 4        # (a cell whose hinted cluster died is scanned)
+    # ... but not when the third entry is within reach: every cell is scanned
+    near = pair.copy()
+    near['third'] = near['second'] - 30.0
+    got = sweep(torn, near)
+    assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+    assert used[-1] == 0
 
 
 def test_given_row_acceptance_ratios_equal_the_array_path(monkeypatch):

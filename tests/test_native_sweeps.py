@@ -44,7 +44,8 @@ def reference_gibbs(ll, post_new, crp_prior, assignment, sizes, new_columns):
     return assignment, cpc, n_new
 
 
-def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns):
+def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns,
+            hint=None, used=None):
     lib = _lib.load()
     N, K = ll0.shape
     ld = K + 2                                  # forces the growth path
@@ -63,6 +64,10 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns):
     order[:K] = np.arange(K)
     scratch = np.empty(2 * (ld + 1))
     st = _lib.GibbsState(N, ld, K, K, 0, -1, N, -1)
+    if hint is not None:        # (hints, priors at launch) for columns 0..K-1
+        st.hint = hint[0].ctypes.data
+        st.hint_prior = hint[1].ctypes.data
+        st.hint_cols = K
     rng, extra = _lib.rng_export()
     n_new = 0
     while True:
@@ -93,6 +98,8 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns):
         st.n_cols += 1
         assignment[cell] = new_id
     _lib.rng_import(rng, extra)
+    if used is not None:
+        used.append(int(st.hint_used))
     live = order[:st.n_active]
     return assignment, {int(col_id[c]): int(col_size[c]) for c in live}, n_new
 
@@ -626,3 +633,64 @@ def test_native_beta_theta_and_this_numpy():
     with pytest.raises(RuntimeError):
         _lib.beta(np.array([1., np.nan]), np.array([1., 1.]))
     assert np.random.get_state()[2] == pos      # nothing was drawn
+
+
+def test_sweep_hints_fuzz():
+    """The per-cell hint (three largest entries, the two best columns and
+    their log-likelihoods) against the plain scan on 200 random sweeps whose
+    matrices hold what a running chain holds: clear winners, cells torn
+    between two near-duplicate columns (the halves of a fresh split) with
+    everything else far below, three-way ties, clusters that die and are
+    born under the hint.  Same assignments, cluster tables, births, stream;
+    most cells are decided without a scan."""
+    decided = cells = 0
+    for seed in range(200):
+        rng = np.random.RandomState(7000 + seed)
+        N = int(rng.choice([30, 90, 200]))
+        K = int(rng.randint(3, 13))
+        ll = -rng.random_sample((N, K)) * 300 - 200       # far below
+        a = rng.randint(0, K, N)
+        b = (a + 1 + rng.randint(0, K - 1, N)) % K
+        ll[np.arange(N), a] = -50 - rng.random_sample(N) * 5
+        kind = rng.random_sample(N)
+        two = kind < 0.4                # torn between two columns
+        ll[two, b[two]] = ll[two, a[two]] - rng.random_sample(two.sum()) * 3
+        three = kind > 0.95             # a third within reach: scanned
+        c = (b + 1) % K
+        ll[three, c[three]] = ll[three, a[three]] - 20
+        post_new = -rng.random_sample(N) * 50 - (300 if seed % 4 else 60)
+        alpha = 2.5
+        crp_prior = np.append(0, O.CRP.log_CRP_prior(
+            np.append(np.arange(1, N + 1), alpha), N, alpha))
+        labels = rng.randint(0, K, N)
+        labels[:K] = np.arange(K)
+        ids = rng.permutation(N)[:K]
+        assignment = ids[labels]
+        sizes = {int(i): int((assignment == i).sum()) for i in ids}
+        new_columns = [-rng.random_sample(N) * 300 - 100
+            for _ in range(N + 1)]
+        col_prior = np.ascontiguousarray(
+            crp_prior[np.fromiter(sizes.values(), dtype=np.int64)])
+        post = ll + col_prior[None, :]
+        order = np.argsort(-post, axis=1, kind='stable')
+        rows = np.arange(N)
+        hint = np.zeros(N, dtype=_lib.TOP2)
+        hint['col'], hint['col2'] = order[:, 0], order[:, 1]
+        hint['best'] = post[rows, order[:, 0]]
+        hint['second'] = post[rows, order[:, 1]]
+        hint['third'] = post[rows, order[:, 2]]
+        hint['ll_best'] = ll[rows, order[:, 0]]
+        hint['ll_second'] = ll[rows, order[:, 1]]
+        outs, used = [], []
+        for h in (None, (hint, col_prior)):
+            np.random.seed(seed)
+            got = native_gibbs(ll, post_new, crp_prior, assignment, sizes,
+                new_columns, hint=h, used=used)
+            outs.append((got[0], list(got[1].items()), got[2],
+                np.random.random(2)))
+        assert np.array_equal(outs[0][0], outs[1][0]), seed
+        assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], seed
+        assert np.array_equal(outs[0][3], outs[1][3]), seed
+        decided += used[1]
+        cells += N
+    assert decided > 0.7 * cells, (decided, cells)
