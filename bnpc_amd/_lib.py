@@ -104,6 +104,8 @@ SIGNATURES = {
         C.c_double, _i64, _ppd]),
     'bnpc_ll_theta_pinned_top2': (C.c_int, [_ctx, C.c_int, _pf, _i64,
         C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
+    'bnpc_ll_theta_pinned_top2_issue': (C.c_int, [_ctx, C.c_int, _pf, _i64,
+        C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
     'bnpc_matrix_wait': (C.c_int, [_ctx]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
@@ -143,6 +145,9 @@ SIGNATURES = {
         C.c_void_p]),
     'bnpc_mh_batch_dev': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
         C.POINTER(MHArgs), C.c_int, C.POINTER(C.c_int)]),
+    'bnpc_label_counts_and_batch': (C.c_int, [_ctx, C.c_void_p,
+        C.POINTER(MT19937), _pi64, _pi64, C.POINTER(MHArgs),
+        C.POINTER(C.c_int)]),
     'bnpc_mh_screen_stats': (C.c_int, [_ctx, C.POINTER(_i64),
         C.POINTER(_i64)]),
     'bnpc_rg_scan_step': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
@@ -534,6 +539,15 @@ class NumpyStream:
         return False
 
 
+def permutation(n):
+    """np.random.permutation(n), natively on the global stream (the legacy
+    shuffle: one masked-rejection interval draw per element)."""
+    out = np.empty(n, dtype=np.int64)
+    with NumpyStream() as rng:
+        check(load().bnpc_mt_permutation(rng, n, ptr(out)), 'mt_permutation')
+    return out
+
+
 def mh_draws(G, M, n_sd):
     """(sd_idx int32 (G, M), U (G, M), u (G, M)): the per-cluster draws of
     MH_cluster_params from the global stream, natively."""
@@ -637,13 +651,15 @@ def threads_for(elements):
 
 def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
             trans_prob, known=None, want_prior=False, draws=None,
-            threads=None, ctx=None, counts_src=0):
+            threads=None, ctx=None, counts_src=0, label=None):
     """bnpc_mh_batch: the draws and the arithmetic of MH_cluster_params for
     the G rows of `old` (float32 G x M).  `draws` = (sd_idx, U, u) evaluates
     given draws instead of taking them from the global stream.  With `ctx`
     (a device Context whose resident counts - counts_src 0: by label, 1: the
     last view counts - are those of n1 / n0) the device screens the batch
-    first and the host evaluates only what it leaves (bnpc_mh_batch_dev).
+    first and the host evaluates only what it leaves (bnpc_mh_batch_dev);
+    with `label` = (assignment, ids) the per-cluster counts are made in the
+    same call and n1 / n0 RECEIVE them (bnpc_label_counts_and_batch).
     Returns (status, new, log_prob, declined, prior, (sd_idx, U, u)); status
     1: only the draws are valid - they are views of scratch that the next
     call overwrites."""
@@ -681,7 +697,16 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
     status = C.c_int(0)
     lib = load()
     handle = getattr(ctx, '_h', None)
-    if handle and not trans_prob:
+    if label is not None:
+        assert handle and draws is None and not trans_prob
+        cells, ids = as_i64(label[0]), as_i64(label[1])
+        assert ids.size == G and n1.flags['WRITEABLE']
+        with NumpyStream() as rng:
+            check(lib.bnpc_label_counts_and_batch(handle,
+                C.addressof(kernels), rng, cells.ctypes.data,
+                ids.ctypes.data, C.byref(a), C.byref(status)),
+                'label_counts_and_batch')
+    elif handle and not trans_prob:
         if draws is None:
             with NumpyStream() as rng:
                 check(lib.bnpc_mh_batch_dev(handle, C.addressof(kernels), rng,
@@ -923,10 +948,12 @@ class Context:
             return np.empty((0, ld))
         return np.ctypeslib.as_array(host, shape=(n, ld))
 
-    def ll_theta_pinned_top2(self, view, theta, FP, FN, ld, col_prior):
+    def ll_theta_pinned_top2(self, view, theta, FP, FN, ld, col_prior,
+                wait=True):
         """ll_theta_pinned plus the sweep's hint: (matrix view, hint) where
-        hint is a structured NumPy VIEW (fields best, second, col; one entry
-        per slot) of pinned memory, or None (more than 64 columns)."""
+        hint is a structured NumPy VIEW (TOP2 records, one per slot) of
+        pinned memory, or None (more than 64 columns).  wait=False returns
+        once the work is queued: call sync() before reading the hints."""
         theta = np.ascontiguousarray(theta, dtype=np.float32)
         K = theta.shape[0]
         if K > 64:
@@ -936,9 +963,10 @@ class Context:
         n = self.view_size(view)
         host = _host_pd()
         hint = C.c_void_p()
-        check(self._lib.bnpc_ll_theta_pinned_top2(self._h, view,
-            ptr(theta, C.c_float), K, float(FP), float(FN), ld,
-            ptr(col_prior), C.byref(host), C.byref(hint)),
+        fn = self._lib.bnpc_ll_theta_pinned_top2 if wait \
+            else self._lib.bnpc_ll_theta_pinned_top2_issue
+        check(fn(self._h, view, ptr(theta, C.c_float), K, float(FP),
+            float(FN), ld, ptr(col_prior), C.byref(host), C.byref(hint)),
             'll_theta_pinned_top2')
         if n == 0:
             return np.empty((0, ld)), None

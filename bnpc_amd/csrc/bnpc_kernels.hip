@@ -2337,11 +2337,10 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     return 0;
 }
 
-extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
-                                         const float *theta, int64_t K,
-                                         double FP, double FN, int64_t ldo,
-                                         const double *col_prior,
-                                         double **host, bnpc_top2 **top2)
+static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
+                        double FP, double FN, int64_t ldo,
+                        const double *col_prior, double **host,
+                        bnpc_top2 **top2, bool wait)
 {
     ARGCHK(c && host && top2 && col_prior, "NULL argument");
     ARGCHK(K > 0 && K <= 64, "K out of range for the top-2 hint");
@@ -2394,7 +2393,7 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
         // the caller gets the hints now; the matrix stays on the device and
         // is copied if and when the sweep first needs a row of it
         // (bnpc_matrix_wait) - a converged sweep never does
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (wait) HIPCHK(hipStreamSynchronize(c->stream));
         c->pin_lazy_bytes = bytes;
     } else {
         HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
@@ -2404,6 +2403,32 @@ extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
     *host = (double *)c->pin;
     *top2 = hint;
     return 0;
+}
+
+extern "C" int bnpc_ll_theta_pinned_top2(bnpc_ctx *c, int view,
+                                         const float *theta, int64_t K,
+                                         double FP, double FN, int64_t ldo,
+                                         const double *col_prior,
+                                         double **host, bnpc_top2 **top2)
+{
+    return ll_top2_impl(c, view, theta, K, FP, FN, ldo, col_prior, host, top2,
+                        true);
+}
+
+// The same, returning as soon as the work is queued when the hints are
+// written in place (the parameters were staged: nothing of the caller's is
+// borrowed): the caller prepares the sweep - its permutation, its tables -
+// under the launch and calls bnpc_sync before reading the hints.
+extern "C" int bnpc_ll_theta_pinned_top2_issue(bnpc_ctx *c, int view,
+                                               const float *theta, int64_t K,
+                                               double FP, double FN,
+                                               int64_t ldo,
+                                               const double *col_prior,
+                                               double **host,
+                                               bnpc_top2 **top2)
+{
+    return ll_top2_impl(c, view, theta, K, FP, FN, ldo, col_prior, host, top2,
+                        false);
 }
 
 // The matrix of the last bnpc_ll_theta_pinned_top2 is complete on return.
@@ -2807,10 +2832,12 @@ extern "C" int bnpc_colcounts(bnpc_ctx *c, const int64_t *cells,
     return 0;
 }
 
-extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
-                                       const int64_t *ids, int64_t K,
-                                       int32_t *n1, int32_t *n0)
+static int colcounts_by_label_impl(bnpc_ctx *c, const int64_t *assignment,
+                                   const int64_t *ids, int64_t K,
+                                   int32_t *n1, int32_t *n0,
+                                   const int **defer)
 {
+    if (defer) *defer = nullptr;
     ARGCHK(c && assignment && ids, "NULL argument");
     ARGCHK(K > 0, "K must be positive");
     HIPCHK(hipSetDevice(c->device));
@@ -2838,7 +2865,7 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
         const int64_t *pp = pos.data();
         int rc = counts_from_masks(c, 0,
             [=](int64_t s) -> int64_t { return pp[assignment[s]]; }, K,
-            c->lab_cnt, n1, n0);
+            c->lab_cnt, n1, n0, defer);
         if (rc == 0) c->lab_K = K;
         return rc;
     }
@@ -2859,6 +2886,13 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
         d2h_finish(b);
     }
     return 0;
+}
+
+extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
+                                       const int64_t *ids, int64_t K,
+                                       int32_t *n1, int32_t *n0)
+{
+    return colcounts_by_label_impl(c, assignment, ids, K, n1, n0, nullptr);
 }
 
 
@@ -2992,15 +3026,25 @@ extern "C" int bnpc_mh_screen(bnpc_ctx *c, int counts_src,
     return 0;
 }
 
-// bnpc_mh_batch with the device screen in front (include/bnpc_hip.h)
-extern "C" int bnpc_mh_batch_dev(bnpc_ctx *c, const bnpc_host_kernels *k,
-                                 bnpc_mt19937 *rng, const bnpc_mh_args *a,
-                                 int counts_src, int *status)
+// bnpc_mh_batch with the device screen in front (include/bnpc_hip.h).
+// `pending`: counts the device is still writing into pinned memory behind the
+// stream (n1 rows then n0 rows, a->G x M each): copied into a->n1 / a->n0
+// once the first screen has been waited for - before the host reads any.
+static bool mh_screen_applies(const bnpc_ctx *c, const bnpc_mh_args *a)
+{
+    return !(a->trans_prob || !c->tun.mh_screen || a->screen
+             || a->G * a->M < c->tun.mh_screen_min);
+}
+
+static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
+                             bnpc_mt19937 *rng, const bnpc_mh_args *a,
+                             int counts_src, int *status, const int *pending)
 {
     ARGCHK(c && a && status, "NULL argument");
-    if (a->trans_prob || !c->tun.mh_screen || a->screen
-        || a->G * a->M < c->tun.mh_screen_min)
+    if (!mh_screen_applies(c, a)) {
+        ARGCHK(!pending, "counts still pending");
         return bnpc_mh_batch(k, rng, a, status);
+    }
     if (int rc = mh_screen_argchk(c, a)) return rc;
     HIPCHK(hipSetDevice(c->device));
     static const bool trace = getenv("BNPC_MH_TRACE") != nullptr;
@@ -3043,6 +3087,11 @@ extern "C" int bnpc_mh_batch_dev(bnpc_ctx *c, const bnpc_host_kernels *k,
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M;
         HIPCHK(hipEventSynchronize(c->mh_ev[p]));
+        if (pending) {          // the counts were written before the screen
+            memcpy((void *)a->n1, pending, E * sizeof(int32_t));
+            memcpy((void *)a->n0, pending + E, E * sizeof(int32_t));
+            pending = nullptr;
+        }
         bnpc_mh_args b = *a;
         b.G = Gp;
         b.old_theta += at;
@@ -3162,6 +3211,34 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
         memcpy(a->u, h.u, E * 8);
     }
     return 0;
+}
+
+extern "C" int bnpc_mh_batch_dev(bnpc_ctx *c, const bnpc_host_kernels *k,
+                                 bnpc_mt19937 *rng, const bnpc_mh_args *a,
+                                 int counts_src, int *status)
+{
+    return mh_batch_dev_impl(c, k, rng, a, counts_src, status, nullptr);
+}
+
+// update_parameters in one call (libs/CRP.py:302-311): the per-cluster
+// column counts for `assignment` (bnpc_colcounts_by_label; they stay resident
+// for bnpc_ll_total) and the screened parameter batch on them, the screens
+// queued behind the counts kernel - the counts reach a->n1 / a->n0 (the
+// caller's arrays, K x M each) with the first screen's results.
+extern "C" int bnpc_label_counts_and_batch(bnpc_ctx *c,
+                                           const bnpc_host_kernels *k,
+                                           bnpc_mt19937 *rng,
+                                           const int64_t *assignment,
+                                           const int64_t *ids,
+                                           const bnpc_mh_args *a, int *status)
+{
+    ARGCHK(c && a && status && a->n1 && a->n0, "NULL argument");
+    const bool fused = mh_screen_applies(c, a) && !c->any_tile_pending();
+    const int *pending = nullptr;
+    if (int rc = colcounts_by_label_impl(c, assignment, ids, a->G,
+            (int32_t *)a->n1, (int32_t *)a->n0, fused ? &pending : nullptr))
+        return rc;
+    return mh_batch_dev_impl(c, k, rng, a, 0, status, pending);
 }
 
 extern "C" int bnpc_mh_screen_stats(bnpc_ctx *c, int64_t *screened,

@@ -636,12 +636,6 @@ class CRP:
             import time
             t_start = time.perf_counter()
         post_new = np.ascontiguousarray(self.get_lpost_single_new_cluster())
-        perm = _lib.as_i64(np.random.permutation(N))
-        # a private copy: the sweep's result is committed at the end, so an
-        # exception half-way leaves assignment and cells_per_cluster consistent
-        # with each other (parameter rows of ids re-used by the aborted sweep
-        # are not restored - the run is over at that point anyway)
-        assignment = np.array(self.assignment, dtype=np.int64, order='C')
         crp_prior = np.ascontiguousarray(self.CRP_prior, dtype=np.float64)
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
@@ -659,13 +653,20 @@ class CRP:
             # decides most cells without scanning them
             hint = None
             if ids.size <= 64 and os.environ.get('BNPC_SWEEP_HINT', '1') != '0':
+                # queued, not waited for: the permutation is drawn and the
+                # sweep's private state copied under the launch (no draw of
+                # the stream sits between them in the reference either: the
+                # launch consumes none)
                 col_prior = np.ascontiguousarray(crp_prior[sizes])
                 ll, top2 = ctx.ll_theta_pinned_top2(VIEW_ALL,
                     self.parameters[ids], self.FP, self.FN, ids.size + spare,
-                    col_prior)
+                    col_prior, wait=False)
+                perm, assignment = self._sweep_order(N)
+                ctx.sync()
                 if top2 is not None:
                     hint = (top2, col_prior)
             else:
+                perm, assignment = self._sweep_order(N)
                 ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids],
                     self.FP, self.FN, ids.size + spare)
             ids, sizes, born = self._gibbs_window(perm, 0, N, VIEW_ALL, ll,
@@ -673,6 +674,7 @@ class CRP:
                 hint=hint)
             opened, tiles = len(born), 1
         else:
+            perm, assignment = self._sweep_order(N)
             # Tiled sweep.  The parameter rows stay resident on the device
             # (row = cluster id) and tiles select clusters by index.  Tiles
             # t+1 and t+2 are in flight while the host walks tile t - the
@@ -762,6 +764,18 @@ class CRP:
         self.assignment = assignment
         self.cells_per_cluster = {
             int(i): int(n) for i, n in zip(ids, sizes)}
+
+    def _sweep_order(self, N):
+        """(visiting order, private copy of the assignment): the sweep's
+        result is committed at the end, so an exception half-way leaves
+        assignment and cells_per_cluster consistent with each other
+        (parameter rows of ids re-used by the aborted sweep are not restored
+        - the run is over at that point anyway)."""
+        if _lib.rng_live() is not None:
+            perm = _lib.permutation(N)
+        else:
+            perm = _lib.as_i64(np.random.permutation(N))
+        return perm, np.array(self.assignment, dtype=np.int64, order='C')
 
     def _gibbs_window(self, perm, pos, pos_end, view, ll, cols, ids, sizes,
                 stale, assignment, post_new, crp_prior, hint=None):
@@ -900,6 +914,35 @@ class CRP:
         column-count launch that is reused by get_ll_full / the error update,
         and the K proposals are evaluated as one batch (the draws stay in the
         reference's per-cluster order)."""
+        ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
+        lab = self._lab
+        stale = lab is None or not np.array_equal(lab['ids'], ids) \
+            or not np.array_equal(lab['assignment'], self.assignment)
+        ctx = self._dev()
+        table = _native_kernels()
+        if stale and table is not None and getattr(ctx, '_h', None) \
+                and ids.size <= 64:
+            # counts and batch in ONE call: the device counts, screens the
+            # proposals against those counts, and hands both back together
+            old = self.parameters[ids]
+            n1 = np.empty(old.shape, dtype=np.int32)
+            n0 = np.empty(old.shape, dtype=np.int32)
+            status, new, _, declined, prior, draws = _lib.mh_batch(
+                table, old, n1, n0, self.param_proposal_sd, TMIN, TMAX,
+                self.FP, self.FN, self.p, self.q, self.beta_prior_uniform,
+                False, known=self._known_prior(ids), want_prior=True,
+                ctx=ctx, label=(self.assignment, ids))
+            self._lab = {'ids': ids, 'assignment': self.assignment.copy(),
+                'n1': n1, 'n0': n0}
+            if status == 0:
+                if prior is not None:
+                    self._remember_prior(ids, new, prior)
+            else:       # an element the library leaves to SciPy
+                new, _, declined = self._mh_batch(old, (n1, n0), False,
+                    known=self._known_prior(ids), keep_prior=ids,
+                    draws=draws)
+            self.parameters[ids] = new
+            return declined.sum(), (self.muts_total - declined).sum()
         lab = self._label_counts()
         ids = lab['ids']
         old = self.parameters[ids]

@@ -166,6 +166,14 @@ int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
                               int64_t K, double FP, double FN, int64_t ldo,
                               const double *col_prior, double **host,
                               bnpc_top2 **top2);
+/* the same without the final wait (when hints are produced): the caller
+ * prepares the sweep under the launch and calls bnpc_sync before it reads
+ * the hints */
+int bnpc_ll_theta_pinned_top2_issue(bnpc_ctx *ctx, int view,
+                                    const float *theta, int64_t K, double FP,
+                                    double FN, int64_t ldo,
+                                    const double *col_prior, double **host,
+                                    bnpc_top2 **top2);
 /* When *top2 is returned non-NULL the matrix behind *host has NOT been copied
  * yet: it stays on the device until bnpc_matrix_wait fetches it (the sweep
  * reads it only where a hint is in doubt - a converged sweep never does).
@@ -433,6 +441,15 @@ int bnpc_mh_screen(bnpc_ctx *ctx, int counts_src, const bnpc_mh_args *a,
 int bnpc_mh_batch_dev(bnpc_ctx *ctx, const bnpc_host_kernels *k,
                       bnpc_mt19937 *rng, const bnpc_mh_args *a,
                       int counts_src, int *status);
+/* CRP.update_parameters (libs/CRP.py:302-311) in one call:
+ * bnpc_colcounts_by_label for `assignment` / ids[0..a->G) followed by
+ * bnpc_mh_batch_dev on those counts, the screens queued behind the counts
+ * kernel (one wait less).  a->n1 / a->n0 are OUTPUTS here: the caller's
+ * K x M arrays receive the counts. */
+int bnpc_label_counts_and_batch(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                                bnpc_mt19937 *rng, const int64_t *assignment,
+                                const int64_t *ids, const bnpc_mh_args *a,
+                                int *status);
 /* elements screened so far on this context / of those, left to the host */
 int bnpc_mh_screen_stats(bnpc_ctx *ctx, int64_t *screened, int64_t *kept);
 

@@ -67,7 +67,8 @@ class FakeContext:
         out = np.empty((n, ld))
         return self.ll_theta(view, theta, FP, FN, out=out)
 
-    def ll_theta_pinned_top2(self, view, theta, FP, FN, ld, col_prior):
+    def ll_theta_pinned_top2(self, view, theta, FP, FN, ld, col_prior,
+                wait=True):
         mat = self.ll_theta_pinned(view, theta, FP, FN, ld)
         K = np.asarray(theta).shape[0]
         if K > 64:
