@@ -169,6 +169,11 @@ SIGNATURES = {
     'bnpc_parse_matrix': (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int,
         C.c_void_p, _pi64, _pi64]),
     'bnpc_codist': (C.c_int, [C.c_int, _pi32, _i64, _i64, _pi32]),
+    'bnpc_post_create': (C.c_int, [C.c_int, _pi32, _i64, _i64,
+        C.POINTER(C.c_void_p), C.POINTER(_i64)]),
+    'bnpc_post_fetch': (C.c_int, [C.c_void_p, _pi32, _pd]),
+    'bnpc_post_mpear': (C.c_int, [C.c_void_p, C.c_void_p, _i64, _pi64]),
+    'bnpc_post_destroy': (C.c_int, [C.c_void_p]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
 }
@@ -378,6 +383,65 @@ def codist(assignments, device=None):
     check(load().bnpc_codist(device, ptr(a, C.c_int32), S, N,
         ptr(out, C.c_int32)), 'codist')
     return out
+
+
+class Posterior:
+    """Device-resident pair counts of a set of posterior samples (bnpc_post):
+    differ[(i, j)] = samples in which cells i and j carry different labels,
+    condensed in pdist order; assignments: samples x cells integers."""
+
+    def __init__(self, assignments, device=None):
+        a = np.ascontiguousarray(assignments, dtype=np.int32)
+        self.S, self.N = a.shape
+        if device is None:
+            device = int(os.environ.get('BNPC_DEVICE', '0'))
+        mark_gpu_touched()
+        handle, total = C.c_void_p(), _i64(0)
+        check(load().bnpc_post_create(device, ptr(a), self.S, self.N,
+            C.byref(handle), C.byref(total)), 'post_create')
+        self._h = handle
+        self.differ_sum = total.value       # sum of all pair counts
+
+    @property
+    def pairs(self):
+        return self.N * (self.N - 1) // 2
+
+    def differ(self):
+        out = np.empty(self.pairs, dtype=np.int32)
+        check(load().bnpc_post_fetch(self._h, ptr(out), None), 'post_fetch')
+        return out
+
+    def dist(self):
+        """differ / S as float64 (utils.get_dist), divided on the device."""
+        out = np.empty(self.pairs, dtype=np.float64)
+        check(load().bnpc_post_fetch(self._h, None, ptr(out)), 'post_fetch')
+        return out
+
+    def mpear_sums(self, labels):
+        """labels: (C, N) integer array of C candidate clusterings ->
+        int64 (C,): sum of differ over the pairs that share a label."""
+        labels = np.asarray(labels)
+        assert labels.ndim == 2 and labels.shape[1] == self.N
+        if labels.size and (labels.min() < 0 or labels.max() >= 65534):
+            raise ValueError('cluster labels must lie in [0, 65534)')
+        lab = np.ascontiguousarray(labels, dtype=np.uint16)
+        out = np.empty(lab.shape[0], dtype=np.int64)
+        for c0 in range(0, lab.shape[0], 1024):
+            part = np.ascontiguousarray(lab[c0:c0 + 1024])
+            check(load().bnpc_post_mpear(self._h, part.ctypes.data,
+                part.shape[0], out[c0:].ctypes.data), 'post_mpear')
+        return out
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load().bnpc_post_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
 
 
 _live = {}

@@ -12,7 +12,9 @@
 // 4 x 4 block of pair counters in registers.  int32 VALU, LDS-broadcast
 // reads; only tiles on or above the diagonal do any work.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "bnpc_hip.h"
 #include "bnpc_internal.h"
@@ -109,5 +111,273 @@ extern "C" int bnpc_codist(int device, const int32_t *assignments, int64_t S,
     (void)hipFree(d_a);
     (void)hipFree(d_d);
 #undef CK
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// The posterior estimator as a pipeline: the pair
+// counts STAY on the device, the mean distance goes to the host once (SciPy's
+// Ward linkage needs it there), and every candidate cut of the tree is scored
+// on the device in one pass over the counts.
+//
+// MPEAR of a clustering c (Fritsch & Ickstadt 2009, eq. 13;
+// /root/reference/libs/utils.py:133-145) needs, with pi = 1 - differ / S,
+//     I_sum  = #{pairs with c_i == c_j}            (from the label counts)
+//     pi_sum = P - sum(differ) / S                  (one sum, all candidates)
+//     index  = sum_{c_i == c_j} pi = I_sum - D_c / S,
+//     D_c    = sum_{i < j, c_i == c_j} differ_ij   <- k_mpear_sums, int64
+// i.e. exact integers, order-free; the float64 `pi` (10 GB at 50 000 cells)
+// and the reference's pass over it per candidate are never made.
+//
+// k_mpear_sums: persistent workgroups walk the 64 x 64 pair tiles on or above
+// the diagonal; a tile's counts sit in LDS (pairs with i >= j as zeros), the
+// labels of its 64 + 64 cells under CP candidates beside them, candidate
+// fastest (conflict-free: the lanes of a wave read consecutive candidates of
+// one cell, the count of one pair is a broadcast).  Thread = (candidate,
+// row part): it adds the counts of its pairs whose two cells share the
+// candidate's label into ONE register accumulator that lives across all its
+// tiles - no reduction inside the loop; at the end the parts are added
+// through LDS and each workgroup makes one 64-bit atomic add per candidate.
+// ---------------------------------------------------------------------------
+#define MP_MAXCP 128
+
+__global__ __launch_bounds__(256) void k_mpear_sums(
+    const int *__restrict__ differ, long long N,
+    const unsigned short *__restrict__ labels,  // [C][N]
+    int c0, int C, int CP, unsigned long long *__restrict__ out)
+{
+    __shared__ int D[64][64];
+    __shared__ unsigned short LA[64][MP_MAXCP];
+    __shared__ unsigned short LB[64][MP_MAXCP];
+    __shared__ unsigned long long red[256];
+    const int tid = threadIdx.x;
+    const int c = tid % CP, part = tid / CP, parts = 256 / CP;
+    const long long nt = (N + 63) / 64;
+    const long long tiles = nt * (nt + 1) / 2;
+    unsigned long long acc = 0;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        // tile index -> (ti <= tj), rows of the upper triangle in order
+        long long ti = (long long)((2.0 * nt + 1.0
+            - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)t))
+            * 0.5);
+        while (ti > 0 && ti * (2 * nt - ti + 1) / 2 > t) ti--;
+        while ((ti + 1) * (2 * nt - ti) / 2 <= t) ti++;
+        const long long tj = ti + (t - ti * (2 * nt - ti + 1) / 2);
+        __syncthreads();                        // the previous tile is done
+        for (int e = tid; e < 4096; e += 256) {
+            const int a = e >> 6, b = e & 63;
+            const long long i = ti * 64 + a, j = tj * 64 + b;
+            int v = 0;
+            if (i < j && j < N)
+                v = differ[i * (2 * N - i - 1) / 2 + (j - i - 1)];
+            D[a][b] = v;
+        }
+        for (int e = tid; e < 64 * CP; e += 256) {
+            const int cell = e / CP, cc = e - cell * CP;
+            const long long i = ti * 64 + cell, j = tj * 64 + cell;
+            const bool live = c0 + cc < C;
+            // cells past N / candidates past C: labels that match nothing
+            LA[cell][cc] = (live && i < N)
+                ? labels[(size_t)(c0 + cc) * N + i] : (unsigned short)0xfffe;
+            LB[cell][cc] = (live && j < N)
+                ? labels[(size_t)(c0 + cc) * N + j] : (unsigned short)0xffff;
+        }
+        __syncthreads();
+        for (int a = part; a < 64; a += parts) {
+            const unsigned short la = LA[a][c];
+            unsigned sum = 0;                   // 64 counts <= S each
+#pragma unroll 8
+            for (int b = 0; b < 64; b++)
+                sum += (LB[b][c] == la) ? (unsigned)D[a][b] : 0u;
+            acc += sum;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (part == 0) {
+        unsigned long long s = 0;
+        for (int p = 0; p < parts; p++) s += red[p * CP + c];
+        if (c0 + c < C && s) atomicAdd(&out[c0 + c], s);
+    }
+}
+
+// sum of all pair counts (pi_sum), fixed grid, one atomic per workgroup
+__global__ __launch_bounds__(256) void k_differ_sum(
+    const int *__restrict__ differ, long long pairs,
+    unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs;
+         i += (long long)gridDim.x * 256)
+        acc += (unsigned long long)differ[i];
+    __shared__ unsigned long long red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0]) atomicAdd(out, red[0]);
+}
+
+// mean distance differ / S as float64 (what SciPy's linkage takes): the same
+// IEEE division NumPy performs on the host, 16 bytes per lane coalesced
+__global__ __launch_bounds__(256) void k_differ_to_dist(
+    const int *__restrict__ differ, long long pairs, double S,
+    double *__restrict__ dist)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs;
+         i += (long long)gridDim.x * 256)
+        dist[i] = (double)differ[i] / S;
+}
+
+struct bnpc_post {
+    int device = 0;
+    int64_t S = 0, N = 0;
+    int *differ = nullptr;                  // condensed, device
+    unsigned long long *sums = nullptr;     // device scratch
+};
+
+#define PCK(expr)                                                            \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            bnpc_set_error("%s failed: %s", #expr, hipGetErrorString(e_));   \
+            return 1;                                                        \
+        }                                                                    \
+    } while (0)
+
+extern "C" int bnpc_post_destroy(bnpc_post *p)
+{
+    if (!p) return 0;
+    (void)hipSetDevice(p->device);
+    if (p->differ) (void)hipFree(p->differ);
+    if (p->sums) (void)hipFree(p->sums);
+    delete p;
+    return 0;
+}
+
+extern "C" int bnpc_post_create(int device, const int32_t *assignments,
+                                int64_t S, int64_t N, bnpc_post **out,
+                                int64_t *differ_sum)
+{
+    if (!assignments || !out || S < 1 || N < 2) {
+        bnpc_set_error("bad argument: need S >= 1 samples of N >= 2 cells");
+        return 2;
+    }
+    *out = nullptr;
+    PCK(hipSetDevice(device));
+    bnpc_post *p = new bnpc_post();
+    p->device = device;
+    p->S = S;
+    p->N = N;
+    const size_t pairs = (size_t)N * (N - 1) / 2;
+    int *d_a = nullptr;
+    auto fail = [&]() {
+        if (d_a) (void)hipFree(d_a);
+        bnpc_post_destroy(p);
+        return 1;
+    };
+#define PF(expr)                                                             \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            bnpc_set_error("%s failed: %s", #expr, hipGetErrorString(e_));   \
+            return fail();                                                   \
+        }                                                                    \
+    } while (0)
+    PF(hipMalloc((void **)&d_a, (size_t)S * N * sizeof(int)));
+    PF(hipMalloc((void **)&p->differ, pairs * sizeof(int)));
+    PF(hipMalloc((void **)&p->sums, (1024 + 1) * sizeof(unsigned long long)));
+    PF(hipMemcpy(d_a, assignments, (size_t)S * N * sizeof(int),
+                 hipMemcpyHostToDevice));
+    const unsigned nt = (unsigned)((N + 63) / 64);
+    hipLaunchKernelGGL(k_codist, dim3(nt, nt), dim3(256), 0, 0, d_a,
+                       (long long)S, (long long)N, p->differ);
+    PF(hipGetLastError());
+    PF(hipMemsetAsync(p->sums, 0, sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(k_differ_sum, dim3(1024), dim3(256), 0, 0, p->differ,
+                       (long long)pairs, p->sums);
+    PF(hipGetLastError());
+    unsigned long long total = 0;
+    PF(hipMemcpy(&total, p->sums, sizeof total, hipMemcpyDeviceToHost));
+    (void)hipFree(d_a);
+    d_a = nullptr;
+#undef PF
+    if (differ_sum) *differ_sum = (int64_t)total;
+    *out = p;
+    return 0;
+}
+
+// condensed pair counts / mean distances to the host (either may be NULL)
+extern "C" int bnpc_post_fetch(bnpc_post *p, int32_t *differ, double *dist)
+{
+    if (!p) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    PCK(hipSetDevice(p->device));
+    const size_t pairs = (size_t)p->N * (p->N - 1) / 2;
+    if (differ)
+        PCK(hipMemcpy(differ, p->differ, pairs * sizeof(int),
+                      hipMemcpyDeviceToHost));
+    if (dist) {
+        // in slabs: the float64 form is twice the counts (10 GB at 50 000)
+        const size_t slab = (size_t)64 << 20;           // elements
+        double *d_slab = nullptr;
+        PCK(hipMalloc((void **)&d_slab, std::min(slab, pairs) * sizeof(double)));
+        for (size_t at = 0; at < pairs; at += slab) {
+            const size_t n = std::min(slab, pairs - at);
+            hipLaunchKernelGGL(k_differ_to_dist, dim3(2048), dim3(256), 0, 0,
+                               p->differ + at, (long long)n, (double)p->S,
+                               d_slab);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess)
+                e = hipMemcpy(dist + at, d_slab, n * sizeof(double),
+                              hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                bnpc_set_error("mean distance: %s", hipGetErrorString(e));
+                (void)hipFree(d_slab);
+                return 1;
+            }
+        }
+        (void)hipFree(d_slab);
+    }
+    return 0;
+}
+
+// same_differ[c] = sum over pairs i < j with labels[c][i] == labels[c][j] of
+// differ_ij, for C candidate clusterings (labels < 65534)
+extern "C" int bnpc_post_mpear(bnpc_post *p, const uint16_t *labels, int64_t C,
+                               int64_t *same_differ)
+{
+    if (!p || !labels || !same_differ || C < 1 || C > 1024) {
+        bnpc_set_error("bad argument: mpear sums of 1..1024 candidates");
+        return 2;
+    }
+    PCK(hipSetDevice(p->device));
+    unsigned short *d_lab = nullptr;
+    const size_t bytes = (size_t)C * p->N * sizeof(unsigned short);
+    PCK(hipMalloc((void **)&d_lab, bytes));
+    hipError_t e = hipMemcpy(d_lab, labels, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemset(p->sums, 0, 1025 * sizeof(unsigned long long));
+    const int CP = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
+    for (int c0 = 0; e == hipSuccess && c0 < C; c0 += CP) {
+        hipLaunchKernelGGL(k_mpear_sums, dim3(1024), dim3(256), 0, 0,
+                           p->differ, (long long)p->N, d_lab, c0, (int)C, CP,
+                           p->sums + 1);
+        e = hipGetLastError();
+    }
+    unsigned long long host[1024];
+    if (e == hipSuccess)
+        e = hipMemcpy(host, p->sums + 1, C * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost);
+    (void)hipFree(d_lab);
+    if (e != hipSuccess) {
+        bnpc_set_error("mpear sums: %s", hipGetErrorString(e));
+        return 1;
+    }
+    for (int64_t c = 0; c < C; c++) same_differ[c] = (int64_t)host[c];
     return 0;
 }

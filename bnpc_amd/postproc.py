@@ -6,7 +6,9 @@ point estimates (:248-282) and the posterior estimator (:90-244: mean
 co-clustering distance, MPEAR-selected Ward clustering, averaged cluster
 genotypes).  The O(samples x cells^2) co-clustering distance - the next
 data-parallel kernel after the likelihood path (SURVEY.md section 8(f) rank
-4) - runs on the GPU (bnpc_codist); the rest is O(cells^2) SciPy on the host.
+4) - and the MPEAR score of every candidate cut run on the GPU (bnpc_post:
+the pair counts stay there, each candidate is one term of ONE pass over
+them); Ward's linkage and the tree cuts are SciPy on the host.
 Metrics (V-measure, ARI, Hamming) and tree helpers are out of scope.
 """
 import numpy as np
@@ -79,7 +81,7 @@ def get_dist(assignments):
     pdist order (utils.py:90-97); exact integer counts from the GPU."""
     from bnpc_amd import _lib
     differ = _lib.codist(assignments)
-    return differ / assignments.shape[0]
+    return differ / np.asarray(assignments).shape[0]
 
 
 def _same_cluster(labels):
@@ -110,23 +112,65 @@ def calc_MPEAR(pi, labels):
         / (.5 * (I_sum + pi_sum) - expected)
 
 
+def mpear_scores(same_differ, labels, differ_sum, S):
+    """MPEAR (Fritsch & Ickstadt 2009, eq. 13; utils.py:133-145) of C
+    candidate clusterings from exact integers: with pi = 1 - differ / S over
+    the P pairs,
+        I_sum  = pairs that share a label        (from the label counts)
+        pi_sum = P - differ_sum / S
+        index  = sum of pi over those pairs = I_sum - same_differ / S.
+    labels: (C, N)."""
+    from scipy.special import binom
+    labels = np.asarray(labels)
+    N = labels.shape[1]
+    P = binom(N, 2)
+    pi_sum = P - differ_sum / S
+    scores = np.empty(labels.shape[0])
+    for c, lab in enumerate(labels):
+        n_k = np.bincount(lab).astype(np.float64)
+        I_sum = float((n_k * (n_k - 1) / 2).sum())
+        index = I_sum - same_differ[c] / S
+        expected = (I_sum * pi_sum) / P
+        scores[c] = (index - expected) / (.5 * (I_sum + pi_sum) - expected)
+    return scores
+
+
 def get_MPEAR(assignments, dist=None):
     """Ward tree on the mean distance, cut where MPEAR is largest
-    (utils.py:100-130)."""
+    (utils.py:100-130).  Product path (dist is None): the pair counts are
+    made and kept on the device, the mean distance comes to the host once
+    for the linkage, and ALL candidate cuts are scored in one device pass
+    over the counts (bnpc_post_mpear) - the float64 similarity `1 - dist`
+    and the reference's pass over it per candidate are never made.  With a
+    given `dist` the scores are evaluated on the host (calc_MPEAR)."""
     from scipy.cluster.hierarchy import cut_tree, linkage
+    from bnpc_amd import _lib
+    assignments = np.asarray(assignments)
+    post = None
     if dist is None:
-        dist = get_dist(assignments)
-    sim = 1 - dist
+        post = _lib.Posterior(assignments)
+        dist = post.dist()
     tree = linkage(dist, method='ward')
     sizable = [int((np.unique(a, return_counts=True)[1] > 2).sum())
         for a in assignments]
     avg = np.mean(sizable)
     candidates = np.arange(max(2, avg * 0.2),
         min(avg * 2.5, assignments.shape[1]), dtype=int)
-    best, best_score = None, -np.inf
     # one pass over the tree yields every cut (SciPy walks the whole tree in
     # Python for each call - 0.8 s at 10000 cells - whatever it is asked for)
     cuts = cut_tree(tree, n_clusters=candidates)
+    if post is not None:
+        del dist
+        labels = np.ascontiguousarray(cuts.T)
+        try:
+            scores = mpear_scores(post.mpear_sums(labels), labels,
+                post.differ_sum, assignments.shape[0])
+        finally:
+            post.close()
+        # first maximum, as the reference's strict `>` keeps it
+        return np.ascontiguousarray(cuts[:, int(np.argmax(scores))])
+    sim = 1 - dist
+    best, best_score = None, -np.inf
     for col in range(candidates.size):
         labels = np.ascontiguousarray(cuts[:, col])
         score = calc_MPEAR(sim, labels)

@@ -617,6 +617,24 @@ int bnpc_parse_matrix(const char *path, char sep, int skip_rows,
 int bnpc_codist(int device, const int32_t *assignments, int64_t S, int64_t N,
                 int32_t *differ);
 
+/* The posterior estimator as a device pipeline (libs/utils.py:90-145): the
+ * pair counts of bnpc_codist stay on the device (bnpc_post); the mean
+ * distance differ / S is fetched once for SciPy's Ward linkage; every
+ * candidate cut of the tree is then scored in ONE pass over the counts:
+ * bnpc_post_mpear returns, per candidate clustering,
+ *   same_differ[c] = sum over pairs i < j with equal labels of differ_ij
+ * (int64, exact, order-free), from which MPEAR (Fritsch & Ickstadt 2009, eq.
+ * 13) follows with the label counts and *differ_sum - the float64 similarity
+ * matrix `pi` and the reference's O(N^2) pass per candidate are never made.
+ * labels: C x N uint16, candidate-major. */
+typedef struct bnpc_post bnpc_post;
+int bnpc_post_create(int device, const int32_t *assignments, int64_t S,
+                     int64_t N, bnpc_post **out, int64_t *differ_sum);
+int bnpc_post_fetch(bnpc_post *post, int32_t *differ, double *dist);
+int bnpc_post_mpear(bnpc_post *post, const uint16_t *labels, int64_t C,
+                    int64_t *same_differ);
+int bnpc_post_destroy(bnpc_post *post);
+
 #ifdef __cplusplus
 }
 #endif

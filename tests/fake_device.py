@@ -198,3 +198,34 @@ def attach(model):
     """Give a bnpc_amd.model instance a FakeContext instead of a GPU."""
     model._ctx = FakeContext(data=model.data)
     return model
+
+
+class FakePosterior:
+    """NumPy stand-in for _lib.Posterior (bnpc_post) on the CPU."""
+
+    def __init__(self, assignments, device=None):
+        from scipy.spatial.distance import pdist
+        a = np.asarray(assignments)
+        self.S, self.N = a.shape
+        self._differ = np.zeros(self.N * (self.N - 1) // 2, dtype=np.int32)
+        for row in a:
+            self._differ += pdist(np.stack([row, row]).T, 'hamming') \
+                .astype(np.int32)
+        self.differ_sum = int(self._differ.astype(np.int64).sum())
+
+    def differ(self):
+        return self._differ.copy()
+
+    def dist(self):
+        return self._differ / self.S
+
+    def mpear_sums(self, labels):
+        from scipy.spatial.distance import pdist
+        out = np.empty(len(labels), dtype=np.int64)
+        for c, lab in enumerate(np.asarray(labels)):
+            same = pdist(np.stack([lab, lab]).T, 'hamming') == 0
+            out[c] = self._differ[same].astype(np.int64).sum()
+        return out
+
+    def close(self):
+        pass

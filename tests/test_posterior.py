@@ -73,8 +73,10 @@ def test_product_posterior_host_logic(G, monkeypatch):
     """The product's estimator with the device kernel replaced by the exact
     NumPy counts: the reference's clustering and genotypes."""
     g, results, data = G
+    from fake_device import FakePosterior
     monkeypatch.setattr(_lib, 'codist',
         lambda a, device=None: differ_counts(np.asarray(a)))
+    monkeypatch.setattr(_lib, 'Posterior', FakePosterior)
     inf = postproc.posterior_estimate(results, data)
     assert np.array_equal(inf['assignment'], g['mean0_assignment'])
     assert np.array_equal(inf['genotypes'].T, g['mean0_genotypes'])
@@ -93,6 +95,53 @@ def test_codist_kernel_is_exact(S, N, K):
     assert got.dtype == np.int32
     assert np.array_equal(got, differ_counts(a))
     assert np.array_equal(postproc.get_dist(a), Q.get_dist(a))
+
+
+def test_mpear_from_integers_picks_the_references_cut(G):
+    """The scores the pipeline computes from exact integers (label counts,
+    the sum of the pair counts, per candidate the sum over its same-label
+    pairs) against the reference-order float evaluation (calc_MPEAR) on the
+    golden samples: equal to 1e-12, same winning cut."""
+    from fake_device import FakePosterior
+    from scipy.cluster.hierarchy import cut_tree, linkage
+    g, results, data = G
+    a0 = results[0]['assignments'][results[0]['burn_in']:]
+    post = FakePosterior(a0)
+    dist = post.dist()
+    assert np.array_equal(dist, g['dist0'])
+    tree = linkage(dist, method='ward')
+    cand = np.arange(2, 12)
+    labels = np.ascontiguousarray(cut_tree(tree, n_clusters=cand).T)
+    got = postproc.mpear_scores(post.mpear_sums(labels), labels,
+        post.differ_sum, a0.shape[0])
+    want = [postproc.calc_MPEAR(1 - dist, lab) for lab in labels]
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    assert int(np.argmax(got)) == int(np.argmax(want))
+    assert np.array_equal(postproc.get_MPEAR(a0, dist=dist), g['mpear0'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,N,K,C', [(5, 2, 2, 1), (33, 63, 4, 3),
+    (64, 130, 3, 40), (100, 65, 7, 70), (37, 300, 12, 130), (120, 1000, 10, 29)])
+def test_posterior_pipeline_on_device_is_exact(S, N, K, C):
+    """bnpc_post: the pair counts kept on the device equal the oracle's, their
+    sum and the mean distance (divided on the device) equal NumPy's bit for
+    bit, and the per-candidate sums over same-label pairs (k_mpear_sums: 1,
+    2 or 3 candidate chunks, tiles on and off the diagonal, ragged edges)
+    equal the direct integer evaluation."""
+    from fake_device import FakePosterior
+    rng = np.random.RandomState(S * 1000 + N)
+    a = rng.randint(0, K, size=(S, N))
+    a[:, : N // 3] = a[:, :1]
+    post, ref = _lib.Posterior(a), FakePosterior(a)
+    try:
+        assert np.array_equal(post.differ(), ref.differ())
+        assert post.differ_sum == ref.differ_sum
+        assert np.array_equal(post.dist(), ref.dist())
+        labels = rng.randint(0, rng.randint(1, 40, size=(C, 1)), size=(C, N))
+        assert np.array_equal(post.mpear_sums(labels), ref.mpear_sums(labels))
+    finally:
+        post.close()
 
 
 @pytest.mark.gpu

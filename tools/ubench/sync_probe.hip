@@ -64,5 +64,45 @@ int main()
             printf("sync only:               launch call %.2f us, sync returned %.2f us\n",
                    med(t_launch), med(t_sync));
     }
+    // mode 2: the kernel does NOT write the flag; the stream does, behind it
+    // (hipStreamWriteValue32: a command-processor write, no launch) and the
+    // host spins on that word instead of calling hipStreamSynchronize
+    {
+        std::vector<double> t_launch, t_flag;
+        unsigned *other;
+        hipHostMalloc(&other, 64, hipHostMallocDefault);
+        unsigned *dother;
+        hipHostGetDevicePointer((void **)&dother, other, 0);
+        bool ok = true;
+        for (unsigned r = 1; r <= 2000 && ok; r++) {
+            flag[0] = 0;
+            double t0 = now();
+            hipLaunchKernelGGL(k_flag, dim3(1), dim3(64), 0, s, dother, r, 2000);
+            if (hipStreamWriteValue32(s, dflag, r, 0) != hipSuccess) {
+                printf("hipStreamWriteValue32 failed: %s\n",
+                       hipGetErrorString(hipGetLastError()));
+                ok = false;
+                break;
+            }
+            double t1 = now();
+            while (*(volatile unsigned *)flag != r) {}
+            double tf = now();
+            if (other[0] != r) {
+                printf("stream write overtook the kernel's store at %u\n", r);
+                ok = false;
+            }
+            if (r > 100) {
+                t_launch.push_back(t1 - t0);
+                t_flag.push_back(tf - t0);
+            }
+        }
+        if (ok) {
+            std::sort(t_launch.begin(), t_launch.end());
+            std::sort(t_flag.begin(), t_flag.end());
+            printf("stream write value, spin:  launch + write calls %.2f us, "
+                   "flag seen %.2f us after the launch began\n",
+                   t_launch[t_launch.size() / 2], t_flag[t_flag.size() / 2]);
+        }
+    }
     return 0;
 }
