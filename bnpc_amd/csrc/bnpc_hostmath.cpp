@@ -136,13 +136,17 @@ private:
     {
         uint32_t seen = 0;      // the word before the first job (a worker
                                 // may start after that job was posted)
+        bool worked = false;    // a rank the last job did not want parks at
+                                // once: only the ranks in use spin for the
+                                // next job (a wake-up reaches every sleeper)
         for (;;) {
             uint32_t w;
             const long t0 = now_ns();
+            const long spin = worked ? spin_ns_ : 0;
             int polls = 0;
             while ((w = word_.load(std::memory_order_acquire)) == seen) {
                 cpu_relax();
-                if ((++polls & 63) == 0 && now_ns() - t0 > spin_ns_) {
+                if ((++polls & 63) == 0 && now_ns() - t0 > spin) {
                     sleepers_.fetch_add(1, std::memory_order_seq_cst);
                     // re-checked by the kernel: returns at once if the word
                     // has moved on
@@ -152,7 +156,8 @@ private:
                 }
             }
             seen = w;
-            if (rank < (int)(w & 0xff)) {
+            worked = rank < (int)(w & 0xff);
+            if (worked) {
                 // (published before the word: the acquire load above pairs
                 // with the seq_cst store in run())
                 (*job_.load(std::memory_order_relaxed))(rank);
