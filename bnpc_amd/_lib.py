@@ -173,6 +173,7 @@ SIGNATURES = {
         C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     'bnpc_post_fetch': (C.c_int, [C.c_void_p, _pi32, _pd]),
     'bnpc_post_mpear': (C.c_int, [C.c_void_p, C.c_void_p, _i64, _pi64]),
+    'bnpc_post_ward': (C.c_int, [C.c_void_p, _pd]),
     'bnpc_post_destroy': (C.c_int, [C.c_void_p]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
@@ -385,6 +386,35 @@ def codist(assignments, device=None):
     return out
 
 
+def ward_finish(raw, n):
+    """nn_chain's epilogue: Z = raw[argsort(height, stable)], then `label`:
+    the two children of merge i become the current roots of the slots it
+    names (smaller root first), the merged cluster gets id n + i and the
+    union's size."""
+    Z = raw[np.argsort(raw[:, 2], kind='mergesort')]
+    parent = np.arange(2 * n - 1, dtype=np.int64)
+    sizes = np.ones(2 * n - 1, dtype=np.int64)
+    lo = Z[:, 0].astype(np.int64)
+    hi = Z[:, 1].astype(np.int64)
+
+    def find(x):
+        p = x
+        while parent[x] != x:
+            x = parent[x]
+        while parent[p] != x:
+            p, parent[p] = parent[p], x
+        return x
+    for i in range(n - 1):
+        a, b = find(lo[i]), find(hi[i])
+        if a > b:
+            a, b = b, a
+        Z[i, 0], Z[i, 1] = a, b
+        parent[a] = parent[b] = n + i
+        sizes[n + i] = sizes[a] + sizes[b]
+        Z[i, 3] = sizes[n + i]
+    return Z
+
+
 class Posterior:
     """Device-resident pair counts of a set of posterior samples (bnpc_post):
     differ[(i, j)] = samples in which cells i and j carry different labels,
@@ -416,6 +446,17 @@ class Posterior:
         out = np.empty(self.pairs, dtype=np.float64)
         check(load().bnpc_post_fetch(self._h, None, ptr(out)), 'post_fetch')
         return out
+
+    def ward(self):
+        """scipy.cluster.hierarchy.linkage(self.dist(), method='ward'): the
+        nearest-neighbour chain on the device (bnpc_post_ward), then SciPy's
+        own last two steps - the stable sort of the merges by height and the
+        relabelling of the clusters (scipy/cluster/_hierarchy.pyx: nn_chain,
+        label, LinkageUnionFind) - on the host."""
+        n = self.N
+        raw = np.empty((n - 1, 4), dtype=np.float64)
+        check(load().bnpc_post_ward(self._h, ptr(raw)), 'post_ward')
+        return ward_finish(raw, n)
 
     def mpear_sums(self, labels):
         """labels: (C, N) integer array of C candidate clusterings ->

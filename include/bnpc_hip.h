@@ -633,6 +633,13 @@ int bnpc_post_create(int device, const int32_t *assignments, int64_t S,
 int bnpc_post_fetch(bnpc_post *post, int32_t *differ, double *dist);
 int bnpc_post_mpear(bnpc_post *post, const uint16_t *labels, int64_t C,
                     int64_t *same_differ);
+/* Ward linkage of the mean distances (`linkage(dist, method='ward')`,
+ * libs/utils.py:104) on the device: SciPy's nearest-neighbour-chain algorithm
+ * (scipy/cluster/_hierarchy.pyx nn_chain + _ward) inside one launch, the
+ * float64 distance vector never leaving the device.  Z_raw[(N - 1) x 4]: the
+ * merges in the order the chain makes them (slot indices x < y, height, size);
+ * the binding applies SciPy's final stable sort by height and relabelling. */
+int bnpc_post_ward(bnpc_post *post, double *Z_raw);
 int bnpc_post_destroy(bnpc_post *post);
 
 #ifdef __cplusplus

@@ -219,6 +219,10 @@ class FakePosterior:
     def dist(self):
         return self._differ / self.S
 
+    def ward(self):
+        from scipy.cluster.hierarchy import linkage
+        return linkage(self.dist(), method='ward')
+
     def mpear_sums(self, labels):
         from scipy.spatial.distance import pdist
         out = np.empty(len(labels), dtype=np.int64)

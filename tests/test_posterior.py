@@ -97,6 +97,30 @@ def test_codist_kernel_is_exact(S, N, K):
     assert np.array_equal(postproc.get_dist(a), Q.get_dist(a))
 
 
+def test_cut_tree_labels_equal_scipys():
+    """postproc.cut_tree_labels against scipy.cluster.hierarchy.cut_tree on
+    Ward / average / single trees of random points incl. duplicated points
+    (tied merges) and every cluster count from 1 to N - 1 (asked for N
+    clusters TOGETHER with other counts, SciPy returns zeros - its row 0 quirk;
+    alone it returns the identity, as here; the estimator's candidate range
+    ends below N either way)."""
+    from scipy.cluster.hierarchy import cut_tree, linkage
+    rng = np.random.RandomState(4)
+    for N, method in ((2, 'ward'), (7, 'ward'), (60, 'ward'), (60, 'average'),
+            (133, 'single'), (300, 'ward')):
+        pts = rng.normal(size=(N, 3))
+        pts[N // 2:] = pts[: N - N // 2] + (rng.random_sample((N - N // 2, 3))
+            < 0.5) * 0.1                    # near / exact duplicates
+        tree = linkage(pts, method=method)
+        counts = np.arange(1, N) if N <= 133 else \
+            np.array([1, 2, 3, 10, 50, 298, 299])
+        want = cut_tree(tree, n_clusters=counts)
+        got = postproc.cut_tree_labels(tree, counts)
+        assert np.array_equal(got, want), (N, method)
+        assert np.array_equal(postproc.cut_tree_labels(tree, [N]),
+            cut_tree(tree, n_clusters=[N]))
+
+
 def test_mpear_from_integers_picks_the_references_cut(G):
     """The scores the pipeline computes from exact integers (label counts,
     the sum of the pair counts, per candidate the sum over its same-label
@@ -140,6 +164,32 @@ def test_posterior_pipeline_on_device_is_exact(S, N, K, C):
         assert np.array_equal(post.dist(), ref.dist())
         labels = rng.randint(0, rng.randint(1, 40, size=(C, 1)), size=(C, N))
         assert np.array_equal(post.mpear_sums(labels), ref.mpear_sums(labels))
+    finally:
+        post.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,N,K', [(5, 2, 2), (7, 3, 2), (33, 63, 4),
+    (64, 130, 3), (100, 65, 7), (37, 300, 12), (120, 1000, 10), (400, 2500, 9)])
+def test_ward_linkage_on_device_is_scipys(S, N, K):
+    """bnpc_post_ward + the binding's sort / relabel against
+    scipy.cluster.hierarchy.linkage(dist, 'ward') on mean co-clustering
+    distances - discrete values k / S with MANY exact ties, blocks of cells
+    at distance 0: the same linkage matrix bit for bit (children, heights,
+    sizes), hence the same tree cuts."""
+    from scipy.cluster.hierarchy import linkage
+    rng = np.random.RandomState(S * 1000 + N)
+    a = rng.randint(0, K, size=(S, N))
+    a[:, : N // 3] = a[:, :1]               # always together: distance 0
+    noise = rng.random_sample((S, N)) < 0.3
+    base = rng.randint(0, K, N)
+    a = np.where(noise, a, base[None, :])
+    a[:, : N // 3] = a[:, :1]
+    post = _lib.Posterior(a)
+    try:
+        want = linkage(post.dist(), method='ward')
+        got = post.ward()
+        assert np.array_equal(got, want)
     finally:
         post.close()
 

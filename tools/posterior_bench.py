@@ -33,16 +33,20 @@ print(f'N={N} S={S} C={C}: {N * (N - 1) // 2:.3e} pairs')
 t0 = t_all = time.perf_counter()
 post = _lib.Posterior(a)
 t0 = lap('pair counts on the device (k_codist) + their sum', t0)
-dist = post.dist()
-t0 = lap('mean distance divided on the device -> host f64', t0)
-tree = linkage(dist, method='ward')
-t0 = lap('Ward linkage (SciPy, host)', t0)
-del dist
+tree = post.ward()
+t0 = lap('Ward linkage on the device (k_ward_nnchain) + relabel', t0)
+if os.environ.get('WARD_CHECK'):
+    dist = post.dist()
+    t0 = lap('mean distance divided on the device -> host f64', t0)
+    want = linkage(dist, method='ward')
+    t0 = lap('Ward linkage (SciPy, host)', t0)
+    print('  device linkage == SciPy linkage:', np.array_equal(tree, want))
+    del dist
 sizable = [int((np.unique(r, return_counts=True)[1] > 2).sum()) for r in a]
 avg = np.mean(sizable)
 cand = np.arange(max(2, avg * 0.2), min(avg * 2.5, N), dtype=int)
-cuts = cut_tree(tree, n_clusters=cand)
-t0 = lap(f'cut_tree for {cand.size} candidates (SciPy, host)', t0)
+cuts = postproc.cut_tree_labels(tree, cand)
+t0 = lap(f'tree cuts for {cand.size} candidates (cut_tree_labels)', t0)
 labels = np.ascontiguousarray(cuts.T)
 sums = post.mpear_sums(labels)
 t0 = lap(f'MPEAR sums of {cand.size} candidates (k_mpear_sums)', t0)
