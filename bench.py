@@ -370,7 +370,14 @@ def main():
         roofline_converged['note'] = (
             'the evaluation inside the timed region (K = K_end): a few '
             'microseconds of work, latency-bound; eval_ms = element tables + '
-            'sums + combine')
+            'sums + combine; traffic: mean per launch of the split sums '
+            'kernel + the combine pass over the bench run of the PMC passes')
+        if args.config == 'c3':
+            parts = [load_pmc_traffic(name) for name in
+                ('k_ll8_asm<2, true>', 'k_ll_combine')]
+            if all(p[0] is not None for p in parts):
+                roofline_converged['traffic'] = sum(p[0] for p in parts)
+                roofline_converged['traffic_source'] = parts[0][1]
         for Kc in sorted({10, 64, K_end}):
             r, ev = ll_roofline(ctx, rng, N, M, Kc, max(20, args.kernel_reps))
             extra[f'll_evals_per_s_K{Kc}'] = ev
