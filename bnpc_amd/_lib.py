@@ -42,7 +42,13 @@ class GibbsState(C.Structure):
         ('pos_end', _i64), ('row_base', _i64), ('threads', _i64),
         ('hint', C.c_void_p), ('hint_prior', C.c_void_p), ('hint_cols', _i64),
         ('hint_used', _i64), ('matrix_wait', C.c_void_p),
-        ('matrix_wait_arg', C.c_void_p), ('pair_used', _i64)]
+        ('matrix_wait_arg', C.c_void_p), ('pair_used', _i64),
+        ('birth_ctx', C.c_void_p), ('birth_view', C.c_int32),
+        ('birth_put', C.c_int32), ('birth_rows', _i64),
+        ('theta_host', C.c_void_p), ('beta_p', C.c_double),
+        ('beta_q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
+        ('FP', C.c_double), ('FN', C.c_double), ('gauss', C.c_void_p),
+        ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64)]
 
 
 class MHArgs(C.Structure):

@@ -20,6 +20,14 @@ int bnpc_team_ranks(int threads);
 int bnpc_team_run(int threads, const std::function<void(int)> &fn);
 #endif
 
+// bnpc_kernels.hip: the {ones, zeros} 64-bit words of one cell's row
+// (W pairs), or NULL
+const unsigned long long *bnpc_ctx_row(const bnpc_ctx *c, int64_t cell,
+                                       int64_t *M, int *W);
+// bnpc_mt.cpp: one legacy Beta draw on the stream (NumPy's legacy_beta)
+double bnpc_legacy_beta1(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double a,
+                         double b);
+
 // bnpc_kernels.hip: counts of the two launch clusters of a restricted scan +
 // the (screened) parameter batch on one stream synchronisation
 int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,

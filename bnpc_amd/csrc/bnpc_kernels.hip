@@ -150,6 +150,9 @@ struct bnpc_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ulonglong2 *rows = nullptr;           // [N][W]
+    std::vector<ulonglong2> host_rows;    // the same words on the host: the
+                                          // observations of ONE cell shape the
+                                          // Beta draws of a cluster it opens
     std::vector<int32_t> cell_n1, cell_n0;
     View views[BNPC_MAX_VIEWS];
     // scratch
@@ -1695,6 +1698,7 @@ static int create_from_planes(int device, int64_t N, int64_t M,
         }                                                                    \
     } while (0)
     const size_t bytes = (size_t)N * c->W * sizeof(ulonglong2);
+    c->host_rows.assign(rows, rows + (size_t)N * c->W);
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRCHK(hipEventCreate(&c->ev0));
     CRCHK(hipEventCreate(&c->ev1));
@@ -1834,6 +1838,17 @@ extern "C" int bnpc_shape(const bnpc_ctx *c, int64_t *N, int64_t *M)
     if (N) *N = c->N;
     if (M) *M = c->M;
     return 0;
+}
+
+// the {ones, zeros} words of one cell's row (bnpc_sweeps.cpp: native births)
+const unsigned long long *bnpc_ctx_row(const bnpc_ctx *c, int64_t cell,
+                                       int64_t *M, int *W)
+{
+    if (!c || cell < 0 || cell >= c->N || c->host_rows.empty()) return nullptr;
+    if (M) *M = c->M;
+    if (W) *W = c->W;
+    return (const unsigned long long *)(c->host_rows.data()
+                                        + (size_t)cell * c->W);
 }
 
 extern "C" int bnpc_cell_counts(bnpc_ctx *c, int32_t *n1, int32_t *n0)

@@ -232,6 +232,12 @@ inline double lg_beta(bnpc_mt19937 *s, bnpc_legacy_gauss *g, double a,
 
 }  // namespace
 
+double bnpc_legacy_beta1(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double a,
+                         double b)
+{
+    return lg_beta(rng, g, a, b);
+}
+
 extern "C" int bnpc_mt_beta(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t n,
                             const double *a, const double *b, double *out)
 {

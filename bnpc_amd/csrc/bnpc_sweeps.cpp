@@ -273,6 +273,63 @@ struct ParScan {
 
 }  // namespace
 
+// CRP.init_new_cluster for one cell (libs/CRP.py:291-299 with :183-188): the
+// lowest free id; its profile: per mutation Beta(p + [x = 1], q + [x = 0])
+// from the cell's own observations (NaN adds nothing), NumPy's legacy sampler
+// on the stream, clipped, float32; the new column of ll from the device.
+static int open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng, int64_t cell,
+                        double *ll, int64_t *assignment, int64_t *col_of_id,
+                        int64_t *col_id, int64_t *col_size, int64_t *order,
+                        int64_t *free_hint)
+{
+    int64_t M = 0;
+    int W = 0;
+    const unsigned long long *row = bnpc_ctx_row(st->birth_ctx, cell, &M, &W);
+    if (!row || !st->theta_host || !st->gauss || !st->born) {
+        bnpc_set_error("bad argument: native birth is not set up");
+        return 2;
+    }
+    int64_t id = *free_hint;
+    while (id < st->n_cells && col_of_id[id] >= 0) id++;
+    if (id >= st->n_cells) {
+        bnpc_set_error("no free cluster id");
+        return 3;
+    }
+    *free_hint = id + 1;
+    float *theta = st->theta_host + (size_t)id * M;
+    bnpc_legacy_gauss *g = (bnpc_legacy_gauss *)st->gauss;
+    for (int64_t m = 0; m < M; m++) {
+        const unsigned long long one = (row[2 * (m >> 6)] >> (m & 63)) & 1ull;
+        const unsigned long long zero =
+            (row[2 * (m >> 6) + 1] >> (m & 63)) & 1ull;
+        double v = bnpc_legacy_beta1(rng, g, st->beta_p + (double)one,
+                                     st->beta_q + (double)zero);
+        v = v < st->tmin ? st->tmin : (v > st->tmax ? st->tmax : v);
+        theta[m] = (float)v;
+    }
+    if (st->birth_put) {
+        const int rc = bnpc_theta_put(st->birth_ctx, id, theta, 1);
+        if (rc) return rc;
+    }
+    static thread_local std::vector<double> column;
+    column.resize((size_t)st->birth_rows);
+    const int rc = bnpc_ll_theta(st->birth_ctx, st->birth_view, theta, 1,
+                                 st->FP, st->FN, column.data(), 1);
+    if (rc) return rc;
+    const int64_t col = st->n_cols, ld = st->ld;
+    for (int64_t r = 0; r < st->birth_rows; r++)
+        ll[(size_t)r * ld + col] = column[(size_t)r];
+    col_id[col] = id;
+    col_size[col] = 1;
+    col_of_id[id] = col;
+    order[st->n_active] = col;
+    st->n_active++;
+    st->n_cols++;
+    assignment[cell] = id;
+    st->born[st->n_born++] = id;
+    return 0;
+}
+
 static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                         const int64_t *perm, const double *ll,
                         const double *post_new, const double *crp_prior,
@@ -353,6 +410,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         if (d_ > drift) drift = d_;                                           \
     }
 
+    int64_t free_hint = 0;      // no id below it is free (native births)
     while (st->pos < st->pos_end) {
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
@@ -410,6 +468,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             st->n_active--;
             col_size[old_col] = 0;
             col_of_id[old_id] = -1;
+            if (old_id < free_hint) free_hint = old_id;
             if (hint) index_live();
         } else {
             col_size[old_col]--;
@@ -663,9 +722,21 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         if (pick > A) pick = A;
 
         st->pos++;
-        if (pick == A) {                  // open a new cluster in the caller
-            st->new_cell = cell;
-            return 0;
+        if (pick == A) {
+            // a new cluster: opened here when the call is equipped for it
+            // and has room, else in the caller
+            if (!st->birth_ctx || st->n_cols >= ld
+                || st->n_born >= st->born_cap) {
+                st->new_cell = cell;
+                return 0;
+            }
+            NEED_MATRIX()           // its column is about to be written
+            const int rc = open_cluster(st, rng, cell, (double *)ll,
+                                        assignment, col_of_id, col_id,
+                                        col_size, order, &free_hint);
+            if (rc) return rc;
+            cpr[st->n_cols - 1] = crp_prior[1];
+            continue;
         }
         const int64_t c = order[pick];
         assignment[cell] = col_id[c];

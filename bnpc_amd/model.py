@@ -842,8 +842,31 @@ class CRP:
                 st.matrix_wait, st.matrix_wait_arg = hook()
         i64, f64 = C.c_int64, C.c_double
         born = []
+        # clusters are opened INSIDE the native loop (lowest free id, Beta
+        # draws of the profile on the same stream, the new column from the
+        # device) when the context is a real one and the native sampler has
+        # passed its comparison; the Python branch below remains for the
+        # births the call cannot make itself (no spare column left)
+        theta = self.parameters
+        native_births = bool(getattr(ctx, '_h', None)) and _native_beta() \
+            and os.environ.get('BNPC_NATIVE_BIRTHS', '1') != '0' \
+            and theta.dtype == np.float32 and theta.flags['C_CONTIGUOUS'] \
+            and theta.shape[1] == self.muts_total
+        if native_births:
+            born_buf = np.empty(256, dtype=np.int64)
+            st.birth_ctx = ctx._h
+            st.birth_view = view
+            st.birth_put = 0 if whole else 1
+            st.birth_rows = n_rows
+            st.theta_host = theta.ctypes.data
+            st.beta_p, st.beta_q = float(self.p), float(self.q)
+            st.tmin, st.tmax = TMIN, TMAX
+            st.FP, st.FN = float(self.FP), float(self.FN)
+            st.born, st.born_cap = born_buf.ctypes.data, born_buf.size
         while True:
-            with _lib.NumpyStream() as rng:
+            st.n_born = 0
+            with _lib.NumpyGaussStream() as (rng, gauss):
+                st.gauss = gauss if native_births else None
                 _lib.check(lib.bnpc_gibbs_sweep(C.byref(st), rng,
                     _lib.ptr(perm, i64), _lib.ptr(ll, f64),
                     _lib.ptr(post_new, f64), _lib.ptr(crp_prior, f64),
@@ -851,6 +874,8 @@ class CRP:
                     _lib.ptr(col_id, i64), _lib.ptr(col_size, i64),
                     _lib.ptr(order, i64), _lib.ptr(scratch, f64)),
                     'gibbs_sweep')
+            if native_births and st.n_born:
+                born.extend(int(i) for i in born_buf[:st.n_born])
             if st.new_cell < 0:
                 break
             if hint is not None:

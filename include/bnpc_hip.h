@@ -568,6 +568,22 @@ typedef struct bnpc_gibbs_state {
     void *matrix_wait_arg;
     int64_t pair_used;  /* out: of hint_used, cells decided between the row's
                          * two best columns (accumulated) */
+    /* Optional: clusters are OPENED inside the call (libs/CRP.py:281-282,
+     * 291-299, 183-188) instead of returning to the caller - the lowest free
+     * id, its profile row drawn with NumPy's legacy Beta sampler on the same
+     * stream from the one cell's observations (bnpc_mt_beta), written to
+     * theta_host[id], its column evaluated on the device and written into
+     * ll.  birth_ctx == NULL: off.  A birth the call cannot make (no spare
+     * column, born[] full) returns through new_cell as before. */
+    struct bnpc_ctx *birth_ctx;
+    int32_t birth_view;     /* the view whose slots are the rows of ll */
+    int32_t birth_put;      /* != 0: also store the row with bnpc_theta_put */
+    int64_t birth_rows;     /* rows of ll */
+    float *theta_host;      /* parameter rows, row = cluster id, stride M */
+    double beta_p, beta_q, tmin, tmax, FP, FN;
+    void *gauss;            /* bnpc_legacy_gauss of the stream */
+    int64_t *born;          /* out: ids opened in this call, in order */
+    int64_t born_cap, n_born;
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
