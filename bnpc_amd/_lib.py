@@ -113,6 +113,7 @@ SIGNATURES = {
     'bnpc_ll_theta_pinned_top2_issue': (C.c_int, [_ctx, C.c_int, _pf, _i64,
         C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
     'bnpc_matrix_wait': (C.c_int, [_ctx]),
+    'bnpc_hints_wait': (C.c_int, [_ctx]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, _ppd]),
@@ -1086,6 +1087,11 @@ class Context:
             return mat, None
         raw = (C.c_char * (n * TOP2.itemsize)).from_address(hint.value)
         return mat, np.frombuffer(raw, dtype=TOP2, count=n)
+
+    def hints_wait(self):
+        """The hints of the last ll_theta_pinned_top2(wait=False) are
+        complete."""
+        check(self._lib.bnpc_hints_wait(self._h), 'hints_wait')
 
     def matrix_wait(self):
         """The matrix of the last ll_theta_pinned_top2 is complete."""

@@ -103,6 +103,8 @@ struct Tunables {
     int seq_stage = 1;              // k_ll_seqp: tables copied to the device
     int seq_kc = 1;                 // clusters per wave in k_ll_seq
     int lazy_matrix = 1;            // sweep matrix copied behind the hints
+    int eager_matrix = 1;           // queue the sweep matrix's copy when the
+                                    // previous sweep needed it
     int mh_screen = 1;              // device screen of the parameter batches
     int mh_screen_min = 512;        // ... from this many elements on
 };
@@ -136,6 +138,7 @@ static void read_tunables(Tunables &t)
     t.seq_stage = env_int("BNPC_SEQ_STAGE", 1);
     t.seq_kc = env_int("BNPC_SEQ_KC", 1);
     t.lazy_matrix = env_int("BNPC_LAZY_MATRIX", 1);
+    t.eager_matrix = env_int("BNPC_EAGER_MATRIX", 1);
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
     t.mh_screen_min = env_int("BNPC_MH_SCREEN_MIN", 512);
 }
@@ -195,6 +198,12 @@ struct bnpc_ctx {
     hipEvent_t mh_ev[2] = {};
     int64_t screened = 0, screen_kept = 0;  // elements seen / left to the host
     size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
+    // ... unless the previous hinted sweep had to fetch it: then the copy is
+    // queued right behind the hint kernel and lands while the host prepares
+    // the sweep (a running chain scans ~9 % of its cells: it always needs it;
+    // a settled one never does)
+    bool matrix_eager = false, lazy_fetched = false, pin_copy_queued = false;
+    hipEvent_t ev_hints = nullptr;
     bool total_pending = false;     // a deferred bnpc_ll_total_issue
     int total_blocks = 0, total_E = 0;
     // where the kernels of the current call read their inputs from: device
@@ -456,6 +465,10 @@ static void d2h_finish(const D2H &t)
 
 static int ensure_pin(bnpc_ctx *c, size_t bytes)
 {
+    if (c->pin_copy_queued) {   // a queued copy still targets the buffer
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->pin_copy_queued = false;
+    }
     c->pin_lazy_bytes = 0;      // a new request supersedes a matrix not fetched
     if (bytes <= c->pin_cap) return 0;
     pinned_free(c->pin, c->pin_cap);
@@ -1817,6 +1830,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
         if (c->tile_out_free[s]) (void)hipEventDestroy(c->tile_out_free[s]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev_hints) (void)hipEventDestroy(c->ev_hints);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2389,6 +2403,9 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
            "not available while an issued tile is in flight");
     const size_t bytes = (size_t)n * ldo * sizeof(double);
     if (bytes && ensure_pin(c, bytes)) return 1;
+    // did the previous hinted sweep read its matrix?
+    c->matrix_eager = c->lazy_fetched;
+    c->lazy_fetched = false;
     int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
     if (rc) return rc;
     if (bytes == 0) {
@@ -2408,7 +2425,16 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
         // the caller gets the hints now; the matrix stays on the device and
         // is copied if and when the sweep first needs a row of it
         // (bnpc_matrix_wait) - a converged sweep never does
-        if (wait) HIPCHK(hipStreamSynchronize(c->stream));
+        if (!c->ev_hints)
+            HIPCHK(hipEventCreateWithFlags(&c->ev_hints,
+                                           hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_hints, c->stream));
+        if (c->matrix_eager && c->tun.eager_matrix) {
+            HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes,
+                                  hipMemcpyDeviceToHost, c->stream));
+            c->pin_copy_queued = true;
+        }
+        if (wait) HIPCHK(hipEventSynchronize(c->ev_hints));
         c->pin_lazy_bytes = bytes;
     } else {
         HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
@@ -2454,9 +2480,25 @@ extern "C" int bnpc_matrix_wait(bnpc_ctx *c)
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = c->pin_lazy_bytes;
     c->pin_lazy_bytes = 0;
-    HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
-                          c->stream));
+    c->lazy_fetched = true;
+    if (!c->pin_copy_queued)
+        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+    c->pin_copy_queued = false;
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The hints of the last bnpc_ll_theta_pinned_top2_issue are complete on
+// return (the matrix copy that may be queued behind them is not waited for).
+extern "C" int bnpc_hints_wait(bnpc_ctx *c)
+{
+    ARGCHK(c, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->ev_hints && c->pin_lazy_bytes)
+        HIPCHK(hipEventSynchronize(c->ev_hints));
+    else
+        HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -662,7 +662,7 @@ class CRP:
                     self.parameters[ids], self.FP, self.FN, ids.size + spare,
                     col_prior, wait=False)
                 perm, assignment = self._sweep_order(N)
-                ctx.sync()
+                ctx.hints_wait()
                 if top2 is not None:
                     hint = (top2, col_prior)
             else:

@@ -174,9 +174,13 @@ int bnpc_ll_theta_pinned_top2_issue(bnpc_ctx *ctx, int view,
                                     double FN, int64_t ldo,
                                     const double *col_prior, double **host,
                                     bnpc_top2 **top2);
+/* the hints of the last ..._issue call are complete on return */
+int bnpc_hints_wait(bnpc_ctx *ctx);
 /* When *top2 is returned non-NULL the matrix behind *host has NOT been copied
  * yet: it stays on the device until bnpc_matrix_wait fetches it (the sweep
- * reads it only where a hint is in doubt - a converged sweep never does).
+ * reads it only where a hint is in doubt - a settled sweep never does; when
+ * the previous hinted sweep did, the copy is queued behind the hints at once
+ * and bnpc_matrix_wait only waits for it).
  * Valid until the next log-likelihood call on the context.  bnpc_gibbs_sweep
  * calls it itself through bnpc_gibbs_state.matrix_wait. */
 int bnpc_matrix_wait(bnpc_ctx *ctx);

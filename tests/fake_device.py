@@ -193,6 +193,9 @@ class FakeContext:
     def sync(self):
         pass
 
+    def hints_wait(self):
+        pass
+
 
 def attach(model):
     """Give a bnpc_amd.model instance a FakeContext instead of a GPU."""
