@@ -685,7 +685,10 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const int64_t blk = G * M <= SMALL_BATCH ? BLK / 2 : BLK;
     const int64_t chunks = (M + blk - 1) / blk;
     const int64_t tasks = G * chunks;
-    if (threads > tasks) threads = (int)tasks;
+    // a rank per 4 tasks (256-512 entries, 30-60 us): waking a parked rank
+    // costs about that much - 2000 entries on 31 ranks were no faster than
+    // on one (round 3: the team is asleep between the batches of a step)
+    if (threads > (tasks + 3) / 4) threads = (int)((tasks + 3) / 4);
     if (threads < 1) threads = 1;
 
     std::atomic<int64_t> next(0), rows_ready(rng ? 0 : G);
@@ -942,8 +945,8 @@ extern "C" int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_arg
     const double bl = a->uniform_prior ? 0.0 : k->betaln(a->p, a->q, 0);
     const int64_t chunks = (a->M + BLK - 1) / BLK, tasks = a->G * chunks;
     int threads = a->threads;
-    if (threads > tasks) threads = (int)tasks;
-    if (tasks * BLK < 2048) threads = 1;
+    if (threads > (tasks + 3) / 4) threads = (int)((tasks + 3) / 4);
+    if (tasks * BLK < 2048 || threads < 1) threads = 1;
     std::atomic<int64_t> next(0);
     std::atomic<int> bail(0);
     auto work = [&](int) {

@@ -216,11 +216,19 @@ def get_MPEAR(assignments, dist=None):
     if dist is None:
         import os
         post = _lib.Posterior(assignments)
+        tree = None
         if os.environ.get('BNPC_WARD_DEVICE', '1') != '0':
             # the linkage on the device too: the distance vector (10 GB at
             # 50 000 cells) is never brought to the host
-            tree = post.ward()
-        else:
+            try:
+                tree = post.ward()
+            except RuntimeError as err:
+                # the full distance matrix (8 N^2 bytes) did not fit the
+                # device: SciPy's own routine on the condensed vector - the
+                # reference's call, the same tree
+                print(f'[bnpc] Ward linkage on the device failed ({err}); '
+                    'falling back to scipy.cluster.hierarchy.linkage')
+        if tree is None:
             dist = post.dist()
             tree = linkage(dist, method='ward')
     else:
