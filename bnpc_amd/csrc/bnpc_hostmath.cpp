@@ -70,8 +70,9 @@ public:
 
     // Workers up to `ranks` ranks in all (the caller is rank 0).  The team
     // grows IN PLACE: a late starter begins with seen = 0 and takes the word
-    // it finds for a job, but its rank is beyond every job posted before it
-    // existed, so it runs nothing old.  A thread the system refuses (EAGAIN
+    // it finds for a job, but the tickets of a job that is over are spent (or
+    // carry another generation), so it runs nothing old.  A thread the system
+    // refuses (EAGAIN
     // under a pids / ulimit cap) ends the growth: the team keeps the ranks it
     // has.  Returns the size reached.
     int grow(int ranks)
@@ -104,14 +105,21 @@ public:
         job_.store(&fn, std::memory_order_relaxed);
         pending_.store(n - 1, std::memory_order_relaxed);
         gen_ = (gen_ + 1) & 0xffffff;
+        // ranks 1 .. n-1 are handed out by ticket to whichever workers turn
+        // up (the generation in the upper half keeps a late worker of the
+        // previous job from drawing a rank of this one)
+        ticket_.store(((uint64_t)gen_ << 32) | 1u, std::memory_order_relaxed);
         // store the word, THEN look for sleepers - in that order for every
         // observer (a full fence: x86 may otherwise satisfy the load before
         // the store is visible, while a worker that has just announced itself
         // still reads the old word in futex_wait, and nobody wakes it)
         word_.store((gen_ << 8) | (uint32_t)n, std::memory_order_seq_cst);
         std::atomic_thread_fence(std::memory_order_seq_cst);
+        // as many sleepers as ranks are wanted, not the whole team: any worker
+        // can take any rank, and a 32-thread team that is woken for a 3-rank
+        // job costs 29 pointless context switches
         if (sleepers_.load(std::memory_order_seq_cst) > 0)
-            syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAKE_PRIVATE, INT_MAX,
+            syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAKE_PRIVATE, n - 1,
                     nullptr, nullptr, 0);
         fn(0);
         while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
@@ -132,7 +140,7 @@ private:
         clock_gettime(CLOCK_MONOTONIC, &ts);
         return ts.tv_sec * 1000000000L + ts.tv_nsec;
     }
-    void loop(int rank)
+    void loop(int /* creation order: ranks are drawn per job */)
     {
         uint32_t seen = 0;      // the word before the first job (a worker
                                 // may start after that job was posted)
@@ -156,11 +164,22 @@ private:
                 }
             }
             seen = w;
-            worked = rank < (int)(w & 0xff);
+            // draw a rank of THIS job (generation w >> 8), if one is left
+            const int n = (int)(w & 0xff);
+            int slot = -1;
+            uint64_t t = ticket_.load(std::memory_order_acquire);
+            while ((uint32_t)(t >> 32) == (w >> 8) && (int)(uint32_t)t < n) {
+                if (ticket_.compare_exchange_weak(t, t + 1,
+                        std::memory_order_acq_rel)) {
+                    slot = (int)(uint32_t)t;
+                    break;
+                }
+            }
+            worked = slot > 0;
             if (worked) {
                 // (published before the word: the acquire load above pairs
                 // with the seq_cst store in run())
-                (*job_.load(std::memory_order_relaxed))(rank);
+                (*job_.load(std::memory_order_relaxed))(slot);
                 pending_.fetch_sub(1, std::memory_order_release);
             }
         }
@@ -172,6 +191,7 @@ private:
     std::vector<std::thread> threads_;
     std::atomic<int> ranks_{1};         // the caller + threads_.size()
     std::atomic<uint32_t> word_{0};
+    std::atomic<uint64_t> ticket_{0};   // generation << 32 | next free rank
     std::atomic<int> pending_{0}, sleepers_{0};
     uint32_t gen_ = 0;
     std::atomic<const std::function<void(int)> *> job_{nullptr};
