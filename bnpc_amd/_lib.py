@@ -705,8 +705,9 @@ def _default_team(cap):
 
 
 def host_threads():
-    """Size of the native host thread team (BNPC_HOST_THREADS; default: see
-    _default_team; 1 = the calling thread only)."""
+    """Size of the native host thread team (BNPC_HOST_THREADS; default: up to
+    8 ranks for a chain alone - see _default_team; 1 = the calling thread
+    only).  The ranks a job really uses follow its size (bnpc_hostmath.cpp)."""
     env = os.environ.get('BNPC_HOST_THREADS')
     key = (env, os.environ.get('BNPC_HOST_SHARE'))
     n = _threads_memo.get(key)
@@ -716,7 +717,7 @@ def host_threads():
         except ValueError:
             n = 0
         if n < 1:
-            n = _default_team(16)
+            n = _default_team(8)
         _threads_memo[key] = n
     return n
 
@@ -747,7 +748,9 @@ def _mh_buffers(G, M):
 
 def threads_for(elements):
     """Team ranks for a parameter batch of `elements` matrix entries: from
-    2048 entries on (BNPC_MH_WIDE_FROM) up to twice the configured team,
+    65536 entries on (BNPC_MH_WIDE_FROM; round 3: the device screens the
+    batches of a converged step, a config-3 chain runs as fast on 4 ranks as
+    on 32, and every extra rank that is woken costs) up to 32 ranks,
     unless BNPC_HOST_THREADS pins the number or the node is shared with other
     chains.  Measured on the 2 x 64-core host, us per bnpc_mh_batch call, 16
     -> 32 ranks: 3 x 1000 (a restricted scan) 67-76 -> 52-58, 10 x 1000
@@ -755,7 +758,7 @@ def threads_for(elements):
     interleaved pairs: median 826 -> 869 steps/s.  (The sweeps' team scan does
     not gain from more than 16.)"""
     n = host_threads()
-    wide_from = int(os.environ.get('BNPC_MH_WIDE_FROM', '2048'))
+    wide_from = int(os.environ.get('BNPC_MH_WIDE_FROM', '65536'))
     if elements >= wide_from and os.environ.get('BNPC_HOST_THREADS') is None:
         n = max(n, min(_default_team(32), _host_cores() // 2))
     return n

@@ -362,7 +362,7 @@ def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
     mcmc._bind_worker_to_gpu(0, n_devices=8, n_chains=2)
     assert os.environ['BNPC_HOST_SHARE'] == '1'
     assert 'BNPC_HOST_SPIN_US' not in os.environ
-    assert _lib.host_threads() == 16
+    assert _lib.host_threads() == 8
     assert _lib.threads_for(10 ** 6) == 32
     monkeypatch.setenv('BNPC_HOST_THREADS', '5')
     monkeypatch.setenv('BNPC_HOST_SHARE', '4')
