@@ -1082,5 +1082,17 @@ def test_screened_batch_on_the_device_equals_the_plain_batch():
         assert a[6] == b[6]
         seen, kept = ctx.mh_screen_stats()
         assert seen == K * 300 and kept < 0.4 * seen, (seen, kept)
+        # update_parameters in one call: the counts are made in the same call
+        # (bnpc_label_counts_and_batch) and handed back with the results
+        c1 = np.full_like(n1, -7)
+        c0 = np.full_like(n0, -7)
+        np.random.seed(11)
+        c = _lib.mh_batch(table, old, c1, c0, sd, P.TMIN, P.TMAX, .01, .2,
+            .25, .25, False, False, want_prior=True, ctx=ctx,
+            label=(assign, np.arange(K))) + (np.random.random(),)
+        assert c[0] == 0 and np.array_equal(c1, n1) and np.array_equal(c0, n0)
+        for i in (1, 3, 4):
+            assert np.array_equal(a[i], c[i]), i
+        assert a[6] == c[6]
     finally:
         ctx.close()
