@@ -24,9 +24,10 @@ int bnpc_team_run(int threads, const std::function<void(int)> &fn);
 // (W pairs), or NULL
 const unsigned long long *bnpc_ctx_row(const bnpc_ctx *c, int64_t cell,
                                        int64_t *M, int *W);
-// bnpc_mt.cpp: one legacy Beta draw on the stream (NumPy's legacy_beta)
-double bnpc_legacy_beta1(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double a,
-                         double b);
+// bnpc_mt.cpp: a profile row of legacy Beta draws from one cell's bit words
+void bnpc_legacy_beta_row(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t M,
+                          const unsigned long long *row, double p, double q,
+                          double tmin, double tmax, float *theta);
 
 // bnpc_kernels.hip: counts of the two launch clusters of a restricted scan +
 // the (screened) parameter batch on one stream synchronisation
@@ -105,6 +106,7 @@ static inline uint64_t mt_interval(bnpc_mt19937 *s, uint64_t max)
 void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n);
 void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max, int32_t *out,
                         int64_t n);
+void mt_fill_permutation(bnpc_mt19937 *s, int64_t n, int64_t *out);
 
 // One element of bnpc_log_diff_pi (include/bnpc_hip.h): complex exp of
 // (q - p, pi) = exp(q - p) * (cos pi, sin pi); the maximal term is split off

@@ -45,6 +45,10 @@ extern "C" int bnpc_mt_permutation(bnpc_mt19937 *rng, int64_t n, int64_t *out)
         bnpc_set_error("bad argument: NULL");
         return 2;
     }
+    if (n > 0 && n <= 0xffffffffll) {
+        mt_fill_permutation(rng, n, out);   // pre-tempered words (bnpc_mt.cpp)
+        return 0;
+    }
     for (int64_t i = 0; i < n; i++) out[i] = i;
     for (int64_t i = n - 1; i >= 1; i--) {
         const int64_t j = (int64_t)mt_interval(rng, (uint64_t)i);
@@ -298,15 +302,8 @@ static int open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng, int64_t cell,
     *free_hint = id + 1;
     float *theta = st->theta_host + (size_t)id * M;
     bnpc_legacy_gauss *g = (bnpc_legacy_gauss *)st->gauss;
-    for (int64_t m = 0; m < M; m++) {
-        const unsigned long long one = (row[2 * (m >> 6)] >> (m & 63)) & 1ull;
-        const unsigned long long zero =
-            (row[2 * (m >> 6) + 1] >> (m & 63)) & 1ull;
-        double v = bnpc_legacy_beta1(rng, g, st->beta_p + (double)one,
-                                     st->beta_q + (double)zero);
-        v = v < st->tmin ? st->tmin : (v > st->tmax ? st->tmax : v);
-        theta[m] = (float)v;
-    }
+    bnpc_legacy_beta_row(rng, g, M, row, st->beta_p, st->beta_q, st->tmin,
+                         st->tmax, theta);
     if (st->birth_put) {
         const int rc = bnpc_theta_put(st->birth_ctx, id, theta, 1);
         if (rc) return rc;
