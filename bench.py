@@ -347,7 +347,7 @@ def main():
     cpu0 = time.process_time()      # all threads of this process
     elapsed = timed_steps(ranks, lambda i: step(chain, i, burn),
         args.warmup + 1, total)
-    cpu_s = time.process_time() - cpu0
+    proc_cpu_s = time.process_time() - cpu0
     clock.on = False
     K_end = len(model.cells_per_cluster)
     ml_end = float(chain.results['ML'][total])
@@ -435,8 +435,8 @@ def main():
             # CPU time of ALL threads of the chain's process per timed step
             # (the team's spinning included) / per wall ms: what a chain
             # costs the host it shares with the other chains of a node
-            'cpu_ms_per_step': round(1e3 * cpu_s / args.steps, 3),
-            'cpu_busy_threads': round(cpu_s / elapsed, 2),
+            'cpu_ms_per_step': round(1e3 * proc_cpu_s / args.steps, 3),
+            'cpu_busy_threads': round(proc_cpu_s / elapsed, 2),
             # parameter-batch entries screened on the device / share of them
             # the host still had to evaluate (accepted or in doubt)
             # cells of all sweeps so far / decided from the device's hint
