@@ -1096,3 +1096,50 @@ def test_screened_batch_on_the_device_equals_the_plain_batch():
         assert a[6] == c[6]
     finally:
         ctx.close()
+
+
+def test_queued_matrix_copy_changes_nothing(monkeypatch):
+    """Hinted sweeps with the matrix copy queued behind the hints as soon as
+    a sweep has needed it (the default) and with the copy always made on
+    demand (BNPC_EAGER_MATRIX=0): the same chain - assignments, traces,
+    parameter rows, stream position."""
+    data = H.synth(6, 1500, 260, 8, 0.2)
+    outs = []
+    for eager in ('1', '0'):
+        monkeypatch.setenv('BNPC_EAGER_MATRIX', eager)
+        res = H.run_chain(H.make(P, 'learn', data), 40, 9, eup=.25)
+        outs.append((res['assignments'].copy(), res['ML'].copy(),
+            res['params'].copy(), np.random.random()))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_native_births_change_nothing(monkeypatch):
+    """Clusters opened inside the native loop (the default) and through the
+    Python branch (BNPC_NATIVE_BIRTHS=0), from a state that opens dozens of
+    clusters in one sweep and recycles the ids of clusters that died: same
+    assignments, cluster table, parameter rows, stream position."""
+    rng = np.random.RandomState(3)
+    profiles = (rng.random_sample((40, 60)) < 0.5).astype(float)
+    data = np.repeat(profiles, 3, axis=0)
+    data[rng.random_sample(data.shape) < 0.05] = np.nan
+    outs = []
+    for native in ('1', '0'):
+        monkeypatch.setenv('BNPC_NATIVE_BIRTHS', native)
+        m = P.CRP(data, DP_alpha=[200, 1], param_beta=[.25, .25],
+            FN_error=0.01, FP_error=0.01)
+        np.random.seed(4)
+        m.init(mode='together')
+        np.random.seed(5)
+        m.update_assignments_Gibbs()
+        np.random.seed(6)
+        m.update_assignments_Gibbs()
+        ids = list(m.cells_per_cluster)
+        outs.append((m.assignment.copy(), list(m.cells_per_cluster.items()),
+            m.parameters[ids].copy(), np.random.random()))
+        m.close()
+    a, b = outs
+    assert len(a[1]) > 20
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and a[3] == b[3]
