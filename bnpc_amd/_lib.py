@@ -51,6 +51,22 @@ class GibbsState(C.Structure):
         ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64)]
 
 
+class MoveState(C.Structure):
+    """bnpc_move_state (include/bnpc_hip.h)"""
+    _fields_ = [('move', C.c_int32), ('scan_no', C.c_int32),
+        ('view', C.c_int32), ('uniform_prior', C.c_int32),
+        ('threads', C.c_int32), ('threads_wide', C.c_int32), ('K', _i64),
+        ('ids', C.c_void_p), ('sizes', C.c_void_p), ('N', _i64), ('M', _i64),
+        ('assignment', C.c_void_p), ('parameters', C.c_void_p),
+        ('param_stride', _i64), ('DP_a', C.c_double), ('sd', C.c_void_p),
+        ('n_sd', _i64), ('FP', C.c_double), ('FN', C.c_double),
+        ('p', C.c_double), ('q', C.c_double), ('tmin', C.c_double),
+        ('tmax', C.c_double), ('fill', C.c_double), ('gauss', C.c_void_p),
+        ('accepted', C.c_int32), ('pad_', C.c_int32), ('cl_i', _i64),
+        ('cl_j', _i64), ('moved', _i64), ('n_cells', _i64),
+        ('log_A', C.c_double)]
+
+
 class MHArgs(C.Structure):
     """bnpc_mh_args (include/bnpc_hip.h)"""
     _fields_ = [('G', _i64), ('M', _i64), ('old_theta', C.c_void_p),
@@ -162,6 +178,12 @@ SIGNATURES = {
         C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'bnpc_log_accept': (C.c_int, [C.c_void_p, C.POINTER(LogAArgs),
         C.POINTER(C.c_int)]),
+    'bnpc_sm_move': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
+        C.POINTER(MoveState), C.POINTER(C.c_int)]),
+    'bnpc_move_propose': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
+        C.POINTER(MoveState), C.c_void_p, C.POINTER(_i64), C.POINTER(_i64),
+        C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]),
+    'bnpc_np_sum': (C.c_int, [C.c_void_p, _i64, C.POINTER(C.c_double)]),
     'bnpc_tn_ppf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
         C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
         C.POINTER(C.c_int)]),
@@ -899,6 +921,93 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
             C.byref(status)), 'rg_scan_step')
     return (status.value, new, n1, n0, (sd_idx, U, u), scan_prob.value,
         log_prob)
+
+
+def np_sum(a):
+    """np.sum of a float64 vector as the library restates it (checker)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = C.c_double(0.0)
+    check(load().bnpc_np_sum(ptr(a, C.c_double), a.size, C.byref(out)),
+        'np_sum')
+    return out.value
+
+
+def _move_state(move, scan_no, ids, sizes, assignment, parameters, DP_a, sd,
+            FP, FN, p, q, uniform, tmin, tmax, fill, view):
+    st = MoveState()
+    st.move, st.scan_no, st.view = int(move), int(scan_no), int(view)
+    st.uniform_prior = int(bool(uniform))
+    N, M = parameters.shape
+    st.threads, st.threads_wide = threads_for(3 * M), host_threads()
+    st.K, st.ids, st.sizes = ids.size, ids.ctypes.data, sizes.ctypes.data
+    st.N, st.M = N, M
+    st.assignment, st.parameters = assignment.ctypes.data, \
+        parameters.ctypes.data
+    st.param_stride = parameters.strides[0] // 4
+    st.DP_a, st.sd, st.n_sd = float(DP_a), sd.ctypes.data, sd.size
+    st.FP, st.FN, st.p, st.q = float(FP), float(FN), float(p), float(q)
+    st.tmin, st.tmax, st.fill = float(tmin), float(tmax), float(fill)
+    return st
+
+
+def _move_arrays(ids, sizes, assignment, parameters, sd):
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    sd = np.ascontiguousarray(sd, dtype=np.float64)
+    assert assignment.dtype == np.int64 and assignment.flags['C_CONTIGUOUS'] \
+        and assignment.flags['WRITEABLE'] and parameters.dtype == np.float32 \
+        and parameters.ndim == 2 and parameters.strides[1] == 4 \
+        and parameters.flags['WRITEABLE'] and ids.size == sizes.size \
+        and assignment.size == parameters.shape[0]
+    return ids, sizes, sd
+
+
+def sm_move(ctx, kernels, move, scan_no, ids, sizes, assignment, parameters,
+            DP_a, sd, FP, FN, p, q, uniform, tmin, tmax, fill, view):
+    """bnpc_sm_move: a whole split (move 0) / merge (1) move on the global
+    stream; assignment (int64) and parameters (float32, row = cluster id) are
+    updated in place when the move is accepted.  None: not done natively -
+    the stream is where it was, nothing was modified.  Else (accepted, cl_i,
+    cl_j, moved cells, cells of the move, log acceptance ratio)."""
+    ids, sizes, sd = _move_arrays(ids, sizes, assignment, parameters, sd)
+    st = _move_state(move, scan_no, ids, sizes, assignment, parameters, DP_a,
+        sd, FP, FN, p, q, uniform, tmin, tmax, fill, view)
+    status = C.c_int(1)
+    with NumpyGaussStream() as (rng, gauss):
+        st.gauss = gauss
+        check(load().bnpc_sm_move(ctx._h, C.addressof(kernels), rng,
+            C.byref(st), C.byref(status)), 'sm_move')
+    if status.value:
+        return None
+    return (bool(st.accepted), st.cl_i, st.cl_j, st.moved, st.n_cells,
+        st.log_A)
+
+
+def move_propose(kernels, move, ids, sizes, assignment):
+    """The proposal of a split / merge move alone on the global stream
+    (checker): (cells, cells of the first cluster, positions in ids, size
+    term, sizes of the other clusters) or None."""
+    assignment = np.ascontiguousarray(assignment, dtype=np.int64)
+    N = assignment.size
+    dummy = np.zeros((N, 1), dtype=np.float32)
+    ids, sizes, sd = _move_arrays(ids, sizes, assignment, dummy, [1.0])
+    st = _move_state(move, 0, ids, sizes, assignment, dummy, 1.0, sd, 0, 0,
+        1, 1, True, 0, 1, 0.5, 1)
+    cells = np.empty(N, dtype=np.int64)
+    others = np.empty(max(ids.size, 1), dtype=np.int64)
+    n_cells, n_first = _i64(0), _i64(0)
+    picked = np.empty(2, dtype=np.int64)
+    size_data = C.c_double(0.0)
+    status = C.c_int(0)
+    with NumpyStream() as rng:
+        check(load().bnpc_move_propose(C.addressof(kernels), rng,
+            C.byref(st), ptr(cells), C.byref(n_cells), C.byref(n_first),
+            ptr(picked), C.byref(size_data), ptr(others),
+            C.byref(status)), 'move_propose')
+    if status.value:
+        return None
+    return (cells[:n_cells.value].copy(), n_first.value, picked,
+        size_data.value, others[:ids.size - 1].copy())
 
 
 def tn_ppf_scalar(kernels, q, a, b, loc, scale):

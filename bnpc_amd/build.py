@@ -9,6 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SOURCES = [os.path.join(PKG, 'csrc', 'bnpc_kernels.hip'),
     os.path.join(PKG, 'csrc', 'bnpc_sweeps.cpp'),
+    os.path.join(PKG, 'csrc', 'bnpc_moves.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_hostmath.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_mt.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_ingest.cpp'),

@@ -52,7 +52,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 4; }
+extern "C" int bnpc_abi_version(void) { return 5; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \

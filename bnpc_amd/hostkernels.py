@@ -32,7 +32,8 @@ class HostKernels(C.Structure):
         'ndtr', 'log_ndtr', 'ndtri_exp', 'sc_log1p', 'xlogy', 'xlog1py',
         'betaln', 'np_log', 'np_exp', 'np_log1p', 'np_expm1', 'np_log_data',
         'np_exp_data', 'np_log1p_data', 'np_expm1_data')] + [
-        ('norm_pdf_logC', C.c_double), ('left_ok', C.c_int)]
+        ('norm_pdf_logC', C.c_double), ('left_ok', C.c_int),
+        ('gammaln', C.c_void_p)]
 
 
 class _UFuncHead(C.Structure):
@@ -79,6 +80,23 @@ def _capsule_pointer(capi, name, signature):
     return ptr
 
 
+def _gammaln_pointer(capi):
+    """scipy.special.gammaln's C entry point if it returns the ufunc's bits
+    over the arguments a move can hand it (cluster sizes), else None: the
+    native moves (bnpc_sm_move) are then not used."""
+    try:
+        from scipy.special import gammaln
+        ptr = _capsule_pointer(capi, 'gammaln', _F1)
+        fn = C.CFUNCTYPE(C.c_double, C.c_double, C.c_int)(ptr)
+        probe = np.concatenate([np.arange(1, 4097), 2 ** np.arange(13, 40),
+            3 ** np.arange(8, 24) + 1]).astype(np.float64)
+        want = gammaln(probe)
+        got = np.array([fn(float(x), 0) for x in probe])
+        return ptr if np.array_equal(want, got) else None
+    except Exception:
+        return None
+
+
 _F1 = 'double (double, int __pyx_skip_dispatch)'
 _F2 = 'double (double, double, int __pyx_skip_dispatch)'
 _cache = {}
@@ -119,6 +137,7 @@ def table():
         if not (fastdist.selfcheck() and fastdist._state['shared']):
             return None
         t.left_ok = int(bool(fastdist._state['left']))
+        t.gammaln = _gammaln_pointer(capi)
         _cache['table'] = t
     except Exception:
         _cache['table'] = None

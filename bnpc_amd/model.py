@@ -282,6 +282,20 @@ def _tn_logpdf_scalar(x, a, b, loc, scale):
     return fastdist.tn_logpdf(x, a, b, loc, scale)
 
 
+# the methods a native move (bnpc_sm_move) stands for: an override of any of
+# them - by a subclass or on the instance - keeps the step-by-step path
+_MOVE_STEPS = ('run_rg_nc', '_propose_split', '_propose_merge', '_rg_open',
+    '_rg_init_split', '_rg_scan_both', '_rg_scan_split', '_rg_scan_merge',
+    '_rg_scan_fused', '_rg_scan_assign', '_rg_scan_params', '_rg_get_ll',
+    '_do_rg_split_MH', '_do_rg_merge_MH', '_get_trans_prob_ratio_split',
+    '_get_trans_prob_ratio_merge', '_get_lprior_ratio_split',
+    '_get_lprior_ratio_merge', '_get_ll_ratio',
+    '_get_ltrans_prob_size_ratio_split', '_get_ltrans_prob_size_ratio_merge',
+    '_rg_get_split_prob', '_beta_draw', '_mh_batch', '_log_A_sum',
+    'MH_cluster_params', '_get_log_A', 'get_empty_cluster', '_tables',
+    '_subset_ll')
+
+
 class CRP:
     """DPMM of Bernoulli profiles with fixed error rates (libs/CRP.py:17)."""
 
@@ -1214,8 +1228,55 @@ class CRP:
             return (self.do_split_move(step_no), move)
         return (self.do_merge_move(step_no), move)
 
-    def do_split_move(self, step_no=5):
-        """libs/CRP.py:434-481"""
+    def _native_move(self, move, step_no):
+        """A whole split (0) / merge (1) move as one native call
+        (bnpc_sm_move): the proposal, the restricted scans, the acceptance
+        test and the writes of an accepted move.  None when the move is not
+        done there - no device context / kernel table / native Beta sampler,
+        a subclass or an instance that overrides a step of the move, a move
+        of at most 4 cells, an element left to SciPy - with the stream and
+        the model untouched, and the caller walks the steps itself."""
+        ctx = self._dev()
+        table = _native_kernels()
+        if table is None or not table.gammaln \
+                or not getattr(ctx, '_h', None) or not _native_beta() \
+                or os.environ.get('BNPC_NATIVE_MOVES', '1') == '0' \
+                or any(name in self.__dict__ or getattr(type(self), name)
+                    is not getattr(CRP, name) for name in _MOVE_STEPS):
+            return None
+        ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
+        sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
+        done = _lib.sm_move(ctx, table, move, step_no, ids, sizes,
+            self.assignment, self.parameters, self.DP_a,
+            self.param_proposal_sd, self.FP, self.FN, self.p, self.q,
+            self.beta_prior_uniform, TMIN, TMAX, self._beta_mix_const[0],
+            VIEW_MOVE)
+        if done is None:
+            return None
+        self._native_moves = getattr(self, '_native_moves', 0) + 1
+        accepted, cl_i, cl_j, moved, n_cells, _ = done
+        self._rg_view = None            # the move's view was overwritten
+        self._note_move('merge' if move else 'split', n_cells, accepted)
+        if not accepted:
+            return [0, 1]
+        if move == 0:
+            self.cells_per_cluster[cl_i] -= moved
+            self.cells_per_cluster[cl_j] = moved
+        else:
+            self.cells_per_cluster[cl_i] += moved
+            del self.cells_per_cluster[cl_j]
+        return [1, 0]
+
+    def _note_move(self, move, n_cells, accepted):
+        """Observer of the restricted-Gibbs runs (tests, tools): called as
+        _move_hook(move, cells of the move, accepted) after every one."""
+        hook = getattr(self, '_move_hook', None)
+        if hook is not None:
+            hook(move, int(n_cells), bool(accepted))
+
+    def _propose_split(self):
+        """libs/CRP.py:434-457: (cluster, its cells with the two anchors
+        first and last, (log transition term, sizes of the others))"""
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
         probs = sizes / sizes.sum()
@@ -1232,10 +1293,17 @@ class CRP:
         ltrans = np.log(probs[pos]) \
             - np.log(self.cells_per_cluster[cl]) \
             - np.log(self.cells_per_cluster[cl] - 1)
-        size_data = (ltrans, np.delete(sizes, pos))
+        return cl, cells, (ltrans, np.delete(sizes, pos))
 
+    def do_split_move(self, step_no=5):
+        """libs/CRP.py:434-481"""
+        done = self._native_move(0, step_no)
+        if done is not None:
+            return done
+        cl, cells, size_data = self._propose_split()
         accept, new_assign, new_params = self.run_rg_nc(
             'split', cells, size_data, step_no)
+        self._note_move('split', cells.size, accept)
         if not accept:
             return [0, 1]
         new_cl = self.get_empty_cluster()
@@ -1247,8 +1315,9 @@ class CRP:
         self.cells_per_cluster[new_cl] = moved.size
         return [1, 0]
 
-    def do_merge_move(self, step_no=5):
-        """libs/CRP.py:484-524"""
+    def _propose_merge(self):
+        """libs/CRP.py:484-510: (the two clusters, the cells of the second,
+        all cells with the anchors first and last, log size term)"""
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=int)
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=int)
         inv = 1 / sizes
@@ -1266,8 +1335,16 @@ class CRP:
         pos = np.argwhere((ids == cl_j) | (ids == cl_i)).flatten()
         size_data = np.cumsum(np.log(probs[pos]))[-1] \
             - np.cumsum(np.log(sizes[pos]))[-1]
+        return cl_i, cl_j, cells_j, cells, size_data
 
+    def do_merge_move(self, step_no=5):
+        """libs/CRP.py:484-524"""
+        done = self._native_move(1, step_no)
+        if done is not None:
+            return done
+        cl_i, cl_j, cells_j, cells, size_data = self._propose_merge()
         accept, new_params = self.run_rg_nc('merge', cells, size_data, step_no)
+        self._note_move('merge', cells.size, accept)
         if not accept:
             return [0, 1]
         self.parameters[cl_i] = new_params

@@ -378,6 +378,7 @@ typedef struct bnpc_host_kernels {
     void *np_log_data, *np_exp_data, *np_log1p_data, *np_expm1_data;
     double norm_pdf_logC;   /* scipy.stats._continuous_distns._norm_pdf_logC */
     int left_ok;            /* bnpc_log_diff_pi verified against SciPy */
+    bnpc_sf1 gammaln;       /* scipy.special.gammaln (bnpc_sm_move), or NULL */
 } bnpc_host_kernels;
 
 typedef struct bnpc_mh_args {
@@ -616,6 +617,59 @@ int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S, const double *ll,
                  double DP_a, int64_t *rg_assignment, const int64_t *target,
                  double *log_prob);
+
+/* ---- a whole split / merge move in one call --------------------------------
+ * CRP.do_split_move / do_merge_move (libs/CRP.py:434-524): the proposal (which
+ * cluster(s), which anchors - np.random.choice with and without p, with and
+ * without replacement, on the caller's stream), run_rg_nc (:527-544: the
+ * launch state from the anchors' rows, `scan_no` restricted scans, the scored
+ * last scan), the four ratios of the acceptance test (:641-820) and, when the
+ * move is accepted, the new assignment and parameter rows written in place.
+ * The sequence of device and host calls is the one the binding makes through
+ * the entry points above; the NumPy expressions in between are restated on
+ * NumPy's own log loop (k->np_log), SciPy's gammaln (k->gammaln) and np.sum's
+ * pairwise order.
+ *   in:  move 0 = split, 1 = merge; ids / sizes = the K live clusters in the
+ *        order of the binding's dict; assignment (N, updated on acceptance);
+ *        parameters (row = cluster id, param_stride floats apart, rows cl_i /
+ *        cl_j updated on acceptance); fill = the value a missing entry of an
+ *        anchor's row stands for (libs/CRP.py:557-560); view = a slot view
+ *        the move may overwrite; gauss = the stream's bnpc_legacy_gauss.
+ *   out: accepted; split: cl_i = the cluster that was split, cl_j = the id
+ *        the `moved` cells went to; merge: cl_i = the cluster that remains,
+ *        cl_j = the one whose `moved` cells joined it; n_cells, log_A.
+ * *status = 1: not done here (a move of at most 4 cells, an element of a
+ * parameter batch the kernel table leaves to SciPy, no host copy of the rows):
+ * the stream and the cached Gaussian are where they were before the call and
+ * nothing else was modified - the caller runs the move step by step. */
+typedef struct bnpc_move_state {
+    int32_t move, scan_no, view, uniform_prior, threads, threads_wide;
+    int64_t K;
+    const int64_t *ids, *sizes;
+    int64_t N, M;
+    int64_t *assignment;
+    float *parameters;
+    int64_t param_stride;
+    double DP_a;
+    const double *sd;
+    int64_t n_sd;
+    double FP, FN, p, q, tmin, tmax, fill;
+    void *gauss;
+    int32_t accepted, pad_;
+    int64_t cl_i, cl_j, moved, n_cells;
+    double log_A;
+} bnpc_move_state;
+int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
+                 bnpc_move_state *st, int *status);
+/* Checker hooks: the proposal alone (cells = [i, S..., j], n_first = cells of
+ * the first cluster of a merge, picked = positions in ids, size_data =
+ * libs/CRP.py:452-455 / :507-508, others = the K - 1 other sizes of a split),
+ * and np.sum of a float64 vector. */
+int bnpc_move_propose(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
+                      const bnpc_move_state *st, int64_t *cells,
+                      int64_t *n_cells, int64_t *n_first, int64_t *picked,
+                      double *size_data, int64_t *others, int *status);
+int bnpc_np_sum(const double *a, int64_t n, double *out);
 
 /* ---- data ingest ---------------------------
  * Body scanner for the reference's text matrix format (libs/dpmmIO.py:27-98):

@@ -70,14 +70,20 @@ def drive(mod, data, config='c5', scheduled=SCHEDULED, progress=None):
     sm_steps = knobs['sm_steps']
 
     moves = []
-    inner = model.run_rg_nc
+    if hasattr(model, '_note_move'):
+        # the device-backed classes report their moves themselves (a move may
+        # run as one native call, bnpc_sm_move)
+        model._move_hook = lambda move, n_cells, accepted: moves.append(
+            (0 if move == 'split' else 1, n_cells, int(accepted)))
+    else:
+        inner = model.run_rg_nc
 
-    def logged(move, cells, size_data, scan_no):
-        out = inner(move, cells, size_data, scan_no)
-        moves.append((0 if move == 'split' else 1, int(len(cells)),
-            int(bool(out[0]))))
-        return out
-    model.run_rg_nc = logged
+        def logged(move, cells, size_data, scan_no):
+            out = inner(move, cells, size_data, scan_no)
+            moves.append((0 if move == 'split' else 1, int(len(cells)),
+                int(bool(out[0]))))
+            return out
+        model.run_rg_nc = logged
 
     trace = dict(assignments=[], ML=[], MAP=[], DP_alpha=[], FN=[], FP=[],
         digest=[], K=[])

@@ -1143,3 +1143,56 @@ def test_native_births_change_nothing(monkeypatch):
     assert len(a[1]) > 20
     assert np.array_equal(a[0], b[0]) and a[1] == b[1]
     assert np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+@pytest.mark.parametrize('pb', [(.25, .25), (1, 1)])
+def test_native_moves_change_nothing(pb, monkeypatch):
+    """Split / merge moves as one native call (bnpc_sm_move, the default)
+    against the same moves walked step by step by the binding
+    (BNPC_NATIVE_MOVES=0) and by the oracle: after EVERY move the result
+    flags, the assignment, the cluster table, the parameter rows and the
+    stream position are the same; both kinds of move get accepted and
+    declined along the way."""
+    data = H.synth(21, 700, 180, 6, 0.15)
+    seen = {}
+    for tag, mod, native in (('native', P, '1'), ('steps', P, '0'),
+            ('oracle', O, '0')):
+        monkeypatch.setenv('BNPC_NATIVE_MOVES', native)
+        m = H.make(mod, 'learn', data, pb)
+        np.random.seed(3)
+        # the generator's clusters, 0 and 1 lumped together (splits get
+        # accepted), the others cut in two at random (merges get accepted)
+        gen = np.random.RandomState(21)
+        gen.random_sample((6, 180))
+        z = gen.randint(0, 6, 700)
+        start = np.where(z < 2, 0, 2 * z + gen.randint(0, 2, 700))
+        m.init(assign=list(start))
+        m.update_parameters()
+        trace = []
+        for rnd in range(120):
+            np.random.seed(500 + rnd)
+            res = m.update_assignments_split_merge([.5, .5], 3)
+            ids = list(m.cells_per_cluster)
+            trace.append((res, m.assignment.copy(),
+                list(m.cells_per_cluster.items()), m.parameters[ids].copy(),
+                np.random.random()))
+            if rnd % 4 == 3:
+                m.update_parameters()
+                if rnd % 8 == 7:
+                    m.update_assignments_Gibbs()
+        seen[tag] = (trace, getattr(m, '_native_moves', 0))
+        if hasattr(m, 'close'):
+            m.close()
+    assert seen['native'][1] > 100 and seen['steps'][1] == 0
+    accepted = {0: 0, 1: 0}
+    for rnd, (a, b, c) in enumerate(zip(seen['native'][0], seen['steps'][0],
+            seen['oracle'][0])):
+        for other in (b, c):
+            assert a[0] == other[0], rnd
+            assert np.array_equal(a[1], other[1]), rnd
+            assert [(int(k), int(v)) for k, v in a[2]] \
+                == [(int(k), int(v)) for k, v in other[2]], rnd
+            assert np.array_equal(a[3], other[3]), rnd
+            assert a[4] == other[4], rnd
+        accepted[int(a[0][1])] += a[0][0][0]
+    assert accepted[0] > 0 and accepted[1] > 0, accepted

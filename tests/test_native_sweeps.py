@@ -694,3 +694,80 @@ def test_sweep_hints_fuzz():
         decided += used[1]
         cells += N
     assert decided > 0.7 * cells, (decided, cells)
+
+
+# ------------------------------------------------ native split / merge moves
+def test_np_sum_restated_is_numpys():
+    """bnpc_sm_move sums the per-mutation terms of the likelihood ratio the
+    way np.sum does (pairwise inside runs of the iterator's 8192-element
+    buffer): the checker hook against NumPy over the sizes around every
+    change of regime."""
+    rng = np.random.RandomState(0)
+    sizes = list(range(1, 300)) + [511, 512, 513, 1000, 1023, 1024, 1025,
+        2000, 4999, 5000, 8191, 8192, 8193, 16384, 16385, 20000, 31600]
+    for n in sizes:
+        for _ in range(3):
+            a = rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)
+            assert _lib.np_sum(a) == np.sum(a), n
+            assert _lib.np_sum(-np.abs(a)) == np.sum(-np.abs(a)), n
+
+
+def test_native_move_proposals_equal_the_bindings():
+    """The proposal part of bnpc_sm_move (np.random.choice with p, without
+    replacement with p, permutation(n)[:2], randint) against the binding's
+    NumPy statements on the same stream: cells with the anchors in place, the
+    size terms to the bit, the stream position - over random cluster tables
+    (dict order != id order, singletons, repeated first picks of a merge)."""
+    from bnpc_amd import hostkernels, model as P
+    table = hostkernels.table()
+    if table is None:
+        pytest.skip('no host kernel table on this stack')
+    rng = np.random.RandomState(1)
+
+    class Probe(P.CRP):
+        def __init__(self):
+            pass
+    repeats = 0
+    for trial in range(200):
+        N = int(rng.choice([5, 12, 60, 400, 3000]))
+        K0 = int(rng.randint(1, max(2, min(N, 40))))
+        lab = rng.randint(0, K0, N) if trial % 7 else np.arange(N)
+        names = rng.permutation(N)
+        m = Probe()
+        m.assignment = np.ascontiguousarray(names[lab], dtype=np.int64)
+        order = rng.permutation(np.unique(m.assignment))
+        m.cells_per_cluster = {int(c): int((m.assignment == c).sum())
+            for c in order}
+        ids = np.fromiter(m.cells_per_cluster.keys(), dtype=np.int64)
+        sizes = np.fromiter(m.cells_per_cluster.values(), dtype=np.int64)
+        for move in (0, 1):
+            if (move == 1 and ids.size < 2) \
+                    or (move == 0 and (sizes == 1).all()):
+                continue
+            seed = int(rng.randint(1 << 30))
+            np.random.seed(seed)
+            if move == 0:
+                _, cells, (ltrans, others) = m._propose_split()
+                want = (cells, 0, float(ltrans[0]))
+            else:
+                _, _, cells_j, cells, size = m._propose_merge()
+                want = (cells, cells.size - cells_j.size, float(size))
+                np.random.seed(seed)
+                u = np.random.random_sample(2)
+                cdf = np.cumsum((1 / sizes) / (1 / sizes).sum())
+                pick = (cdf / cdf[-1]).searchsorted(u, side='right')
+                repeats += pick[0] == pick[1]
+                np.random.seed(seed)
+                m._propose_merge()
+            after = np.random.random()
+            np.random.seed(seed)
+            got = _lib.move_propose(table, move, ids, sizes, m.assignment)
+            assert got is not None
+            assert np.array_equal(got[0], want[0]), (trial, move)
+            assert got[3] == want[2], (trial, move)
+            assert np.random.random() == after, (trial, move)
+            if move == 0:
+                assert np.array_equal(got[4], others)
+            else:
+                assert got[1] == want[1]
+    assert repeats > 5
