@@ -296,6 +296,19 @@ _MOVE_STEPS = ('run_rg_nc', '_propose_split', '_propose_merge', '_rg_open',
     '_subset_ll')
 
 
+_MOVE_STEP_SET = frozenset(_MOVE_STEPS)
+_plain_classes = {}
+
+
+def _overrides_a_move_step(model):
+    cls = type(model)
+    plain = _plain_classes.get(cls)
+    if plain is None:
+        plain = _plain_classes[cls] = all(
+            getattr(cls, name) is getattr(CRP, name) for name in _MOVE_STEPS)
+    return not plain or not _MOVE_STEP_SET.isdisjoint(model.__dict__)
+
+
 class CRP:
     """DPMM of Bernoulli profiles with fixed error rates (libs/CRP.py:17)."""
 
@@ -1241,8 +1254,7 @@ class CRP:
         if table is None or not table.gammaln \
                 or not getattr(ctx, '_h', None) or not _native_beta() \
                 or os.environ.get('BNPC_NATIVE_MOVES', '1') == '0' \
-                or any(name in self.__dict__ or getattr(type(self), name)
-                    is not getattr(CRP, name) for name in _MOVE_STEPS):
+                or _overrides_a_move_step(self):
             return None
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
