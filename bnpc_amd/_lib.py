@@ -184,6 +184,10 @@ SIGNATURES = {
         C.POINTER(MoveState), C.c_void_p, C.POINTER(_i64), C.POINTER(_i64),
         C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]),
     'bnpc_np_sum': (C.c_int, [C.c_void_p, _i64, C.POINTER(C.c_double)]),
+    'bnpc_pair_pick': (C.c_int, [C.c_int, C.c_double, _i64, _i64, _i64,
+        C.c_double, C.POINTER(_i64)]),
+    'bnpc_two_way_pick': (C.c_int, [C.c_int, C.c_double, C.c_double,
+        C.c_double, C.POINTER(_i64)]),
     'bnpc_tn_ppf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
         C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
         C.POINTER(C.c_int)]),

@@ -135,8 +135,15 @@ bool propose_split(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                    double *ltrans)
 {
     const int64_t K = st->K;
-    int64_t tot = 0;
-    for (int64_t i = 0; i < K; i++) tot += st->sizes[i];
+    int64_t tot = 0, largest = 0;
+    for (int64_t i = 0; i < K; i++) {
+        if (st->sizes[i] < 1) return false;
+        tot += st->sizes[i];
+        if (st->sizes[i] > largest) largest = st->sizes[i];
+    }
+    // nothing but singletons: the reference's loop (libs/CRP.py:441-447)
+    // never ends; that is left to the caller, where it can be interrupted
+    if (largest < 2) return false;
     s.probs.resize((size_t)K);
     for (int64_t i = 0; i < K; i++)
         s.probs[i] = (double)st->sizes[i] / (double)tot;
@@ -173,7 +180,10 @@ bool propose_merge(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const int64_t K = st->K;
     if (K < 2) return false;
     s.work.resize((size_t)K);
-    for (int64_t i = 0; i < K; i++) s.work[i] = 1.0 / (double)st->sizes[i];
+    for (int64_t i = 0; i < K; i++) {
+        if (st->sizes[i] < 1) return false;
+        s.work[i] = 1.0 / (double)st->sizes[i];
+    }
     const double tot = np_sum(s.work.data(), K);
     s.probs.resize((size_t)K);
     for (int64_t i = 0; i < K; i++) s.probs[i] = s.work[i] / tot;

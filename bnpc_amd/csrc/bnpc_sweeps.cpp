@@ -327,6 +327,123 @@ static int open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng, int64_t cell,
     return 0;
 }
 
+// A cell torn between two live entries (`top`, the first maximum, and `sec`,
+// d2 = runner-up - top <= 0 apart), every other of the A + 1 entries on the
+// 1e-15 floor: which entry does the uniform u pick?  Only WHICH interval of
+// the cumulative sums u falls into matters, not their bits.  The two live
+// entries have probabilities 1 / (1 + x) and x / (1 + x), x = exp(d2): the
+// interval ends are known to ~1e-14 (A floors of 1e-15, a few roundings of
+// 1e-16, the exponent's own rounding 37 * 1e-16) from ONE exp() instead of four
+// calls, A + 1 adds and a bisection with divisions.  A uniform further than
+// 1e-11 from both ends of one of the two wide intervals picks what the full
+// arithmetic picks; -1 = nearer than that (or inside a floor sliver): the
+// caller evaluates the cell in full.
+static inline int64_t pair_pick_quick(double d2, int64_t A, int64_t top,
+                                      int64_t sec, double u)
+{
+    const double x = d2 > -746.0 ? exp(d2) : 0.0;
+    const double p_top = 1.0 / (1.0 + x), p_sec = x * p_top;
+    const int64_t m1 = top < sec ? top : sec;
+    const int64_t m2 = top < sec ? sec : top;
+    const double e1 = m1 == top ? p_top : p_sec;
+    const double e2 = m1 == top ? p_sec : p_top;
+    const double un = u * (1.0 + (double)(A - 1) * EXP_LOG_EPS);
+    const double lo1 = (double)m1 * EXP_LOG_EPS, hi1 = lo1 + e1;
+    const double lo2 = hi1 + (double)(m2 - m1 - 1) * EXP_LOG_EPS;
+    const double hi2 = lo2 + e2;
+    const double band = 1e-11;
+    if (un > lo1 + band && un < hi1 - band) return m1;
+    if (un > lo2 + band && un < hi2 - band) return m2;
+    return -1;
+}
+
+// The same pick by the scan's own arithmetic (_normalize_log_probs,
+// libs/CRP.py:88-100, with every entry but the two at the floor; cdf: A + 1
+// doubles of scratch)
+static inline int64_t pair_pick_full(double d2, int64_t A, int64_t top,
+                                     int64_t sec, double u, double *cdf)
+{
+    double tail = 0.0, run = 0.0;
+    if (d2 > -746.0) tail += exp(d2);
+    const double lnorm = log1p(tail);
+    const double v_top = 0.0 - lnorm;
+    const double v_sec = d2 - lnorm;
+    const double e_top = (v_top <= LOG_EPS) ? EXP_LOG_EPS
+        : exp(v_top > 0.0 ? 0.0 : v_top);
+    const double e_sec = (v_sec <= LOG_EPS) ? EXP_LOG_EPS
+        : exp(v_sec > 0.0 ? 0.0 : v_sec);
+    for (int64_t a = 0; a <= A; a++) {
+        run += a == top ? e_top : (a == sec ? e_sec : EXP_LOG_EPS);
+        cdf[a] = run;
+    }
+    const double total = cdf[A];
+    int64_t lo = 0, hi = A + 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] / total > u) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// One cell of a restricted 2-way scan that needs no log-probabilities:
+// P(0) = 1 / (1 + x) or x / (1 + x), x = exp(-|p0 - p1|) (d <= 0, `big` = the
+// larger entry), known to ~1e-15 from one exp(); a uniform further than 1e-11
+// from it picks what two_way_pick_full picks, -1 = too close to tell.
+static inline int two_way_pick_quick(double d, int big, double u)
+{
+    const double x = exp(d);
+    const double q0 = big ? x / (1.0 + x) : 1.0 / (1.0 + x);
+    if (fabs(u - q0) > 1e-11) return u < q0 ? 0 : 1;
+    return -1;
+}
+
+// _normalize_log for two entries + np.random.choice([0, 1], p=exp(.)) given
+// its uniform (libs/CRP.py:103-116, 625-628); l0 / l1 = the log-probabilities
+static inline int two_way_pick_full(double d, int big, double u, double *l0,
+                                    double *l1)
+{
+    const double z = log1p(exp(d));
+    *l0 = big ? d - z : 0.0 - z;
+    *l1 = big ? 0.0 - z : d - z;
+    const double e0 = exp(*l0), e1 = exp(*l1);
+    const double c0 = e0, c1 = e0 + e1;
+    int pick = (c0 / c1 > u) ? 0 : 1;
+    if (!(c1 / c1 > u)) pick = 1;
+    return pick;
+}
+
+// Checker hooks for the four functions above (tests/test_native_sweeps.py):
+// -1 from a quick variant = "not decided here".
+extern "C" int bnpc_pair_pick(int quick, double d2, int64_t A, int64_t top,
+                              int64_t sec, double u, int64_t *pick)
+{
+    if (!pick || A < 1 || A > 4096 || top < 0 || top > A || sec < 0
+        || sec > A || top == sec || !(d2 <= 0.0)) {
+        bnpc_set_error("bad argument: pair_pick");
+        return 2;
+    }
+    std::vector<double> cdf((size_t)A + 1);
+    *pick = quick ? pair_pick_quick(d2, A, top, sec, u)
+                  : pair_pick_full(d2, A, top, sec, u, cdf.data());
+    return 0;
+}
+
+extern "C" int bnpc_two_way_pick(int quick, double p0, double p1, double u,
+                                 int64_t *pick)
+{
+    if (!pick || !(p0 == p0) || !(p1 == p1)) {
+        bnpc_set_error("bad argument: two_way_pick");
+        return 2;
+    }
+    const int big = p1 > p0 ? 1 : 0;
+    const double d = big ? p0 - p1 : p1 - p0;
+    double l0, l1;
+    *pick = quick ? two_way_pick_quick(d, big, u)
+                  : two_way_pick_full(d, big, u, &l0, &l1);
+    return 0;
+}
+
 static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                         const int64_t *perm, const double *ll,
                         const double *post_new, const double *crp_prior,
@@ -355,7 +472,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     static const int64_t ahead_by = [] {
         const char *e = getenv("BNPC_SWEEP_PREFETCH");
         const long v = e ? atol(e) : 16;
-        return (int64_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+        return (int64_t)(v < 0 ? 0 : (v > 64 ? 64 : v));
     }();
     for (int64_t c = 0; c < st->n_cols && c < ld; c++) {
         const int64_t sz = col_size[c];
@@ -373,6 +490,30 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                              && st->hint_cols <= st->n_cols && FLOOR_STEP > 0)
         ? st->hint : nullptr;
     const int64_t hint_cols = hint ? st->hint_cols : 0;
+    // The hints sit in pinned memory the device has just written: every line
+    // of them is a miss all the way to DRAM, and the loop visits them in
+    // permutation order - one exposed miss per cell, which software prefetch
+    // hides only in part (measured: 140-230 cycles per decided cell, best at
+    // a prefetch distance of 4, against ~40 from a private copy).  One
+    // sequential pass at the start of the sweep (the hardware prefetcher
+    // streams it: 240 KB in 7 us) into a block that stays in L2 costs a
+    // twentieth of that.
+    static thread_local std::vector<bnpc_top2> hint_local;
+    static thread_local const bnpc_top2 *hint_local_of = nullptr;
+    static const bool copy_hints = [] {
+        const char *e = getenv("BNPC_SWEEP_HINT_COPY");
+        return !(e && e[0] == '0');
+    }();
+    if (hint && copy_hints) {
+        if (st->pos == 0 || hint_local_of != hint
+            || (int64_t)hint_local.size() != N) {
+            hint_local.resize((size_t)N);
+            memcpy(hint_local.data(), hint, (size_t)N * sizeof(bnpc_top2));
+            hint_local_of = hint;
+        }
+        // (a sweep resumed after a birth in the caller finds its copy)
+        hint = hint_local.data();
+    }
     const double *cpr0 = st->hint_prior;
     double drift = 0.0;
     int64_t pos_of_col[64];
@@ -412,7 +553,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
         // per-cell scalars) of a cell a few positions ahead into the cache
-        if (st->pos + ahead_by < st->pos_end) {
+        if (ahead_by > 0 && st->pos + ahead_by < st->pos_end) {
             const int64_t ahead = perm[st->pos + ahead_by];
             if (ahead >= 0 && ahead < N) {
                 const char *r = (const char *)(ll + (size_t)(
@@ -628,16 +769,21 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // walking them: `top` copies of the floor added one by one
             // (floor_sums), then + 1.0, then every further floor moves the
             // sum, which now lies in [1, 2), by exactly FLOOR_STEP ulps.
+            const double u = mt_double(rng);
             const double at_top = fs[top] + 1.0;
             auto cdf_at = [&](int64_t a) {
                 return a < top ? fs[a + 1]
                     : at_top + (double)(FLOOR_STEP * (a - top)) * 0x1p-52;
             };
             const double total = cdf_at(A);
-            const double u = mt_double(rng);
             // the answer is `top` unless u falls into one of the 1e-15
-            // slivers (the predicate cdf[a]/total > u is monotone in a)
-            if (cdf_at(top) / total > u
+            // slivers (the predicate cdf[a]/total > u is monotone in a).
+            // With at most 512 entries the slivers below `top` end under
+            // 512e-15 and the ones above it start beyond 1 - 513e-15: a
+            // uniform between 1e-12 and 1 - 1e-12 needs no division to know.
+            if (shortcuts && A <= 512 && u > 1e-12 && u < 1.0 - 1e-12) {
+                lo = top;
+            } else if (cdf_at(top) / total > u
                 && (top == 0 || !(cdf_at(top - 1) / total > u))) {
                 lo = top;
             } else {
@@ -653,24 +799,23 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // every entry clipped at log(1e-15) contributes exp(LOG_EPS).
             double run = 0.0;
             double tail = 0.0;
-            if (pair) {
-                // the scan's arithmetic with every entry but `top` and the
-                // runner-up at the floor: one term in the tail sum, two
-                // exponentials in the running sum
-                const double d2 = second - ptop;
-                if (d2 > -746.0) tail += exp(d2);
-                const double lnorm = log1p(tail);
-                const double v_top = (ptop - ptop) - lnorm;
-                const double v_sec = d2 - lnorm;
-                const double e_top = (v_top <= LOG_EPS) ? EXP_LOG_EPS
-                    : exp(v_top > 0.0 ? 0.0 : v_top);
-                const double e_sec = (v_sec <= LOG_EPS) ? EXP_LOG_EPS
-                    : exp(v_sec > 0.0 ? 0.0 : v_sec);
-                for (int64_t a = 0; a <= A; a++) {
-                    run += a == top ? e_top
-                        : (a == pair_second ? e_sec : EXP_LOG_EPS);
-                    cdf[a] = run;
+            // (the uniform is drawn here; nothing below touches the stream)
+            const double u = mt_double(rng);
+            bool decided = false;
+            if (pair && shortcuts) {
+                const int64_t quick = pair_pick_quick(second - ptop, A, top,
+                                                      pair_second, u);
+                if (quick >= 0) {
+                    lo = quick;
+                    decided = true;
                 }
+            }
+            if (decided) {
+                // lo holds the pick
+            } else if (pair) {
+                lo = pair_pick_full(second - ptop, A, top, pair_second, u,
+                                    cdf);
+                decided = true;
             } else if (par && A >= par_min) {
                 // the exponentials on the team, the sums here in index order
                 par->top = top;
@@ -707,12 +852,13 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                     cdf[a] = run;
                 }
             }
-            const double total = cdf[A];
-            const double u = mt_double(rng);
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (cdf[mid] / total > u) hi = mid;
-                else lo = mid + 1;
+            if (!decided) {
+                const double total = cdf[A];
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (cdf[mid] / total > u) hi = mid;
+                    else lo = mid + 1;
+                }
             }
         }
         int64_t pick = lo;
@@ -809,7 +955,7 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
                             double *log_prob)
 {
     if ((mode == 0 && !rng) || (S > 0 && (!ll || !rg_assignment)) ||
-        (mode == 1 && S > 0 && !target) || !log_prob) {
+        (mode == 1 && S > 0 && !target) || (mode == 1 && !log_prob)) {
         bnpc_set_error("bad argument: NULL");
         return 2;
     }
@@ -859,6 +1005,18 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
         // and every uniform draw but an exact 0.0 picks the larger entry.
         const int big = p1 > p0 ? 1 : 0;
         const double d = big ? p0 - p1 : p1 - p0;
+        if (mode == 0 && !log_prob && shortcuts && d >= -40.0) {
+            // An unscored scan needs the pick, not the log-probabilities
+            const double u = mt_double(rng);
+            int pick = two_way_pick_quick(d, big, u);
+            if (pick < 0) {     // in doubt: the full arithmetic, same uniform
+                double l0, l1;
+                pick = two_way_pick_full(d, big, u, &l0, &l1);
+            }
+            rg_assignment[cell] = pick;
+            ones += (pick == 1);
+            continue;
+        }
         const bool far = shortcuts && d < -40.0;
         const double z = far ? exp(d) : log1p(exp(d));
         double l0, l1;
@@ -888,9 +1046,11 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
         ones += (pick == 1);
         prob[cell] = pick ? l1 : l0;
     }
-    double sum = 0.0;
-    for (int64_t s = 0; s < S; s++) sum += prob[s];
-    *log_prob = sum;
+    if (log_prob) {
+        double sum = 0.0;
+        for (int64_t s = 0; s < S; s++) sum += prob[s];
+        *log_prob = sum;
+    }
     return 0;
 }
 
@@ -929,9 +1089,11 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     int rc = bnpc_ll_theta(ctx, view, mh->old_theta, 2, mh->FP, mh->FN,
                            ll.data(), 0);
     if (rc) return rc;
+    // (an unscored scan: no log-probabilities, the loop may take its picks
+    // from one exp() per cell)
     double log_prob = 0.0;
     rc = bnpc_rg_scan(rng, 0, S, ll.data() + 2, DP_a, rg_assignment, nullptr,
-                      &log_prob);
+                      mh->trans_prob ? &log_prob : nullptr);
     if (rc) return rc;
 
     // anchors: first slot -> cluster i, last slot -> cluster j

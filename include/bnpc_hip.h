@@ -524,6 +524,19 @@ int bnpc_tn_ppf_scalar(const bnpc_host_kernels *k, double q, double a,
  * native sweep evaluates them in closed form instead of walking the array;
  * the tests compare this with NumPy's cumsum bit for bit. */
 int bnpc_dominated_cdf(int64_t A, int64_t top, double *cdf);
+/* Checker hooks: the pick of a Gibbs cell torn between two live entries (`top`
+ * the first maximum, `sec` the runner-up d2 <= 0 below it, the other A - 1 of
+ * the A + 1 entries on the 1e-15 floor) and of a cell of a restricted 2-way
+ * scan, given the uniform u.  quick = 0: the reference's arithmetic
+ * (_normalize_log_probs / _normalize_log + np.random.choice, four libm calls);
+ * quick = 1: the decision the native loops try first - one exp(), u compared
+ * with the interval ends it implies, *pick = -1 when u is within 1e-11 of an
+ * end (the loops then take the quick = 0 path).  A decided quick pick must
+ * equal the full one: the tests compare them around the ends. */
+int bnpc_pair_pick(int quick, double d2, int64_t A, int64_t top, int64_t sec,
+                   double u, int64_t *pick);
+int bnpc_two_way_pick(int quick, double p0, double p1, double u,
+                      int64_t *pick);
 
 /* The sequential per-cell loop of CRP.update_assignments_Gibbs
  * (libs/CRP.py:260-288, with _normalize_log_probs :88-100 and
@@ -611,8 +624,9 @@ int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
  *   mode 1  the scoring loop of CRP._rg_get_split_prob (libs/CRP.py:808-818):
  *           index order, no RNG, cells are forced to `target`.
  * rg_assignment (S, values 0/1) is updated in place; *log_prob receives the
- * sum in index order of the chosen log-probabilities (always for mode 1, for
- * mode 0 only meaningful to callers that need it).  Uses
+ * sum in index order of the chosen log-probabilities (mode 1: required; mode
+ * 0: NULL for an unscored scan - the loop may then take a cell's pick from
+ * one exp() where the uniform is clear of the boundary, bnpc_two_way_pick).  Uses
  * CRP._normalize_log (libs/CRP.py:103-116) and CRP.log_CRP_prior (:83-85). */
 int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S, const double *ll,
                  double DP_a, int64_t *rg_assignment, const int64_t *target,

@@ -771,3 +771,113 @@ def test_native_move_proposals_equal_the_bindings():
             else:
                 assert got[1] == want[1]
     assert repeats > 5
+
+
+def test_quick_picks_equal_the_full_arithmetic_around_every_boundary():
+    """The native loops first try to take a pick from ONE exp() - the
+    uniform against the interval ends that exp() implies - and fall back to
+    the reference's arithmetic when the uniform is within 1e-11 of an end
+    (DESIGN.md 5a).  Here both variants are driven with uniforms placed ON
+    the ends and 1e-16 ... 1e-3 either side of them, for random gaps,
+    cluster counts and positions: wherever the quick variant decides, it
+    decides what the full arithmetic decides; it declines only near an end;
+    far from the ends it always decides."""
+    lib = _lib.load()
+    rng = np.random.RandomState(11)
+    pick = C.c_int64(0)
+
+    def pair(quick, d2, A, top, sec, u):
+        _lib.check(lib.bnpc_pair_pick(quick, d2, A, top, sec, u,
+            C.byref(pick)), 'pair_pick')
+        return pick.value
+
+    def two(quick, p0, p1, u):
+        _lib.check(lib.bnpc_two_way_pick(quick, p0, p1, u, C.byref(pick)),
+            'two_way_pick')
+        return pick.value
+
+    offsets = [0.0] + [s * 10.0 ** e for e in range(-16, -2) for s in (1, -1)]
+    floor = 1e-15
+    declined = decided = 0
+    for trial in range(4000):
+        A = int(rng.randint(2, 65))
+        top, sec = (int(x) for x in rng.permutation(A + 1)[:2])
+        d2 = -float(rng.choice([0.0, 1e-9, 0.3, 2.0, 9.0, 20.0, 33.0, 36.0])
+            * rng.random_sample())
+        x = np.exp(d2)
+        p_top, p_sec = 1 / (1 + x), x / (1 + x)
+        m1, m2 = min(top, sec), max(top, sec)
+        e1, e2 = (p_top, p_sec) if m1 == top else (p_sec, p_top)
+        total = 1 + (A - 1) * floor
+        ends = [m1 * floor, m1 * floor + e1,
+            m1 * floor + e1 + (m2 - m1 - 1) * floor]
+        ends.append(ends[-1] + e2)
+        for end in ends:
+            for off in offsets:
+                u = end / total + off
+                if not 0.0 <= u < 1.0:
+                    continue
+                full = pair(0, d2, A, top, sec, u)
+                quick = pair(1, d2, A, top, sec, u)
+                if quick < 0:
+                    declined += 1
+                    # (near an end - of this interval or, for an interval
+                    # narrower than the offset, of its other side)
+                    assert abs(off) < 1e-10 or min(e1, e2) < 2 * abs(off) \
+                        + 1e-10, (d2, A, top, sec, off)
+                else:
+                    decided += 1
+                    assert quick == full, (d2, A, top, sec, u, off)
+        for _ in range(4):              # anywhere: decided, and the same
+            u = rng.random_sample()
+            assert pair(1, d2, A, top, sec, u) == pair(0, d2, A, top, sec, u)
+    assert decided > 50000 and declined > 50000
+
+    declined = decided = 0
+    for trial in range(6000):
+        gap = float(rng.choice([0.0, 1e-9, 0.5, 3.0, 15.0, 39.9])
+            * rng.random_sample())
+        base = -rng.random_sample() * 800
+        p0, p1 = (base, base - gap) if trial % 2 else (base - gap, base)
+        x = np.exp(-gap)
+        q0 = 1 / (1 + x) if p0 >= p1 else x / (1 + x)
+        for off in offsets:
+            u = q0 + off
+            if not 0.0 <= u < 1.0:
+                continue
+            full = two(0, p0, p1, u)
+            quick = two(1, p0, p1, u)
+            if quick < 0:
+                declined += 1
+                assert abs(off) < 1e-10
+            else:
+                decided += 1
+                assert quick == full, (p0, p1, u, off)
+        u = rng.random_sample()
+        assert two(1, p0, p1, u) == two(0, p0, p1, u)
+    assert decided > 20000 and declined > 20000
+
+
+def test_unscored_restricted_scan_equals_the_scored_one():
+    """bnpc_rg_scan without a log-probability output (the intermediate scans
+    of a move: picks from one exp() per cell where that is safe) against the
+    same scan with it: same assignments, same stream position."""
+    lib = _lib.load()
+    for seed in range(300):
+        rng = np.random.RandomState(9000 + seed)
+        S = int(rng.choice([3, 40, 333, 2000]))
+        spread = rng.choice([0.1, 3.0, 50.0, 90.0, 900.0])
+        ll = np.ascontiguousarray(-rng.random_sample((S, 2)) * spread)
+        start = rng.randint(0, 2, S).astype(np.int64)
+        outs = []
+        for scored in (True, False):
+            rg = start.copy()
+            np.random.seed(seed)
+            st, extra = _lib.rng_export()
+            out = C.c_double(0)
+            _lib.check(lib.bnpc_rg_scan(C.byref(st), 0, S, _lib.ptr(ll, f64),
+                3.7, _lib.ptr(rg, i64), None,
+                C.byref(out) if scored else None), 'rg_scan')
+            outs.append((rg, int(st.pos), bytes(st.key)))
+        assert np.array_equal(outs[0][0], outs[1][0]), seed
+        assert outs[0][1:] == outs[1][1:], seed
