@@ -654,8 +654,13 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         const int32_t *sure_p = sure.data();
         // a thread per ~12 tasks: waking a parked team costs more than
         // several hundred elements
-        if (threads > (n_tasks + 11) / 12)
-            threads = (int)((n_tasks + 11) / 12);
+        static const int64_t per = [] {
+            const char *e = getenv("BNPC_MH_TASKS_PER_RANK");
+            const long v = e ? atol(e) : 0;
+            return (int64_t)(v >= 1 && v <= 1024 ? v : 12);
+        }();
+        if (threads > (n_tasks + per - 1) / per)
+            threads = (int)((n_tasks + per - 1) / per);
         if (threads < 1) threads = 1;
         std::atomic<int64_t> next(0);
         auto work = [&](int) {
