@@ -598,32 +598,62 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         sure_at.assign(G + 1, 0);
         miss_at.assign(G + 1, 0);
         const bool want_prior = a->prior_out && !a->uniform_prior;
+        // One pass per row used to touch every element (copy, cache compare,
+        // branch on its flag: 4 ns each, half a millisecond per 125 000 - the
+        // largest single piece of a config-5 batch and a quarter of a
+        // config-3 one).  Now: the declined majority by block copies, the
+        // flagged minority found eight flags at a time, the cache misses by a
+        // compare that all but never fires.
         for (int64_t g = 0; g < G; g++) {
             const size_t row = (size_t)g * M;
             const uint8_t *sc = a->screen + row;
             const float *old = a->old_theta + row;
             float *out = a->new_theta + row;
-            int64_t kept = 0;
-            for (int64_t m = 0; m < M; m++) {
-                if (sc[m]) {
-                    (sc[m] == 2 ? sure : todo).push_back((int32_t)m);
-                    continue;
-                }
-                kept++;
-                out[m] = old[m];
-                if (want_prior) {
-                    if (a->known_theta
-                        && !memcmp(a->known_theta + row + m, old + m,
-                                   sizeof(float)))
-                        a->prior_out[row + m] = a->known_prior[row + m];
-                    else
-                        miss.push_back((int32_t)m);
+            memcpy(out, old, (size_t)M * sizeof(float));
+            int64_t flagged = 0;
+            int64_t m = 0;
+            for (; m + 8 <= M; m += 8) {
+                uint64_t w;
+                memcpy(&w, sc + m, 8);
+                if (!w) continue;
+                for (int b = 0; b < 8; b++) {
+                    const uint8_t f = sc[m + b];
+                    if (f) {
+                        (f == 2 ? sure : todo).push_back((int32_t)(m + b));
+                        flagged++;
+                    }
                 }
             }
-            if (a->prior_out && a->uniform_prior)
-                for (int64_t m = 0; m < M; m++)
-                    if (!sc[m]) a->prior_out[row + m] = 0.0;
-            a->declined[g] = kept;
+            for (; m < M; m++) {
+                if (sc[m]) {
+                    (sc[m] == 2 ? sure : todo).push_back((int32_t)m);
+                    flagged++;
+                }
+            }
+            if (want_prior) {
+                if (a->known_theta) {
+                    // entries whose cached parameter has the bits of the old
+                    // one take the cached density; the others (declined ones
+                    // only: the flagged get theirs from the evaluation) are
+                    // evaluated
+                    memcpy(a->prior_out + row, a->known_prior + row,
+                           (size_t)M * sizeof(double));
+                    const float *kt = a->known_theta + row;
+                    for (int64_t i = 0; i < M; i++) {
+                        uint32_t x, y;
+                        memcpy(&x, kt + i, 4);
+                        memcpy(&y, old + i, 4);
+                        if (x != y && !sc[i]) miss.push_back((int32_t)i);
+                    }
+                } else {
+                    for (int64_t i = 0; i < M; i++)
+                        if (!sc[i]) miss.push_back((int32_t)i);
+                }
+            } else if (a->prior_out) {
+                // uniform prior: the density is 0 everywhere
+                memset(a->prior_out + row, 0, (size_t)M * sizeof(double));
+            }
+            a->declined[g] = M - flagged;
             todo_at[g + 1] = (int64_t)todo.size();
             sure_at[g + 1] = (int64_t)sure.size();
             miss_at[g + 1] = (int64_t)miss.size();

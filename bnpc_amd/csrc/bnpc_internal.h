@@ -39,22 +39,13 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
 // ---------------------------------------------------------------------------
 // MT19937 (Matsumoto & Nishimura), state layout of np.random.get_state()
 // ---------------------------------------------------------------------------
+// bnpc_mt.cpp: the state refill (624 words), vectorised; picked at load time
+#ifdef __cplusplus
+void mt_refill_block(uint32_t *key);
+#endif
 static inline void mt_refill(bnpc_mt19937 *s)
 {
-    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
-    uint32_t *k = s->key;
-    int i;
-    uint32_t y;
-    for (i = 0; i < 624 - 397; i++) {
-        y = (k[i] & UPPER) | (k[i + 1] & LOWER);
-        k[i] = k[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
-    }
-    for (; i < 623; i++) {
-        y = (k[i] & UPPER) | (k[i + 1] & LOWER);
-        k[i] = k[i + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
-    }
-    y = (k[623] & UPPER) | (k[0] & LOWER);
-    k[623] = k[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+    mt_refill_block(s->key);
     s->pos = 0;
 }
 

@@ -46,6 +46,69 @@ BNPC_CLONES void refill(uint32_t *__restrict__ k)
     k[623] = k[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
 }
 
+}  // namespace
+
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+// The state refill with explicit 512-bit operations (the compiler's own
+// vectorisation of the loops above manages 0.30 ns per word, this 0.06): the
+// same recurrence in blocks of 16 words - a block reads itself, the word after
+// it and a block 397 ahead (first stretch) or 227 behind (second stretch, all
+// of it already new), none of which it has written yet.
+__attribute__((target("avx512f"))) static inline __m512i
+twist_512(const uint32_t *cur, const uint32_t *far)
+{
+    const __m512i upper = _mm512_set1_epi32((int)0x80000000u);
+    const __m512i lower = _mm512_set1_epi32(0x7fffffff);
+    const __m512i matrix = _mm512_set1_epi32((int)0x9908b0dfu);
+    const __m512i one = _mm512_set1_epi32(1), zero = _mm512_setzero_si512();
+    const __m512i y = _mm512_or_si512(
+        _mm512_and_si512(_mm512_loadu_si512((const void *)cur), upper),
+        _mm512_and_si512(_mm512_loadu_si512((const void *)(cur + 1)), lower));
+    const __m512i mag = _mm512_and_si512(
+        _mm512_sub_epi32(zero, _mm512_and_si512(y, one)), matrix);
+    return _mm512_xor_si512(
+        _mm512_xor_si512(_mm512_loadu_si512((const void *)far),
+                         _mm512_srli_epi32(y, 1)), mag);
+}
+
+__attribute__((target("avx512f"))) static void refill_512(uint32_t *k)
+{
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
+    int i = 0;
+    for (; i + 16 <= 624 - 397; i += 16)
+        _mm512_storeu_si512((void *)(k + i), twist_512(k + i, k + i + 397));
+    for (; i < 624 - 397; i++) {
+        const uint32_t y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+        k[i] = k[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+    }
+    for (; i + 16 <= 623; i += 16)
+        _mm512_storeu_si512((void *)(k + i), twist_512(k + i, k + i - 227));
+    for (; i < 623; i++) {
+        const uint32_t y = (k[i] & UPPER) | (k[i + 1] & LOWER);
+        k[i] = k[i - 227] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+    }
+    const uint32_t y = (k[623] & UPPER) | (k[0] & LOWER);
+    k[623] = k[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+}
+#define BNPC_HAVE_REFILL_512 1
+#endif
+
+// the refill every consumer of the stream uses (mt_next32 included)
+void mt_refill_block(uint32_t *key)
+{
+#ifdef BNPC_HAVE_REFILL_512
+    static const bool wide = __builtin_cpu_supports("avx512f");
+    if (wide) {
+        refill_512(key);
+        return;
+    }
+#endif
+    refill(key);
+}
+
+namespace {
+
 BNPC_CLONES void doubles_from(const uint32_t *__restrict__ k,
                               double *__restrict__ o, int64_t pairs)
 {
@@ -64,13 +127,53 @@ BNPC_CLONES void masked_from(const uint32_t *__restrict__ k,
 
 }  // namespace
 
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define BNPC_HAVE_AVX512_DRAWS 1
+// doubles_from for whole blocks of 8 doubles (16 state words) with explicit
+// 512-bit operations: the words of a pair share a 64-bit lane (low half the
+// first, high half the second), so a = low >> 5 and b = high >> 6 fall out of
+// two 64-bit shifts without any shuffle; both are below 2^27 and become
+// doubles through the 2^52 bit pattern; a * 2^26 + b < 2^53 and the division
+// by 2^53 are exact, so the result has the bits of the scalar expression.
+__attribute__((target("avx512f"))) static int64_t
+doubles_from_512(const uint32_t *k, double *o, int64_t pairs)
+{
+    const __m512i c1 = _mm512_set1_epi32((int)0x9d2c5680u);
+    const __m512i c2 = _mm512_set1_epi32((int)0xefc60000u);
+    const __m512i low = _mm512_set1_epi64(0xffffffffll);
+    const __m512i magic = _mm512_set1_epi64(0x4330000000000000ll);
+    const __m512d magic_d = _mm512_castsi512_pd(magic);
+    const __m512d two26 = _mm512_set1_pd(67108864.0);
+    const __m512d inv53 = _mm512_set1_pd(1.0 / 9007199254740992.0);
+    int64_t j = 0;
+    for (; j + 8 <= pairs; j += 8) {
+        __m512i y = _mm512_loadu_si512((const void *)(k + 2 * j));
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), c1));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), c2));
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+        const __m512i a = _mm512_srli_epi64(_mm512_and_si512(y, low), 5);
+        const __m512i b = _mm512_srli_epi64(y, 32 + 6);
+        const __m512d da = _mm512_sub_pd(
+            _mm512_castsi512_pd(_mm512_or_si512(a, magic)), magic_d);
+        const __m512d db = _mm512_sub_pd(
+            _mm512_castsi512_pd(_mm512_or_si512(b, magic)), magic_d);
+        const __m512d v = _mm512_mul_pd(
+            _mm512_add_pd(_mm512_mul_pd(da, two26), db), inv53);
+        _mm512_storeu_pd(o + j, v);
+    }
+    return j;
+}
+#endif
+
 // n x random_sample()
 void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n)
 {
     int64_t i = 0;
     while (i < n) {
         if (s->pos >= 624) {
-            refill(s->key);
+            mt_refill_block(s->key);
             s->pos = 0;
         }
         int64_t pairs = (624 - s->pos) / 2;
@@ -79,11 +182,44 @@ void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n)
             out[i++] = mt_double(s);
             continue;
         }
-        doubles_from(s->key + s->pos, out + i, pairs);
+        int64_t done = 0;
+#ifdef BNPC_HAVE_AVX512_DRAWS
+        static const bool wide = __builtin_cpu_supports("avx512f");
+        if (wide) done = doubles_from_512(s->key + s->pos, out + i, pairs);
+#endif
+        doubles_from(s->key + s->pos + 2 * done, out + i + done, pairs - done);
         s->pos += (int32_t)(2 * pairs);
         i += pairs;
     }
 }
+
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define BNPC_HAVE_COMPRESS 1
+// The accepted candidates of whole blocks of 16, in order, by a register
+// compress (the scalar slot-advance loop costs ~1.2 ns per candidate, as much
+// as producing it): stops a block short of `need` outputs, so it never takes
+// a candidate the one-by-one loop would not have taken.  Returns the outputs
+// written; *used = candidates consumed.
+__attribute__((target("avx512f"))) static int64_t
+accept_blocks(const uint32_t *cand, int avail, uint32_t max, int32_t *out,
+              int64_t need, int *used)
+{
+    const __m512i vmax = _mm512_set1_epi32((int)max);
+    int j = 0;
+    int64_t cnt = 0;
+    while (j + 16 <= avail && cnt + 16 <= need) {
+        const __m512i v = _mm512_loadu_si512((const void *)(cand + j));
+        const __mmask16 m = _mm512_cmple_epu32_mask(v, vmax);
+        _mm512_storeu_si512((void *)(out + cnt),
+                            _mm512_maskz_compress_epi32(m, v));
+        cnt += __builtin_popcount((unsigned)m);
+        j += 16;
+    }
+    *used = j;
+    return cnt;
+}
+#endif
 
 // n x random_interval(max) for max < 2^32 (masked rejection on 32-bit draws)
 void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max, int32_t *out, int64_t n)
@@ -102,12 +238,16 @@ void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max, int32_t *out, int64_t n)
     int64_t cnt = 0;
     while (cnt < n) {
         if (s->pos >= 624) {
-            refill(s->key);
+            mt_refill_block(s->key);
             s->pos = 0;
         }
         const int avail = 624 - s->pos;
         masked_from(s->key + s->pos, cand, avail, mask);
         int j = 0;
+#ifdef BNPC_HAVE_COMPRESS
+        static const bool wide = __builtin_cpu_supports("avx512f");
+        if (wide) cnt += accept_blocks(cand, avail, max, out + cnt, n - cnt, &j);
+#endif
         // every candidate is written to the next free slot; the slot only
         // advances when it is accepted (no data-dependent branch)
         for (; j < avail && cnt < n; j++) {
@@ -172,7 +312,7 @@ struct Words {
     inline uint32_t next32()
     {
         if (pos >= 624) {
-            refill(s->key);
+            mt_refill_block(s->key);
             temper_block(s->key, buf, 0);
             pos = 0;
         }

@@ -881,3 +881,39 @@ def test_unscored_restricted_scan_equals_the_scored_one():
             outs.append((rg, int(st.pos), bytes(st.key)))
         assert np.array_equal(outs[0][0], outs[1][0]), seed
         assert outs[0][1:] == outs[1][1:], seed
+
+
+def test_bulk_draws_equal_numpys_at_every_block_boundary():
+    """The vectorised stream (512-bit state refill, tempering + conversion of
+    8 doubles at a time, accepted interval candidates by register compress)
+    against NumPy's own randint / uniform / random from the same state: batch
+    lengths around the vector widths and the 624-word block, starting at even
+    and odd word positions of the block, several interval widths; values and
+    the state left behind."""
+    bad = []
+    for n_sd in (1, 2, 3, 5, 8, 100, 257):
+        for M in (1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 311, 312, 313, 623,
+                624, 625, 1000, 2500):
+            for pre in (0, 1, 300, 611, 623):
+                np.random.seed(n_sd * 31 + M)
+                if pre:
+                    np.random.random_sample(pre // 2)
+                if pre % 2:
+                    np.random.randint(0, 2 ** 31)   # an odd word offset
+                start = np.random.get_state()
+                got = _lib.mh_draws(2, M, n_sd)
+                after = np.random.get_state()
+                np.random.set_state(start)
+                ok = True
+                for g in range(2):
+                    idx = np.random.randint(0, n_sd, M)
+                    U = np.random.uniform(size=M)
+                    u = np.random.random(M)
+                    ok &= np.array_equal(idx, got[0][g]) \
+                        and np.array_equal(U, got[1][g]) \
+                        and np.array_equal(u, got[2][g])
+                now = np.random.get_state()
+                ok &= now[2] == after[2] and np.array_equal(now[1], after[1])
+                if not ok:
+                    bad.append((n_sd, M, pre))
+    assert not bad, bad[:10]
