@@ -444,6 +444,7 @@ def main():
             'sweep_cells': getattr(model, '_swept', 0),
             'sweep_hinted': getattr(model, '_hint_used', 0),
             'sweep_pairs': getattr(model, '_pair_used', 0),
+            'sweep_triples': getattr(model, '_triple_used', 0),
             'mh_screened': seen,
             'mh_left_to_host': round(kept / seen, 4) if seen else None,
         }

@@ -32,8 +32,10 @@ class MT19937(C.Structure):
 
 # bnpc_top2 (include/bnpc_hip.h) as a NumPy record
 TOP2 = np.dtype([('best', np.float64), ('second', np.float64),
-    ('third', np.float64), ('ll_best', np.float64), ('ll_second', np.float64),
-    ('col', np.int32), ('col2', np.int32)])
+    ('third', np.float64), ('fourth', np.float64), ('ll_best', np.float64),
+    ('ll_second', np.float64), ('ll_third', np.float64), ('col', np.int16),
+    ('col2', np.int16), ('col3', np.int16), ('pad_', np.int16)])
+assert TOP2.itemsize == 64
 
 
 class GibbsState(C.Structure):
@@ -48,7 +50,8 @@ class GibbsState(C.Structure):
         ('theta_host', C.c_void_p), ('beta_p', C.c_double),
         ('beta_q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
         ('FP', C.c_double), ('FN', C.c_double), ('gauss', C.c_void_p),
-        ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64)]
+        ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64),
+        ('triple_used', _i64)]
 
 
 class MoveState(C.Structure):
@@ -187,6 +190,8 @@ SIGNATURES = {
     'bnpc_pair_pick': (C.c_int, [C.c_int, C.c_double, _i64, _i64, _i64,
         C.c_double, C.POINTER(_i64)]),
     'bnpc_two_way_pick': (C.c_int, [C.c_int, C.c_double, C.c_double,
+        C.c_double, C.POINTER(_i64)]),
+    'bnpc_triple_pick': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, _i64,
         C.c_double, C.POINTER(_i64)]),
     'bnpc_tn_ppf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
         C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
@@ -925,6 +930,33 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
             C.byref(status)), 'rg_scan_step')
     return (status.value, new, n1, n0, (sd_idx, U, u), scan_prob.value,
         log_prob)
+
+
+def hints_from_matrix(mat, col_prior):
+    """The hint records the device returns for the first K = len(col_prior)
+    columns of `mat` (k_row_top2: the four largest entries of ll + prior,
+    first one on ties, the columns and log-likelihoods of the three largest)
+    - for the CPU stand-in of the device and the tests."""
+    mat = np.asarray(mat)
+    col_prior = np.asarray(col_prior, dtype=np.float64)
+    K = col_prior.size
+    ll = mat[:, :K]
+    post = ll + col_prior[None, :]
+    n = post.shape[0]
+    rows = np.arange(n)
+    order = np.argsort(-post, axis=1, kind='stable')
+    hint = np.zeros(n, dtype=TOP2)
+    for rank, (val, lik, col) in enumerate((('best', 'll_best', 'col'),
+            ('second', 'll_second', 'col2'), ('third', 'll_third', 'col3'))):
+        if rank < K:
+            c = order[:, rank]
+            hint[val] = post[rows, c]
+            hint[lik] = ll[rows, c]
+            hint[col] = np.where(np.isfinite(hint[val]) | (rank == 0), c, -1)
+        else:
+            hint[val], hint[col] = -np.inf, -1
+    hint['fourth'] = post[rows, order[:, 3]] if K > 3 else -np.inf
+    return hint
 
 
 def np_sum(a):

@@ -52,7 +52,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 5; }
+extern "C" int bnpc_abi_version(void) { return 6; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -1267,8 +1267,8 @@ __global__ __launch_bounds__(256) void k_stage_copy(
 }
 
 // ---------------------------------------------------------------------------
-// K2t: per slot the three largest entries of out[s][k] + prior[k], k < K <= 64,
-// the columns of the two largest (first on ties) and their log-likelihoods:
+// K2t: per slot the four largest entries of out[s][k] + prior[k], k < K <= 64,
+// the columns of the three largest (first on ties) and their log-likelihoods:
 // the sweep's hint.  The
 // priors travel as kernel arguments (no memory to fetch them from); the matrix
 // was just written and is read from L2.
@@ -1285,13 +1285,17 @@ __global__ __launch_bounds__(256) void k_row_top2(
     if (slot >= n) return;
     const double *__restrict__ r = ll + (size_t)slot * ldo;
     double best = -INFINITY, second = -INFINITY, third = -INFINITY;
-    double lb = 0.0, ls = 0.0;
-    int col = 0, col2 = -1;
+    double fourth = -INFINITY;
+    double lb = 0.0, ls = 0.0, lt = 0.0;
+    int col = 0, col2 = -1, col3 = -1;
     for (int k = 0; k < K; k++) {
         const double l = r[k];
         const double v = l + prior.v[k];
         if (v > best) {
+            fourth = third;
             third = second;
+            lt = ls;
+            col3 = col2;
             second = best;
             ls = lb;
             col2 = best > -INFINITY ? col : -1;
@@ -1299,22 +1303,34 @@ __global__ __launch_bounds__(256) void k_row_top2(
             lb = l;
             col = k;
         } else if (v > second) {
+            fourth = third;
             third = second;
+            lt = ls;
+            col3 = col2;
             second = v;
             ls = l;
             col2 = k;
         } else if (v > third) {
+            fourth = third;
             third = v;
+            lt = l;
+            col3 = k;
+        } else if (v > fourth) {
+            fourth = v;
         }
     }
     bnpc_top2 t;
     t.best = best;
     t.second = second;
     t.third = third;
+    t.fourth = fourth;
     t.ll_best = lb;
     t.ll_second = ls;
-    t.col = col;
-    t.col2 = col2;
+    t.ll_third = lt;
+    t.col = (int16_t)col;
+    t.col2 = (int16_t)col2;
+    t.col3 = (int16_t)col3;
+    t.pad_ = 0;
     out[slot] = t;
 }
 

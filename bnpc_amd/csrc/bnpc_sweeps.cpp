@@ -413,6 +413,115 @@ static inline int two_way_pick_full(double d, int big, double u, double *l0,
     return pick;
 }
 
+// The same for a cell with THREE live entries (the pieces of a cluster that
+// was split twice, 9 % of the cells of a running config-3 chain): values q[i]
+// at list positions a[i], every other of the A + 1 entries more than 61 below
+// the runner-up (floor probability, no term in the tail sum).  Probabilities
+// x_i / (1 + x_b + x_c) from two exp(); an entry the scan would clip to the
+// floor differs from that by less than 1e-15.  -1 = u is within 1e-11 of an
+// interval end: the caller scans the cell (with the same uniform).
+static inline int64_t triple_pick_quick(const double q[3], const int64_t a[3],
+                                        int64_t A, double u)
+{
+    int t = 0;
+    for (int i = 1; i < 3; i++)
+        if (q[i] > q[t] || (q[i] == q[t] && a[i] < a[t])) t = i;
+    double x[3], Z = 0.0;
+    for (int i = 0; i < 3; i++) {
+        const double d = q[i] - q[t];
+        x[i] = i == t ? 1.0 : (d > -746.0 ? exp(d) : 0.0);
+        Z += x[i];
+    }
+    int o[3] = {0, 1, 2};                       // by list position
+    if (a[o[0]] > a[o[1]]) { const int w = o[0]; o[0] = o[1]; o[1] = w; }
+    if (a[o[1]] > a[o[2]]) { const int w = o[1]; o[1] = o[2]; o[2] = w; }
+    if (a[o[0]] > a[o[1]]) { const int w = o[0]; o[0] = o[1]; o[1] = w; }
+    const double un = u * (1.0 + (double)(A - 2) * EXP_LOG_EPS);
+    const double band = 1e-11;
+    double edge = 0.0;
+    int64_t prev = -1;
+    for (int j = 0; j < 3; j++) {
+        const int i = o[j];
+        const double lo = edge + (double)(a[i] - prev - 1) * EXP_LOG_EPS;
+        const double hi = lo + x[i] / Z;
+        if (un > lo + band && un < hi - band) return a[i];
+        edge = hi;
+        prev = a[i];
+    }
+    return -1;
+}
+
+// _normalize_log_probs + choice for a scanned cell whose maximum (`top`,
+// value ptop) and runner-up value are known: the arithmetic of the plain scan
+// (exp() only where its result is not known, see sweep_window)
+static inline int64_t scan_pick_full(const double *post, int64_t A,
+                                     int64_t top, double ptop, double second,
+                                     double u, double *cdf, bool shortcuts)
+{
+    double run = 0.0, tail = 0.0;
+    const double cut = shortcuts ? (second - ptop) - 60.0 : -INFINITY;
+    for (int64_t a = 0; a <= A; a++) {
+        if (a == top) continue;
+        const double d = post[a] - ptop;
+        if (d > -746.0 && d >= cut) tail += exp(d);
+    }
+    const double lnorm = log1p(tail);
+    for (int64_t a = 0; a <= A; a++) {
+        const double v = post[a] - ptop - lnorm;
+        if (v <= LOG_EPS) run += EXP_LOG_EPS;
+        else run += exp(v > 0.0 ? 0.0 : v);
+        cdf[a] = run;
+    }
+    const double total = cdf[A];
+    int64_t lo = 0, hi = A + 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] / total > u) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Checker hook: the pick of a cell with three live entries.  quick = 1: the
+// one-exp-per-entry decision (-1 = not decided); quick = 0: the scan's own
+// arithmetic over the full row (the three values at their positions, -1e4
+// everywhere else).
+extern "C" int bnpc_triple_pick(int quick, const double *q, const int64_t *a,
+                                int64_t A, double u, int64_t *pick)
+{
+    if (!pick || !q || !a || A < 2 || A > 4096) {
+        bnpc_set_error("bad argument: triple_pick");
+        return 2;
+    }
+    for (int i = 0; i < 3; i++)
+        if (a[i] < 0 || a[i] > A || !(q[i] == q[i])
+            || a[i] == a[(i + 1) % 3]) {
+            bnpc_set_error("bad argument: triple_pick");
+            return 2;
+        }
+    if (quick) {
+        *pick = triple_pick_quick(q, a, A, u);
+        return 0;
+    }
+    std::vector<double> post((size_t)A + 1, -1e4), cdf((size_t)A + 1);
+    for (int i = 0; i < 3; i++) post[(size_t)a[i]] = q[i];
+    int64_t top = 0;
+    double best = -INFINITY, second = -INFINITY;
+    for (int64_t i = 0; i <= A; i++) {
+        const double v = post[i];
+        if (v > best) {
+            second = best;
+            best = v;
+            top = i;
+        } else if (v > second) {
+            second = v;
+        }
+    }
+    *pick = scan_pick_full(post.data(), A, top, best, second, u, cdf.data(),
+                           loop_shortcuts());
+    return 0;
+}
+
 // Checker hooks for the four functions above (tests/test_native_sweeps.py):
 // -1 from a quick variant = "not decided here".
 extern "C" int bnpc_pair_pick(int quick, double d2, int64_t A, int64_t top,
@@ -686,8 +795,60 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
-        if (!hinted && !pair) NEED_MATRIX()
-        if (hinted || pair) {
+        // Three candidates (a cluster split twice): the same reasoning with
+        // the hint's third column - everything else (the fourth entry at
+        // launch widened by the drift, the new-cluster entry, columns born
+        // since) more than 61 below the runner-up.  The cell's uniform is
+        // drawn now; if it is clear of the interval ends the three entries
+        // imply, the pick is known, else the cell is scanned with that same
+        // uniform.
+        bool triple = false, have_u = false;
+        int64_t triple_pick = 0;
+        double u_saved = 0.0;
+        if (hint && !hinted && !pair && A <= 64 && A >= 2 && shortcuts) {
+            const bnpc_top2 &h = hint[cell];
+            const int64_t c[3] = {h.col, h.col2, h.col3};
+            bool ok = c[0] != c[1] && c[0] != c[2] && c[1] != c[2];
+            for (int i = 0; i < 3 && ok; i++)
+                ok = c[i] >= 0 && c[i] < hint_cols && col_size[c[i]] > 0
+                    && pos_of_col[c[i]] >= 0;
+            if (ok) {
+                const double q[3] = {h.ll_best + cpr[c[0]],
+                                     h.ll_second + cpr[c[1]],
+                                     h.ll_third + cpr[c[2]]};
+                double other = h.fourth + drift;
+                const double pn = post_new[cell];
+                if (pn > other) other = pn;
+                for (int64_t a = A - 1; a >= 0 && order[a] >= hint_cols; a--) {
+                    NEED_MATRIX()
+                    const double v = row[order[a]] + cpr[order[a]];
+                    if (v > other) other = v;
+                }
+                // the runner-up: the middle one of the three
+                const double hi3 = q[0] > q[1] ? (q[0] > q[2] ? q[0] : q[2])
+                                               : (q[1] > q[2] ? q[1] : q[2]);
+                const double lo3 = q[0] < q[1] ? (q[0] < q[2] ? q[0] : q[2])
+                                               : (q[1] < q[2] ? q[1] : q[2]);
+                const double mid3 = q[0] + q[1] + q[2] - hi3 - lo3;
+                // (mid3 carries a rounding error of a few ulps: the margin
+                // below is 61 against the scan's 60)
+                if (lo3 > -INFINITY && hi3 < INFINITY
+                    && other < mid3 - 61.0) {
+                    const int64_t a3[3] = {pos_of_col[c[0]], pos_of_col[c[1]],
+                                           pos_of_col[c[2]]};
+                    u_saved = mt_double(rng);
+                    have_u = true;
+                    triple_pick = triple_pick_quick(q, a3, A, u_saved);
+                    if (triple_pick >= 0) {
+                        triple = true;
+                        st->hint_used++;
+                        st->triple_used++;
+                    }
+                }
+            }
+        }
+        if (!hinted && !pair && !triple) NEED_MATRIX()
+        if (hinted || pair || triple) {
             // `top` is known: nothing else is needed from the row
         } else if (par && A >= par_min) {
             par->row = row;
@@ -732,7 +893,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
-        if (!hinted && !pair) {
+        if (!hinted && !pair && !triple) {
             const double v = post_new[cell];
             post[A] = v;
             const bool gt = v > best;
@@ -746,7 +907,8 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // -inf) has no counterpart here: the reference would go through its
         // FloatingPointError branches (CRP.py:94-98).  Nothing has been drawn
         // for this cell yet; fail loudly instead of opening a cluster.
-        if (!hinted && !pair && !(best > -INFINITY && best < INFINITY)) {
+        if (!hinted && !pair && !triple
+            && !(best > -INFINITY && best < INFINITY)) {
             bnpc_set_error("non-finite log posterior for cell %lld "
                            "(maximum %g over %lld clusters)",
                            (long long)cell, best, (long long)A);
@@ -758,7 +920,9 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const double ptop = best;
         const double u_dominated = dom_bound[A];
         int64_t lo = 0, hi = A + 1;       // first a with cdf[a]/total > u
-        if (hinted || (FLOOR_STEP > 0 && second - ptop < u_dominated)) {
+        if (triple) {
+            lo = triple_pick;
+        } else if (hinted || (FLOOR_STEP > 0 && second - ptop < u_dominated)) {
             // One cluster dominates: the tail sum of exponentials is below
             // 2^-55, so log1p(tail) == tail < half an ulp of 1: the winner's
             // probability is exp(-tail) == 1.0 exactly and every other entry
@@ -769,7 +933,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // walking them: `top` copies of the floor added one by one
             // (floor_sums), then + 1.0, then every further floor moves the
             // sum, which now lies in [1, 2), by exactly FLOOR_STEP ulps.
-            const double u = mt_double(rng);
+            const double u = have_u ? u_saved : mt_double(rng);
             const double at_top = fs[top] + 1.0;
             auto cdf_at = [&](int64_t a) {
                 return a < top ? fs[a + 1]
@@ -799,8 +963,9 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // every entry clipped at log(1e-15) contributes exp(LOG_EPS).
             double run = 0.0;
             double tail = 0.0;
-            // (the uniform is drawn here; nothing below touches the stream)
-            const double u = mt_double(rng);
+            // (the uniform is drawn here - unless the three-candidate test
+            // above has drawn it; nothing below touches the stream)
+            const double u = have_u ? u_saved : mt_double(rng);
             bool decided = false;
             if (pair && shortcuts) {
                 const int64_t quick = pair_pick_quick(second - ptop, A, top,
@@ -837,20 +1002,9 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 // far inside what libm's exp() and NumPy's differ by (see
                 // the note at the top of this file); before the runner-up
                 // is added they cannot be told from zeros afterwards.
-                const double cut = shortcuts ? (second - ptop) - 60.0
-                                             : -INFINITY;
-                for (int64_t a = 0; a <= A; a++) {
-                    if (a == top) continue;
-                    const double d = post[a] - ptop;
-                    if (d > -746.0 && d >= cut) tail += exp(d);
-                }
-                const double lnorm = log1p(tail);
-                for (int64_t a = 0; a <= A; a++) {
-                    const double v = post[a] - ptop - lnorm;
-                    if (v <= LOG_EPS) run += EXP_LOG_EPS;
-                    else run += exp(v > 0.0 ? 0.0 : v);
-                    cdf[a] = run;
-                }
+                lo = scan_pick_full(post, A, top, ptop, second, u, cdf,
+                                    shortcuts);
+                decided = true;
             }
             if (!decided) {
                 const double total = cdf[A];

@@ -940,6 +940,8 @@ class CRP:
         live = order[:st.n_active]
         self._hint_used = getattr(self, '_hint_used', 0) + int(st.hint_used)
         self._pair_used = getattr(self, '_pair_used', 0) + int(st.pair_used)
+        self._triple_used = getattr(self, '_triple_used', 0) \
+            + int(st.triple_used)
         self._swept = getattr(self, '_swept', 0) + (pos_end - pos)
         if tile_timing:
             print(f'[bnpc]   tile [{pos},{pos_end}) cols={cols.size} '

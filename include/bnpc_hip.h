@@ -153,15 +153,17 @@ int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
 typedef struct bnpc_top2 {
     double best, second;    /* largest / second largest entry of the row */
     double third;           /* third largest (-inf with fewer than 3 columns) */
-    /* the log-likelihoods (no prior) behind best / second: with them the
-     * loop re-scores the row's two candidates under the CURRENT priors
+    double fourth;          /* fourth largest (-inf with fewer than 4) */
+    /* the log-likelihoods (no prior) behind best / second / third: with them
+     * the loop re-scores the row's candidates under the CURRENT priors
      * exactly as a scan would (row[c] + prior[c]) - a cell torn between two
-     * close clusters (the halves of a fresh split), everything else far
-     * below, is decided from these two entries alone */
-    double ll_best, ll_second;
-    int32_t col;            /* column of the largest (first one on ties) */
-    int32_t col2;           /* column of the second largest, -1 if none */
-} bnpc_top2;
+     * or three close clusters (the pieces of a fresh split), everything else
+     * far below, is decided from these entries alone */
+    double ll_best, ll_second, ll_third;
+    int16_t col;            /* column of the largest (first one on ties) */
+    int16_t col2, col3;     /* of the second / third largest, -1 if none */
+    int16_t pad_;
+} bnpc_top2;                /* 64 bytes: one cache line per cell */
 int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
                               int64_t K, double FP, double FN, int64_t ldo,
                               const double *col_prior, double **host,
@@ -537,6 +539,11 @@ int bnpc_pair_pick(int quick, double d2, int64_t A, int64_t top, int64_t sec,
                    double u, int64_t *pick);
 int bnpc_two_way_pick(int quick, double p0, double p1, double u,
                       int64_t *pick);
+/* ... and of a cell with three live entries q[0..3) at list positions
+ * a[0..3) (the other A - 2 entries far below): quick = 1 from two exp(), -1 =
+ * not decided; quick = 0 by the scan's arithmetic over the whole row. */
+int bnpc_triple_pick(int quick, const double *q, const int64_t *a, int64_t A,
+                     double u, int64_t *pick);
 
 /* The sequential per-cell loop of CRP.update_assignments_Gibbs
  * (libs/CRP.py:260-288, with _normalize_log_probs :88-100 and
@@ -602,6 +609,8 @@ typedef struct bnpc_gibbs_state {
     void *gauss;            /* bnpc_legacy_gauss of the stream */
     int64_t *born;          /* out: ids opened in this call, in order */
     int64_t born_cap, n_born;
+    int64_t triple_used;    /* out: of hint_used, cells decided among the row's
+                             * three best columns */
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

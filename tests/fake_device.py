@@ -73,24 +73,8 @@ class FakeContext:
         K = np.asarray(theta).shape[0]
         if K > 64:
             return mat, None
-        post = mat[:, :K] + np.asarray(col_prior)[None, :]
-        from bnpc_amd._lib import TOP2
-        n = post.shape[0]
-        rows = np.arange(n)
-        hint = np.zeros(n, dtype=TOP2)
-        hint['col'] = np.argmax(post, axis=1)
-        hint['best'] = post[rows, hint['col']]
-        hint['ll_best'] = mat[rows, hint['col']]
-        rest = post.copy()
-        rest[rows, hint['col']] = -np.inf
-        hint['second'], hint['third'], hint['col2'] = -np.inf, -np.inf, -1
-        if K > 1:
-            hint['col2'] = np.argmax(rest, axis=1)
-            hint['second'] = rest[rows, hint['col2']]
-            hint['ll_second'] = mat[rows, hint['col2']]
-            rest[rows, hint['col2']] = -np.inf
-            if K > 2:
-                hint['third'] = rest.max(axis=1)
+        from bnpc_amd._lib import hints_from_matrix
+        hint = hints_from_matrix(mat[:, :K], col_prior)
         return mat, hint
 
     def matrix_wait(self):

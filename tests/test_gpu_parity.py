@@ -947,6 +947,16 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         rest = post.copy()
         rest[np.arange(N), col] = -np.inf
         assert np.array_equal(hint['second'], rest.max(axis=1))
+        # every field, against the record built from the matrix on the host
+        # (four largest entries, columns and log-likelihoods of three)
+        want = _lib.hints_from_matrix(ll[:, :K], prior)
+        for name in ('best', 'second', 'third', 'fourth', 'col', 'col2',
+                'col3'):
+            assert np.array_equal(hint[name], want[name]), (K, name)
+        for lik, col in (('ll_best', 'col'), ('ll_second', 'col2'),
+                ('ll_third', 'col3')):
+            there = want[col] >= 0
+            assert np.array_equal(hint[lik][there], want[lik][there]), (K, lik)
     theta = np.clip(rng.uniform(size=(65, M)), 1e-5, 1 - 1e-5) \
         .astype(np.float32)
     assert ctx.ll_theta_pinned_top2(0, theta, .01, .2, 70, np.zeros(65))[1] \

@@ -691,8 +691,8 @@ def test_sweep_hint_is_used_and_falls_back():
     hint['best'] = -100.0 + col_prior[truth]
     hint['second'] = -500.0 + col_prior.max()
     hint['col'] = truth
-    hint['col2'] = -1
-    hint['third'] = -np.inf
+    hint['col2'] = hint['col3'] = -1
+    hint['third'] = hint['fourth'] = -np.inf
     post_new = np.full(N, -800.0)
 
     def sweep(mat, hints):
@@ -742,6 +742,7 @@ def test_sweep_hint_is_used_and_falls_back():
     pair['best'] = -100.0 + col_prior[truth]
     pair['second'] = -100.7 + col_prior[rival]
     pair['third'] = -500.0 + col_prior.max()
+    pair['col3'], pair['fourth'] = -1, -np.inf
     want = sweep(torn, None)
     assert not np.array_equal(want[0], truth)       # some cells do move
     got = sweep(torn, pair)

@@ -100,6 +100,8 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns,
     _lib.rng_import(rng, extra)
     if used is not None:
         used.append(int(st.hint_used))
+        native_gibbs.last = (int(st.hint_used), int(st.pair_used),
+            int(st.triple_used))
     live = order[:st.n_active]
     return assignment, {int(col_id[c]): int(col_size[c]) for c in live}, n_new
 
@@ -643,7 +645,7 @@ def test_sweep_hints_fuzz():
     everything else far below, three-way ties, clusters that die and are
     born under the hint.  Same assignments, cluster tables, births, stream;
     most cells are decided without a scan."""
-    decided = cells = 0
+    decided = cells = pairs = triples = 0
     for seed in range(200):
         rng = np.random.RandomState(7000 + seed)
         N = int(rng.choice([30, 90, 200]))
@@ -655,9 +657,18 @@ def test_sweep_hints_fuzz():
         kind = rng.random_sample(N)
         two = kind < 0.4                # torn between two columns
         ll[two, b[two]] = ll[two, a[two]] - rng.random_sample(two.sum()) * 3
-        three = kind > 0.95             # a third within reach: scanned
-        c = (b + 1) % K
-        ll[three, c[three]] = ll[three, a[three]] - 20
+        three = kind > 0.8              # a third within reach: decided
+        c = (b + 1) % K                 # among the three (or scanned)
+        c[c == a] = (c[c == a] + 1) % K
+        ll[three, b[three]] = ll[three, a[three]] \
+            - rng.random_sample(three.sum()) * 3
+        ll[three, c[three]] = ll[three, a[three]] \
+            - rng.random_sample(three.sum()) * 20
+        four = kind > 0.97              # ... and a fourth: scanned
+        d = (c + 1) % K
+        d[(d == a) | (d == b) | (d == c)] = -1
+        sel = four & (d >= 0) & (K > 3)
+        ll[sel, d[sel]] = ll[sel, a[sel]] - 25
         post_new = -rng.random_sample(N) * 50 - (300 if seed % 4 else 60)
         alpha = 2.5
         crp_prior = np.append(0, O.CRP.log_CRP_prior(
@@ -671,16 +682,7 @@ def test_sweep_hints_fuzz():
             for _ in range(N + 1)]
         col_prior = np.ascontiguousarray(
             crp_prior[np.fromiter(sizes.values(), dtype=np.int64)])
-        post = ll + col_prior[None, :]
-        order = np.argsort(-post, axis=1, kind='stable')
-        rows = np.arange(N)
-        hint = np.zeros(N, dtype=_lib.TOP2)
-        hint['col'], hint['col2'] = order[:, 0], order[:, 1]
-        hint['best'] = post[rows, order[:, 0]]
-        hint['second'] = post[rows, order[:, 1]]
-        hint['third'] = post[rows, order[:, 2]]
-        hint['ll_best'] = ll[rows, order[:, 0]]
-        hint['ll_second'] = ll[rows, order[:, 1]]
+        hint = _lib.hints_from_matrix(ll, col_prior)
         outs, used = [], []
         for h in (None, (hint, col_prior)):
             np.random.seed(seed)
@@ -692,8 +694,11 @@ def test_sweep_hints_fuzz():
         assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], seed
         assert np.array_equal(outs[0][3], outs[1][3]), seed
         decided += used[1]
+        pairs += native_gibbs.last[1]
+        triples += native_gibbs.last[2]
         cells += N
     assert decided > 0.7 * cells, (decided, cells)
+    assert pairs > 0.1 * cells and triples > 0.05 * cells, (pairs, triples)
 
 
 # ------------------------------------------------ native split / merge moves
@@ -917,3 +922,57 @@ def test_bulk_draws_equal_numpys_at_every_block_boundary():
                 if not ok:
                     bad.append((n_sd, M, pre))
     assert not bad, bad[:10]
+
+
+def test_quick_pick_among_three_equals_the_scan_around_every_boundary():
+    """A cell with three candidate clusters (bnpc_triple_pick): the pick from
+    two exp() against the scan's own arithmetic over the whole row, with the
+    uniform ON every interval end and 1e-16 ... 1e-3 either side, for random
+    gaps (ties, a third entry beyond the 60-below rule, beyond the floor),
+    cluster counts and positions."""
+    lib = _lib.load()
+    rng = np.random.RandomState(12)
+    pick = C.c_int64(0)
+
+    def triple(quick, q, a, A, u):
+        _lib.check(lib.bnpc_triple_pick(quick, q.ctypes.data, a.ctypes.data, A,
+            u, C.byref(pick)), 'triple_pick')
+        return pick.value
+
+    offsets = [0.0] + [s * 10.0 ** e for e in range(-16, -2) for s in (1, -1)]
+    floor = 1e-15
+    declined = decided = 0
+    for trial in range(3000):
+        A = int(rng.randint(2, 65))
+        a = np.ascontiguousarray(rng.permutation(A + 1)[:3], dtype=np.int64)
+        gaps = -rng.choice([0.0, 1e-9, 0.3, 2.0, 9.0, 30.0, 45.0, 70.0, 95.0],
+            2) * rng.random_sample(2)
+        if trial % 5 == 0:
+            gaps[1] = gaps[0]                   # a tie among the other two
+        q = np.ascontiguousarray(
+            rng.permutation(np.array([0.0, gaps[0], gaps[0] + gaps[1]]))
+            - rng.random_sample() * 300)
+        x = np.exp(q - q.max())
+        p = x / x.sum()
+        total = 1 + (A - 2) * floor
+        ends, edge, prev = [], 0.0, -1
+        for i in np.argsort(a):
+            lo = edge + (a[i] - prev - 1) * floor
+            ends += [lo, lo + p[i]]
+            edge, prev = lo + p[i], a[i]
+        for end in ends:
+            for off in offsets:
+                u = end / total + off
+                if not 0.0 <= u < 1.0:
+                    continue
+                quick = triple(1, q, a, A, u)
+                if quick < 0:
+                    declined += 1
+                else:
+                    decided += 1
+                    assert quick == triple(0, q, a, A, u), (q, a, A, u, off)
+        for _ in range(3):
+            u = rng.random_sample()
+            quick = triple(1, q, a, A, u)
+            assert quick < 0 or quick == triple(0, q, a, A, u), (q, a, A, u)
+    assert decided > 50000 and declined > 50000
