@@ -34,7 +34,7 @@ class MT19937(C.Structure):
 TOP2 = np.dtype([('best', np.float64), ('second', np.float64),
     ('third', np.float64), ('fourth', np.float64), ('ll_best', np.float64),
     ('ll_second', np.float64), ('ll_third', np.float64), ('col', np.int16),
-    ('col2', np.int16), ('col3', np.int16), ('pad_', np.int16)])
+    ('col2', np.int16), ('col3', np.int16), ('row_here', np.int16)])
 assert TOP2.itemsize == 64
 
 

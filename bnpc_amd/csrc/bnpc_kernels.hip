@@ -1279,7 +1279,8 @@ struct Top2Prior {
 
 __global__ __launch_bounds__(256) void k_row_top2(
     const double *__restrict__ ll, long long n, long long ldo, int K,
-    Top2Prior prior, bnpc_top2 *__restrict__ out)
+    Top2Prior prior, bnpc_top2 *__restrict__ out,
+    double *__restrict__ host_ll)
 {
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
     if (slot >= n) return;
@@ -1330,7 +1331,19 @@ __global__ __launch_bounds__(256) void k_row_top2(
     t.col = (int16_t)col;
     t.col2 = (int16_t)col2;
     t.col3 = (int16_t)col3;
-    t.pad_ = 0;
+    // A row without a clear winner and with a fourth entry within reach of
+    // the runner-up is one the sweep will have to scan (the host decides
+    // cells among up to three candidates from the hint alone; a clear winner
+    // needs none): it is written through to the host's
+    // copy of the matrix here, with the hints, so that the scan does not have
+    // to wait for the whole matrix to be copied (row_here = 1).
+    int through = 0;
+    if (host_ll && fourth > second - 72.0 && second > best - 48.0) {
+        double *__restrict__ h = host_ll + (size_t)slot * ldo;
+        for (int k = 0; k < K; k++) h[k] = r[k];
+        through = 1;
+    }
+    t.row_here = (int16_t)through;
     out[slot] = t;
 }
 
@@ -2431,10 +2444,17 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     if (hint) {
         Top2Prior pr;
         for (int k = 0; k < 64; k++) pr.v[k] = k < K ? col_prior[k] : 0.0;
+        // the host's copy of the matrix as the device sees it (rows the
+        // sweep is going to scan are written through by the hint kernel)
+        void *pin_dev = nullptr;
+        double *rows_dev = nullptr;
+        if (c->tun.lazy_matrix
+            && hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
+            rows_dev = (double *)pin_dev;
         hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->out.p,
                            (long long)n, (long long)ldo, (int)K, pr,
-                           (bnpc_top2 *)zc_dev);
+                           (bnpc_top2 *)zc_dev, rows_dev);
         HIPCHK(hipGetLastError());
     }
     if (hint && c->tun.lazy_matrix) {

@@ -613,7 +613,11 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         const char *e = getenv("BNPC_SWEEP_HINT_COPY");
         return !(e && e[0] == '0');
     }();
-    if (hint && copy_hints) {
+    // (up to 1 MiB of hints, 16 384 cells: at config 5's 3.2 MB the pass
+    // itself runs at 2 GB/s and costs more than the misses it saves - Gibbs
+    // step 3.6-4.5 against 2.05 ms - while 640 KB at config 4 still gain)
+    if (hint && copy_hints
+        && (size_t)N * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
         if (st->pos == 0 || hint_local_of != hint
             || (int64_t)hint_local.size() != N) {
             hint_local.resize((size_t)N);
@@ -847,7 +851,15 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 }
             }
         }
-        if (!hinted && !pair && !triple) NEED_MATRIX()
+        if (!hinted && !pair && !triple) {
+            // the scan reads the row: columns of the launch from the matrix
+            // - which the hint kernel has written through for the rows it
+            // could tell would be scanned - and columns born since, which
+            // were written here after the matrix had arrived
+            if (!(hint && hint[cell].row_here == 1
+                  && (A == 0 || order[A - 1] < hint_cols)))
+                NEED_MATRIX()
+        }
         if (hinted || pair || triple) {
             // `top` is known: nothing else is needed from the row
         } else if (par && A >= par_min) {

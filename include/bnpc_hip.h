@@ -162,7 +162,12 @@ typedef struct bnpc_top2 {
     double ll_best, ll_second, ll_third;
     int16_t col;            /* column of the largest (first one on ties) */
     int16_t col2, col3;     /* of the second / third largest, -1 if none */
-    int16_t pad_;
+    int16_t row_here;       /* 1: the row's first K entries are already in the
+                             * host matrix (written through by the hint kernel
+                             * because there is no clear winner and a fourth
+                             * entry is within reach: a row the sweep will
+                             * scan) - no need to wait for the
+                             * matrix copy to read them */
 } bnpc_top2;                /* 64 bytes: one cache line per cell */
 int bnpc_ll_theta_pinned_top2(bnpc_ctx *ctx, int view, const float *theta,
                               int64_t K, double FP, double FN, int64_t ldo,

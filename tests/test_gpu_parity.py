@@ -930,7 +930,15 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         if K > 2:
             prior[2] = prior[0]
         ll, hint = ctx.ll_theta_pinned_top2(0, theta, .01, .2, K + 3, prior)
+        # rows with a fourth entry within reach of the runner-up (the ones a
+        # sweep scans) are in the host matrix already, with the hints
+        here = hint['row_here'] == 1
+        assert np.array_equal(here, (hint['fourth'] > hint['second'] - 72.0)
+            & (hint['second'] > hint['best'] - 48.0))
+        early = ll[here, :K].copy()
         ctx.matrix_wait()       # the matrix is copied behind the hints
+        assert np.array_equal(early, ll[here, :K])
+        assert not here.any() or K > 3
         live_ll, live_hint = ll, hint
         ll, hint = ll.copy(), hint.copy()
         assert np.array_equal(ll[:, :K], ctx.ll_theta(0, theta, .01, .2))
