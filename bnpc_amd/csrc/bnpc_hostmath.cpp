@@ -740,10 +740,18 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const int64_t blk = G * M <= SMALL_BATCH ? BLK / 2 : BLK;
     const int64_t chunks = (M + blk - 1) / blk;
     const int64_t tasks = G * chunks;
-    // a rank per 4 tasks (256-512 entries, 30-60 us): waking a parked rank
-    // costs about that much - 2000 entries on 31 ranks were no faster than
-    // on one (round 3: the team is asleep between the batches of a step)
-    if (threads > (tasks + 3) / 4) threads = (int)((tasks + 3) / 4);
+    // a rank per 2 tasks (4 until a move became one native call: the batches
+    // of a move now follow each other within the team's spin, and a rank per
+    // 2 tasks is worth 10-25 us per move; waking a PARKED rank still costs as
+    // much as 256-512 entries - 2000 entries on 31 ranks were no faster than
+    // on one when the team was asleep between the batches of a step)
+    static const int64_t dense_per = [] {
+        const char *e = getenv("BNPC_MH_DENSE_TASKS_PER_RANK");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v >= 1 && v <= 1024 ? v : 2);
+    }();
+    if (threads > (tasks + dense_per - 1) / dense_per)
+        threads = (int)((tasks + dense_per - 1) / dense_per);
     if (threads < 1) threads = 1;
 
     std::atomic<int64_t> next(0), rows_ready(rng ? 0 : G);
@@ -1000,8 +1008,19 @@ extern "C" int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_arg
     const double bl = a->uniform_prior ? 0.0 : k->betaln(a->p, a->q, 0);
     const int64_t chunks = (a->M + BLK - 1) / BLK, tasks = a->G * chunks;
     int threads = a->threads;
-    if (threads > (tasks + 3) / 4) threads = (int)((tasks + 3) / 4);
-    if (tasks * BLK < 2048 || threads < 1) threads = 1;
+    static const int64_t accept_per = [] {
+        const char *e = getenv("BNPC_ACCEPT_TASKS_PER_RANK");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v >= 1 && v <= 1024 ? v : 2);
+    }();
+    static const int64_t accept_min = [] {
+        const char *e = getenv("BNPC_ACCEPT_TEAM_FROM");
+        const long v = e ? atol(e) : 0;
+        return (int64_t)(v >= 1 ? v : 1024);
+    }();
+    if (threads > (tasks + accept_per - 1) / accept_per)
+        threads = (int)((tasks + accept_per - 1) / accept_per);
+    if (tasks * BLK < accept_min || threads < 1) threads = 1;
     std::atomic<int64_t> next(0);
     std::atomic<int> bail(0);
     auto work = [&](int) {
