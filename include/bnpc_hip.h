@@ -143,11 +143,12 @@ int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
                          int64_t K, double FP, double FN, int64_t ldo,
                          double **host);
 
-/* bnpc_ll_theta_pinned plus, per slot, the two largest entries of
+/* bnpc_ll_theta_pinned plus, per slot, the four largest entries of
  *   out[s, k] + col_prior[k]   (k < K <= 64)
- * and the column of the largest: a HINT for the sequential sweep, which then
- * scores a cell in O(1) instead of O(K) whenever the winner is beyond doubt
- * (bnpc_gibbs_state.hint).  col_prior[k] is the log prior of column k's
+ * with the columns and log-likelihoods of the three largest: a HINT for the
+ * sequential sweep, which then scores a cell in O(1) instead of O(K) whenever
+ * the winner is beyond doubt or the cell is torn between two or three
+ * columns with everything else far below (bnpc_gibbs_state.hint).  col_prior[k] is the log prior of column k's
  * cluster at launch time (CRP_prior[size], libs/CRP.py:226).  *top2 points
  * into pinned host memory, valid until the next call on the context. */
 typedef struct bnpc_top2 {
