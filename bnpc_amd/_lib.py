@@ -13,6 +13,24 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # bnpc_amd/build.py); never a different implementation
 LIB_PATH = os.environ.get('BNPC_LIB') or os.path.join(_PKG, 'libbnpc_hip.so')
 
+# os.environ.get costs 0.5 us a call (key and value are encoded / decoded every
+# time) and a step asks for a dozen switches: read the process environment's
+# own byte-keyed table where CPython exposes it (still live: a switch changed
+# through os.environ is seen at once), else os.environ
+_environ_raw = getattr(os.environ, '_data', None)
+if not isinstance(_environ_raw, dict) \
+        or (_environ_raw and not isinstance(next(iter(_environ_raw)), bytes)):
+    _environ_raw = None
+
+
+def env(name, default=None):
+    """os.environ.get(name, default), cheaply."""
+    if _environ_raw is None:
+        return os.environ.get(name, default)
+    val = _environ_raw.get(name.encode() if isinstance(name, str) else name)
+    return default if val is None else os.fsdecode(val)
+
+
 MAX_VIEWS = 6
 TILE_SLOTS = 3      # include/bnpc_hip.h: BNPC_TILE_SLOTS
 MAX_TRIALS = 4
@@ -710,7 +728,7 @@ def _host_share():
     """Chains running next to this one on the same GPU / NUMA node
     (BNPC_HOST_SHARE, set per worker by bnpc_amd.mcmc)."""
     try:
-        return max(1, int(os.environ.get('BNPC_HOST_SHARE') or 1))
+        return max(1, int(env('BNPC_HOST_SHARE') or 1))
     except ValueError:
         return 1
 
@@ -739,12 +757,12 @@ def host_threads():
     """Size of the native host thread team (BNPC_HOST_THREADS; default: up to
     8 ranks for a chain alone - see _default_team; 1 = the calling thread
     only).  The ranks a job really uses follow its size (bnpc_hostmath.cpp)."""
-    env = os.environ.get('BNPC_HOST_THREADS')
-    key = (env, os.environ.get('BNPC_HOST_SHARE'))
+    env_threads = env('BNPC_HOST_THREADS')
+    key = (env_threads, env('BNPC_HOST_SHARE'))
     n = _threads_memo.get(key)
     if n is None:
         try:
-            n = int(env or 0)
+            n = int(env_threads or 0)
         except ValueError:
             n = 0
         if n < 1:
@@ -789,8 +807,8 @@ def threads_for(elements):
     interleaved pairs: median 826 -> 869 steps/s.  (The sweeps' team scan does
     not gain from more than 16.)"""
     n = host_threads()
-    wide_from = int(os.environ.get('BNPC_MH_WIDE_FROM', '65536'))
-    if elements >= wide_from and os.environ.get('BNPC_HOST_THREADS') is None:
+    wide_from = int(env('BNPC_MH_WIDE_FROM', '65536'))
+    if elements >= wide_from and env('BNPC_HOST_THREADS') is None:
         n = max(n, min(_default_team(32), _host_cores() // 2))
     return n
 

@@ -118,7 +118,7 @@ def _native_kernels():
         _NATIVE.clear()
         _NATIVE['pid'] = pid
         _NATIVE['table'] = None
-        if os.environ.get('BNPC_NATIVE_MH', '1') != '0':
+        if _lib.env('BNPC_NATIVE_MH', '1') != '0':
             table = hostkernels.table()
             if table is not None and _native_batch_is_exact(table):
                 _NATIVE['table'] = table
@@ -228,7 +228,7 @@ def _native_beta():
     if _BETA.get('pid') != pid:
         _BETA.clear()
         _BETA.update(pid=pid, ok=False)
-        if os.environ.get('BNPC_NATIVE_BETA', '1') != '0':
+        if _lib.env('BNPC_NATIVE_BETA', '1') != '0':
             saved = np.random.get_state()
             try:
                 a = np.array([.25, 1.25, 7.25, .25, 1., 1., .999, 400.5, .5,
@@ -658,7 +658,7 @@ class CRP:
         proceeds.  Same decisions, same draws, same trajectory either way.
         """
         N = self.cells_total
-        timing = os.environ.get('BNPC_TIMING')
+        timing = _lib.env('BNPC_TIMING')
         if timing:
             import time
             t_start = time.perf_counter()
@@ -668,7 +668,7 @@ class CRP:
         sizes = np.fromiter(self.cells_per_cluster.values(), dtype=np.int64)
         K_start = ids.size
 
-        budget = int(os.environ.get('BNPC_SWEEP_BYTES', 256 << 20))
+        budget = int(_lib.env('BNPC_SWEEP_BYTES', 256 << 20))
         ctx = self._dev()
         if budget // (8 * (ids.size + 16)) >= N:
             # the whole matrix in one launch, rows = cell ids
@@ -679,7 +679,7 @@ class CRP:
             # best columns under the priors at launch: the native loop then
             # decides most cells without scanning them
             hint = None
-            if ids.size <= 64 and os.environ.get('BNPC_SWEEP_HINT', '1') != '0':
+            if ids.size <= 64 and _lib.env('BNPC_SWEEP_HINT', '1') != '0':
                 # queued, not waited for: the permutation is drawn and the
                 # sweep's private state copied under the launch (no draw of
                 # the stream sits between them in the reference either: the
@@ -712,9 +712,9 @@ class CRP:
             ctx.theta_put(0, self.parameters[:int(ids.max()) + 1])
 
             tile_bytes = min(budget,
-                int(os.environ.get('BNPC_TILE_BYTES', 256 << 20)))
+                int(_lib.env('BNPC_TILE_BYTES', 256 << 20)))
             ahead_max = max(1, min(_lib.TILE_SLOTS - 1,
-                int(os.environ.get('BNPC_TILES_AHEAD', 2))))
+                int(_lib.env('BNPC_TILES_AHEAD', 2))))
             born_log = []       # ids born during this sweep, in order
 
             def issue(start, number):
@@ -819,7 +819,7 @@ class CRP:
         N = self.cells_total
         whole = view == VIEW_ALL
         n_rows, ld = ll.shape
-        tile_timing = os.environ.get('BNPC_TIMING') == '2'
+        tile_timing = _lib.env('BNPC_TIMING') == '2'
         if tile_timing:
             import time
             t0 = time.perf_counter()
@@ -876,7 +876,7 @@ class CRP:
         # births the call cannot make itself (no spare column left)
         theta = self.parameters
         native_births = bool(getattr(ctx, '_h', None)) and _native_beta() \
-            and os.environ.get('BNPC_NATIVE_BIRTHS', '1') != '0' \
+            and _lib.env('BNPC_NATIVE_BIRTHS', '1') != '0' \
             and theta.dtype == np.float32 and theta.flags['C_CONTIGUOUS'] \
             and theta.shape[1] == self.muts_total
         if native_births:
@@ -1255,7 +1255,7 @@ class CRP:
         table = _native_kernels()
         if table is None or not table.gammaln \
                 or not getattr(ctx, '_h', None) or not _native_beta() \
-                or os.environ.get('BNPC_NATIVE_MOVES', '1') == '0' \
+                or _lib.env('BNPC_NATIVE_MOVES', '1') == '0' \
                 or _overrides_a_move_step(self):
             return None
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)
@@ -1498,7 +1498,7 @@ class CRP:
         if table is None or cells.size <= 4 or not getattr(ctx, '_h', None) \
                 or view is None or view.size != cells.size \
                 or not np.array_equal(view, cells) \
-                or os.environ.get('BNPC_RG_FUSED', '1') == '0':
+                or _lib.env('BNPC_RG_FUSED', '1') == '0':
             return None
         rg = np.array(self.rg_assignment, dtype=np.int64, order='C')
         rows = self.rg_params_split if final else np.concatenate(
