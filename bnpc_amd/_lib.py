@@ -114,6 +114,10 @@ class LogAArgs(C.Structure):
         ('sum', C.c_void_p), ('threads', C.c_int)]
 
 
+# the version bnpc_abi_version() of a matching library reports (bumped with
+# every change of a structure or signature of include/bnpc_hip.h)
+ABI_VERSION = 6
+
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
     'bnpc_last_error': (C.c_char_p, []),
@@ -256,6 +260,12 @@ def load():
         fn = getattr(lib, name)     # AttributeError if a symbol is missing
         fn.restype = res
         fn.argtypes = args
+    built = lib.bnpc_abi_version()
+    if built != ABI_VERSION:
+        raise RuntimeError(
+            f'{LIB_PATH} was built for ABI version {built}, this binding '
+            f'expects {ABI_VERSION} (structures of include/bnpc_hip.h have '
+            'changed): run `python -m bnpc_amd.build`')
     _lib = lib
     return lib
 
