@@ -2448,9 +2448,12 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
         // sweep is going to scan are written through by the hint kernel)
         void *pin_dev = nullptr;
         double *rows_dev = nullptr;
-        if (c->tun.lazy_matrix
-            && hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
-            rows_dev = (double *)pin_dev;
+        if (c->tun.lazy_matrix) {
+            if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
+                rows_dev = (double *)pin_dev;
+            else
+                (void)hipGetLastError();    // not mapped: no write-through
+        }
         hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->out.p,
                            (long long)n, (long long)ldo, (int)K, pr,
