@@ -276,9 +276,19 @@ def check(rc, what=''):
         raise RuntimeError(f'libbnpc_hip {what} failed (code {rc}): {msg}')
 
 
+_from_buffer = C.c_char.from_buffer
+_addressof = C.addressof
+
+
 def ptr(arr, ctype=None):
-    """Address of a C-contiguous array (the ctype is documentation)."""
-    return arr.ctypes.data
+    """Address of a C-contiguous array (the ctype is documentation).
+    `arr.ctypes.data` builds a helper object per call (0.7-1.3 us, three
+    dozen times a step); the buffer protocol gives the same address in 0.2 us
+    for the writable, contiguous, non-empty arrays that are the rule here."""
+    try:
+        return _addressof(_from_buffer(arr))
+    except (TypeError, ValueError):
+        return arr.ctypes.data
 
 
 def as_i64(a):
@@ -427,7 +437,7 @@ def rng_export():
     """Snapshot of the global legacy np.random state as an MT19937 struct."""
     kind, key, pos, has_gauss, cached = np.random.get_state()
     st = MT19937()
-    C.memmove(st.key, key.ctypes.data, 624 * 4)
+    C.memmove(st.key, ptr(key), 624 * 4)
     st.pos = pos
     return st, (has_gauss, cached)
 
@@ -535,8 +545,8 @@ class Posterior:
         out = np.empty(lab.shape[0], dtype=np.int64)
         for c0 in range(0, lab.shape[0], 1024):
             part = np.ascontiguousarray(lab[c0:c0 + 1024])
-            check(load().bnpc_post_mpear(self._h, part.ctypes.data,
-                part.shape[0], out[c0:].ctypes.data), 'post_mpear')
+            check(load().bnpc_post_mpear(self._h, ptr(part),
+                part.shape[0], ptr(out[c0:])), 'post_mpear')
         return out
 
     def close(self):
@@ -799,8 +809,8 @@ def _mh_buffers(G, M):
         A = np.empty((G, M))
         args = MHArgs()
         args.G, args.M = G, M
-        args.sd_idx, args.U, args.u = (x.ctypes.data for x in (sd_idx, U, u))
-        args.A = A.ctypes.data
+        args.sd_idx, args.U, args.u = (ptr(x) for x in (sd_idx, U, u))
+        args.A = ptr(A)
         buf = _mh_scratch[key] = (args, sd_idx, U, u, A)
     return buf
 
@@ -857,15 +867,15 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
         kt = np.ascontiguousarray(known[0], dtype=np.float32)
         kp = np.ascontiguousarray(known[1], dtype=np.float64)
         assert kt.shape == kp.shape == (G, M)
-    a.old_theta, a.n1, a.n0 = old.ctypes.data, n1.ctypes.data, n0.ctypes.data
-    a.sd, a.n_sd = sd.ctypes.data, sd.size
+    a.old_theta, a.n1, a.n0 = ptr(old), ptr(n1), ptr(n0)
+    a.sd, a.n_sd = ptr(sd), sd.size
     a.tmin, a.tmax, a.FP, a.FN, a.p, a.q = tmin, tmax, FP, FN, p, q
     a.uniform_prior, a.trans_prob = int(bool(uniform)), int(bool(trans_prob))
-    a.known_theta = kt.ctypes.data if kt is not None else None
-    a.known_prior = kp.ctypes.data if kp is not None else None
-    a.new_theta = new.ctypes.data
-    a.prior_out = prior.ctypes.data if prior is not None else None
-    a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
+    a.known_theta = ptr(kt) if kt is not None else None
+    a.known_prior = ptr(kp) if kp is not None else None
+    a.new_theta = ptr(new)
+    a.prior_out = ptr(prior) if prior is not None else None
+    a.log_prob, a.declined = ptr(log_prob), ptr(declined)
     a.threads = threads_for(G * M) if threads is None else threads
     a.screen = None
     status = C.c_int(0)
@@ -877,8 +887,8 @@ def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,
         assert ids.size == G and n1.flags['WRITEABLE']
         with NumpyStream() as rng:
             check(lib.bnpc_label_counts_and_batch(handle,
-                C.addressof(kernels), rng, cells.ctypes.data,
-                ids.ctypes.data, C.byref(a), C.byref(status)),
+                C.addressof(kernels), rng, ptr(cells),
+                ptr(ids), C.byref(a), C.byref(status)),
                 'label_counts_and_batch')
     elif handle and not trans_prob:
         if draws is None:
@@ -911,9 +921,9 @@ def log_A(kernels, new, old, std, n1, n0, fmin, fmax, tmin, tmax, FP, FN, p,
     assert old.shape == std.shape == n1.shape == n0.shape == (G, M)
     A = np.empty((G, M))
     total = np.empty(G)
-    a = LogAArgs(G, M, new.ctypes.data, old.ctypes.data, std.ctypes.data,
-        n1.ctypes.data, n0.ctypes.data, fmin, fmax, tmin, tmax, FP, FN, p, q,
-        int(bool(uniform)), int(bool(clip)), A.ctypes.data, total.ctypes.data,
+    a = LogAArgs(G, M, ptr(new), ptr(old), ptr(std),
+        ptr(n1), ptr(n0), fmin, fmax, tmin, tmax, FP, FN, p, q,
+        int(bool(uniform)), int(bool(clip)), ptr(A), ptr(total),
         host_threads() if threads is None else threads)
     status = C.c_int(0)
     check(load().bnpc_log_accept(C.addressof(kernels), C.byref(a),
@@ -939,22 +949,22 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
     new = np.empty((G, M), dtype=np.float32)
     log_prob = np.empty(G)
     declined = np.empty(G, dtype=np.int64)
-    a.old_theta, a.n1, a.n0 = theta3.ctypes.data, n1.ctypes.data, n0.ctypes.data
-    a.sd, a.n_sd = sd.ctypes.data, sd.size
+    a.old_theta, a.n1, a.n0 = ptr(theta3), ptr(n1), ptr(n0)
+    a.sd, a.n_sd = ptr(sd), sd.size
     a.tmin, a.tmax, a.FP, a.FN, a.p, a.q = tmin, tmax, FP, FN, p, q
     a.uniform_prior = int(bool(uniform))
     a.trans_prob = int(bool(trans_prob))
     a.known_theta = a.known_prior = a.prior_out = None
-    a.new_theta = new.ctypes.data
-    a.log_prob, a.declined = log_prob.ctypes.data, declined.ctypes.data
+    a.new_theta = ptr(new)
+    a.log_prob, a.declined = ptr(log_prob), ptr(declined)
     a.threads = threads_for(G * M) if threads is None else threads
     a.screen = None
     status = C.c_int(0)
     scan_prob = C.c_double(0.0)
     with NumpyStream() as rng:
         check(load().bnpc_rg_scan_step(ctx._h, C.addressof(kernels), rng, view,
-            n, rg_assignment.ctypes.data, float(DP_a), C.byref(a),
-            n1.ctypes.data, n0.ctypes.data, C.byref(scan_prob),
+            n, ptr(rg_assignment), float(DP_a), C.byref(a),
+            ptr(n1), ptr(n0), C.byref(scan_prob),
             C.byref(status)), 'rg_scan_step')
     return (status.value, new, n1, n0, (sd_idx, U, u), scan_prob.value,
         log_prob)
@@ -1003,12 +1013,12 @@ def _move_state(move, scan_no, ids, sizes, assignment, parameters, DP_a, sd,
     st.uniform_prior = int(bool(uniform))
     N, M = parameters.shape
     st.threads, st.threads_wide = threads_for(3 * M), host_threads()
-    st.K, st.ids, st.sizes = ids.size, ids.ctypes.data, sizes.ctypes.data
+    st.K, st.ids, st.sizes = ids.size, ptr(ids), ptr(sizes)
     st.N, st.M = N, M
-    st.assignment, st.parameters = assignment.ctypes.data, \
-        parameters.ctypes.data
+    st.assignment, st.parameters = ptr(assignment), \
+        ptr(parameters)
     st.param_stride = parameters.strides[0] // 4
-    st.DP_a, st.sd, st.n_sd = float(DP_a), sd.ctypes.data, sd.size
+    st.DP_a, st.sd, st.n_sd = float(DP_a), ptr(sd), sd.size
     st.FP, st.FN, st.p, st.q = float(FP), float(FN), float(p), float(q)
     st.tmin, st.tmax, st.fill = float(tmin), float(tmax), float(fill)
     return st
@@ -1104,8 +1114,8 @@ def beta_logpdf_f32(kernels, x, p, q, known=None, threads=None):
         assert kt.shape == kp.shape == x.shape
     check(load().bnpc_beta_logpdf_f32(C.addressof(kernels),
         ptr(x, C.c_float), x.size, p, q,
-        kt.ctypes.data if kt is not None else None,
-        kp.ctypes.data if kp is not None else None, ptr(out, C.c_double),
+        ptr(kt) if kt is not None else None,
+        ptr(kp) if kp is not None else None, ptr(out, C.c_double),
         C.byref(total), threads_for(x.size) if threads is None else threads),
         'beta_logpdf_f32')
     return out, total.value
@@ -1134,7 +1144,7 @@ class Context:
         if planes is not None:      # bnpc_amd.bitplanes.BitPlanes
             N, M = data.shape
             self._keep = planes = np.ascontiguousarray(planes, dtype='<u8')
-            check(lib.bnpc_create_planes(device, N, M, planes.ctypes.data,
+            check(lib.bnpc_create_planes(device, N, M, ptr(planes),
                 C.byref(handle)), 'create_planes')
             del self._keep
         elif codes is not None:
@@ -1367,13 +1377,13 @@ class Context:
         u = np.ascontiguousarray(draws[2], dtype=np.float64)
         a = MHArgs()
         a.G, a.M = G, M
-        a.old_theta, a.sd, a.n_sd = old.ctypes.data, sd.ctypes.data, sd.size
+        a.old_theta, a.sd, a.n_sd = ptr(old), ptr(sd), sd.size
         a.tmin, a.tmax, a.FP, a.FN, a.p, a.q = tmin, tmax, FP, FN, p, q
         a.uniform_prior, a.trans_prob = int(bool(uniform)), 0
-        a.sd_idx, a.U, a.u = sd_idx.ctypes.data, U.ctypes.data, u.ctypes.data
+        a.sd_idx, a.U, a.u = ptr(sd_idx), ptr(U), ptr(u)
         flags = np.empty((G, M), dtype=np.uint8)
         check(self._lib.bnpc_mh_screen(self._h, counts_src, C.byref(a),
-            flags.ctypes.data), 'mh_screen')
+            ptr(flags)), 'mh_screen')
         return flags
 
     def mh_screen_stats(self):

@@ -859,8 +859,8 @@ class CRP:
             -1 if whole else pos, _lib.host_threads())
         if hint is not None and whole and not late.size:
             # columns 0..cols.size-1 of ll are the hint's columns
-            st.hint = hint[0].ctypes.data
-            st.hint_prior = hint[1].ctypes.data
+            st.hint = _lib.ptr(hint[0])
+            st.hint_prior = _lib.ptr(hint[1])
             st.hint_cols = cols.size
             hook = getattr(ctx, 'matrix_wait_hook', None)
             if hook is not None:
@@ -885,11 +885,11 @@ class CRP:
             st.birth_view = view
             st.birth_put = 0 if whole else 1
             st.birth_rows = n_rows
-            st.theta_host = theta.ctypes.data
+            st.theta_host = _lib.ptr(theta)
             st.beta_p, st.beta_q = float(self.p), float(self.q)
             st.tmin, st.tmax = TMIN, TMAX
             st.FP, st.FN = float(self.FP), float(self.FN)
-            st.born, st.born_cap = born_buf.ctypes.data, born_buf.size
+            st.born, st.born_cap = _lib.ptr(born_buf), born_buf.size
         while True:
             st.n_born = 0
             with _lib.NumpyGaussStream() as (rng, gauss):
