@@ -1025,7 +1025,8 @@ class CRP:
         if self.beta_prior_uniform or not cache:
             return None
         c_ids, c_theta, c_prior = cache
-        if c_ids.size == ids.size and np.array_equal(c_ids, ids):
+        if c_ids.size == ids.size and c_ids.dtype == ids.dtype \
+                and c_ids.tobytes() == ids.tobytes():
             return c_theta, c_prior
         pos = {int(cl): g for g, cl in enumerate(c_ids)}
         take = np.array([pos.get(int(cl), -1) for cl in ids], dtype=np.int64)
