@@ -79,12 +79,11 @@ inline double np_sum(const double *a, int64_t n)
     return out;
 }
 
-// np.random.choice(K, p=p) of the legacy RandomState: cdf = cumsum(p);
-// cdf /= cdf[-1]; searchsorted(random_sample(), side='right')
-int64_t choice_p(bnpc_mt19937 *rng, const double *p, int64_t K,
-                 std::vector<double> &cdf, double u)
+// np.random.choice(K, p=p) of the legacy RandomState given its uniform u:
+// cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, side='right')
+int64_t choice_p(const double *p, int64_t K, std::vector<double> &cdf,
+                 double u)
 {
-    (void)rng;
     cdf.resize((size_t)K);
     double s = 0.0;
     for (int64_t k = 0; k < K; k++) {
@@ -99,7 +98,7 @@ int64_t choice_p(bnpc_mt19937 *rng, const double *p, int64_t K,
 struct Scratch {
     std::vector<int64_t> cells, others, rg, labels, perm, target;
     std::vector<double> probs, cdf, work, L, ll, tmp, U, u, A, std2;
-    std::vector<int32_t> n1, n0, sd_idx, cnt1, cnt0;
+    std::vector<int32_t> n1, n0, sd_idx;
     std::vector<float> rows, fresh, gather;
 };
 
@@ -149,7 +148,7 @@ bool propose_split(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         s.probs[i] = (double)st->sizes[i] / (double)tot;
     int64_t pos;
     for (;;) {
-        pos = choice_p(rng, s.probs.data(), K, s.cdf, mt_double(rng));
+        pos = choice_p(s.probs.data(), K, s.cdf, mt_double(rng));
         if (pos >= K) return false;
         s.cells.clear();
         gather_cells(st->assignment, st->N, st->ids[pos], s.cells);
@@ -191,14 +190,14 @@ bool propose_merge(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     // both looked up in the same cdf; a repeated pick is redrawn with the
     // first one's probability zeroed
     const double u0 = mt_double(rng), u1 = mt_double(rng);
-    int64_t a = choice_p(rng, s.probs.data(), K, s.cdf, u0);
+    int64_t a = choice_p(s.probs.data(), K, s.cdf, u0);
     int64_t b = std::upper_bound(s.cdf.begin(), s.cdf.end(), u1)
                 - s.cdf.begin();
     if (a >= K || b >= K) return false;
     while (a == b) {
         std::vector<double> p(s.probs);
         p[(size_t)a] = 0.0;
-        b = choice_p(rng, p.data(), K, s.cdf, mt_double(rng));
+        b = choice_p(p.data(), K, s.cdf, mt_double(rng));
         if (b >= K) return false;
     }
     s.cells.clear();
