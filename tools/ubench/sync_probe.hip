@@ -104,5 +104,35 @@ int main()
                    t_launch[t_launch.size() / 2], t_flag[t_flag.size() / 2]);
         }
     }
+    // mode 3 / 4: an event recorded behind the kernel, waited for with
+    // hipEventSynchronize / polled with hipEventQuery; mode 5: hipStreamQuery
+    {
+        hipEvent_t ev;
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        unsigned *other;
+        hipHostMalloc(&other, 64, hipHostMallocDefault);
+        unsigned *dother;
+        hipHostGetDevicePointer((void **)&dother, other, 0);
+        for (int mode = 3; mode <= 5; mode++) {
+            std::vector<double> t_done;
+            for (unsigned r = 1; r <= 2000; r++) {
+                double t0 = now();
+                hipLaunchKernelGGL(k_flag, dim3(1), dim3(64), 0, s, dother, r, 2000);
+                if (mode != 5) hipEventRecord(ev, s);
+                if (mode == 3) hipEventSynchronize(ev);
+                else if (mode == 4) while (hipEventQuery(ev) == hipErrorNotReady) {}
+                else while (hipStreamQuery(s) == hipErrorNotReady) {}
+                double t2 = now();
+                if (other[0] != r) printf("result not visible at %u\n", r);
+                if (r > 100) t_done.push_back(t2 - t0);
+            }
+            std::sort(t_done.begin(), t_done.end());
+            printf("%s: returned %.2f us after the launch began\n",
+                   mode == 3 ? "event record + hipEventSynchronize"
+                   : mode == 4 ? "event record + hipEventQuery poll "
+                               : "hipStreamQuery poll               ",
+                   t_done[t_done.size() / 2]);
+        }
+    }
     return 0;
 }
