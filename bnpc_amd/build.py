@@ -18,12 +18,13 @@ HEADERS = [os.path.join(ROOT, 'include', 'bnpc_hip.h'),
     os.path.join(PKG, 'csrc', 'bnpc_internal.h')]
 TARGET = os.path.join(PKG, 'libbnpc_hip.so')
 # BNPC_SANITIZE=thread|address,undefined builds the HOST side instrumented
-# into libbnpc_hip.<sanitizer>.so next to the product library (CPU runs only:
-# the GPU pool has no sanitizer support); load it with BNPC_LIB=<path> and the
-# matching runtime in LD_PRELOAD (tools/run_sanitized.sh).
+# into build/libbnpc_hip.<sanitizer>.so (git- AND gpurun-ignored: CPU runs
+# only, the GPU pool has no sanitizer support); load it with BNPC_LIB=<path>
+# and the matching runtime in LD_PRELOAD (tools/run_sanitized.sh).
 SANITIZE = os.environ.get('BNPC_SANITIZE', '')
 if SANITIZE:
-    TARGET = os.path.join(PKG,
+    os.makedirs(os.path.join(ROOT, 'build'), exist_ok=True)
+    TARGET = os.path.join(ROOT, 'build',
         f'libbnpc_hip.{SANITIZE.replace(",", "_")}.so')
 
 

@@ -493,6 +493,55 @@ def test_example_data_trajectory_matches_reference(golden_dir):
     np.testing.assert_allclose(res['MAP'], t['ex_fixed_MAP'], rtol=1e-9)
 
 
+def test_example_data_learned_errors_prefix_matches_reference(golden_dir):
+    """Config 1 as BASELINE.json states it (the CLI without -FP/-FN is the
+    learned-error model, libs/CRP_learning_errors.py:52-111): example_data,
+    seed 42.  The DEVICE chain walks the reference's own trajectory for the
+    first 40 recorded states (beyond that the golden SciPy 1.7.1 and this
+    stack's scalar truncnorm differ by an ulp, SURVEY.md Appendix A - the same
+    prefix tests/test_oracle_golden.py pins for the oracle), ML / FN / FP to
+    1e-8; and the 60 x 40 split-merge-heavy learned-error chain for 50."""
+    from bnpc_amd.io import load_data
+    t = np.load(os.path.join(golden_dir, 'trajectories.npz'))
+    data = load_data(os.path.join(golden_dir, 'example_data.csv'))
+    res = H.run_chain(H.make(P, 'learn', data), 200, 42, eup=.25)
+    n = 40
+    assert np.array_equal(res['assignments'][:n],
+        t['ex_learn_assignments'][:n])
+    for key in ('ML', 'FN', 'FP', 'DP_alpha'):
+        np.testing.assert_allclose(res[key][:n], t[f'ex_learn_{key}'][:n],
+            rtol=1e-8, err_msg=key)
+    np.testing.assert_allclose(res['MAP'][:n], t['ex_learn_MAP'][:n],
+        rtol=1e-8)
+    small = decode(t['small_data'])
+    res = H.run_chain(H.make(P, 'learn', small), 120, 7, sm_prob=.5,
+        sm_steps=2, eup=.25)
+    n = 50
+    assert np.array_equal(res['assignments'][:n],
+        t['sm_learn_assignments'][:n])
+    for key in ('ML', 'FN', 'FP'):
+        np.testing.assert_allclose(res[key][:n], t[f'sm_learn_{key}'][:n],
+            rtol=1e-8, err_msg=key)
+
+
+def test_eight_chains_in_workers_equal_in_process_chains():
+    """Configs 4 / 5 are `-n 8`: eight forked workers, eight device contexts
+    at once (libs/MCMC.py:100-135).  Config 4's generator at 2000 x 400, 30
+    steps through MCMC.run with the pool: every worker's results are
+    bit-equal to the chain of the same seed run alone in a process of its own,
+    every worker runs on the device ordinal device_for_chain gives it, and no
+    /dev/shm block is left behind (tests/eight_chains_check.py, in a fresh
+    interpreter: this one has touched the GPU and would spawn, not fork)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable,
+        os.path.join(root, 'tests', 'eight_chains_check.py'), '8', '2000',
+        '400', '30'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert 'EIGHT CHAINS OK' in res.stdout, res.stdout[-3000:]
+
+
 def test_config2_chain_matches_oracle():
     """BASELINE config 2 (1000 x 200, 10 % missing, fixed FP/FN), 12 steps
     including the first sweep from K0 ~ 630 clusters."""

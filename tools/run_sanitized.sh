@@ -15,7 +15,7 @@ case "$SAN" in
   *) PRE=$RT/libclang_rt.asan-x86_64.so ;;
 esac
 BNPC_SANITIZE=$SAN python3 -m bnpc_amd.build
-export BNPC_LIB=$ROOT/bnpc_amd/libbnpc_hip.${SAN//,/_}.so
+export BNPC_LIB=$ROOT/build/libbnpc_hip.${SAN//,/_}.so
 # Python itself is not instrumented: report races in the library only
 LOGDIR=${SAN_LOG_DIR:-/tmp/bnpc_sanitizer}
 rm -rf "$LOGDIR"; mkdir -p "$LOGDIR"
