@@ -87,8 +87,9 @@ def new_chain(model, learned, total_steps, config=None):
 
 
 def step(chain, i, burn_in):
-    chain.do_step()
-    chain.update_results(i, i < burn_in)
+    """do_step + update_results: ONE native call on the device model
+    (Chain.step -> CRP.native_step), the two calls for the oracle."""
+    chain.step(i, i < burn_in)
 
 
 class MoveClock:
@@ -104,6 +105,13 @@ class MoveClock:
     def __init__(self, model):
         self.acc = {}
         self.on = False
+        self.model = model
+        # a model that makes whole steps natively keeps this clock itself
+        # (bnpc_chain.clock_ns); wrapping its methods would send every step
+        # back through the interpreter
+        self.native0 = self._native_clocks()
+        if self.native0 is not None:
+            return
         for name in self.MOVES:
             fn = getattr(model, name, None)
             if fn is None:
@@ -125,7 +133,29 @@ class MoveClock:
                 return out
             setattr(model, name, timed)
 
+    def _native_clocks(self):
+        nat = getattr(self.model, '_nat', None)
+        if nat is None or os.environ.get('BNPC_NATIVE_STEP', '1') == '0':
+            return None
+        return list(nat.st.clock_ns), list(nat.st.clock_calls)
+
     def report(self, steps, elapsed):
+        if self.native0 is not None:
+            from bnpc_amd import _lib
+            ns, calls = self._native_clocks()
+            out, total = {}, 0.0
+            for i, key in enumerate(_lib.STEP_CLOCKS):
+                n = calls[i] - self.native0[1][i]
+                t = (ns[i] - self.native0[0][i]) * 1e-9
+                if n:
+                    out[key] = {'calls': n,
+                        'ms_per_call': round(1e3 * t / n, 4),
+                        'ms_per_step': round(1e3 * t / steps, 4)}
+                    total += t
+            out['other'] = {'ms_per_step':
+                round(1e3 * (elapsed - total) / steps, 4)}
+            out['clock'] = 'native (bnpc_chain.clock_ns)'
+            return out
         short = {'update_assignments_Gibbs': 'gibbs',
             'update_DP_alpha': 'dp_alpha', 'update_parameters': 'parameters',
             'update_error_rates': 'error_rates',
@@ -425,6 +455,7 @@ def main():
     if rank == 0:
         from bnpc_amd import _lib, model as pmodel
         seen, kept = model._dev().mh_screen_stats()
+        stats = model.host_stats()
         host_info = {
             'threads': _lib.host_threads(),
             'threads_wide_batches': _lib.threads_for(K_end * M),
@@ -441,10 +472,14 @@ def main():
             # the host still had to evaluate (accepted or in doubt)
             # cells of all sweeps so far / decided from the device's hint
             # without a scan / of those, between the row's two best columns
-            'sweep_cells': getattr(model, '_swept', 0),
-            'sweep_hinted': getattr(model, '_hint_used', 0),
-            'sweep_pairs': getattr(model, '_pair_used', 0),
-            'sweep_triples': getattr(model, '_triple_used', 0),
+            'sweep_cells': stats['swept'],
+            'sweep_hinted': stats['hint_used'],
+            'sweep_pairs': stats['pair_used'],
+            'sweep_triples': stats['triple_used'],
+            # steps made as ONE native call (bnpc_chain_step) / split-merge
+            # moves made as one native call (bnpc_sm_move)
+            'native_steps': stats['native_steps'],
+            'native_moves': stats['native_moves'],
             'mh_screened': seen,
             'mh_left_to_host': round(kept / seen, 4) if seen else None,
         }

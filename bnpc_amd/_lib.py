@@ -114,9 +114,51 @@ class LogAArgs(C.Structure):
         ('sum', C.c_void_p), ('threads', C.c_int)]
 
 
+class ChainState(C.Structure):
+    """bnpc_chain (include/bnpc_hip.h): the model and the knobs of one chain
+    as bnpc_chain_step reads and updates them"""
+    _fields_ = [('N', _i64), ('M', _i64), ('assignment', C.c_void_p),
+        ('parameters', C.c_void_p), ('param_stride', _i64),
+        ('ids', C.c_void_p), ('sizes', C.c_void_p), ('K', _i64),
+        ('crp_prior', C.c_void_p), ('DP_a', C.c_double),
+        ('dpa_shape', C.c_double), ('dpa_rate', C.c_double),
+        ('FP', C.c_double), ('FN', C.c_double), ('p', C.c_double),
+        ('q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
+        ('mix0', C.c_double), ('mix1', C.c_double),
+        ('uniform_prior', C.c_int32), ('learning', C.c_int32),
+        ('sd', C.c_void_p), ('n_sd', _i64), ('FP_prior', C.c_double * 4),
+        ('FN_prior', C.c_double * 4), ('FP_sd', C.c_double * 3),
+        ('FN_sd', C.c_double * 3), ('sm_prob', C.c_double),
+        ('dpa_prob', C.c_double), ('error_prob', C.c_double),
+        ('sm_ratios', C.c_double * 2), ('sm_steps', C.c_int32),
+        ('fix_assign', C.c_int32), ('threads', C.c_int32),
+        ('threads_wide', C.c_int32), ('wide_from', _i64),
+        ('sweep_bytes', _i64), ('view_move', C.c_int32),
+        ('sweep_hint', C.c_int32), ('gauss', C.c_void_p),
+        ('phase', C.c_int32), ('need', C.c_int32),
+        ('rec_scalars', C.c_void_p * 5), ('rec_assignment', C.c_void_p),
+        ('rec_params', C.c_void_p), ('rec_params_cap', _i64),
+        ('move', C.c_int32), ('sm_accepted', C.c_int32), ('sm_cells', _i64),
+        ('alpha_updated', C.c_int32), ('errors_updated', C.c_int32),
+        ('FP_accepted', C.c_int32), ('FN_accepted', C.c_int32),
+        ('par_declined', _i64), ('par_accepted', _i64),
+        ('rec_params_done', C.c_int32), ('pad_', C.c_int32),
+        ('ML', C.c_double), ('lprior', C.c_double), ('swept', _i64),
+        ('hint_used', _i64), ('pair_used', _i64), ('triple_used', _i64),
+        ('native_moves', _i64), ('steps', _i64), ('clock_ns', _i64 * 10),
+        ('clock_calls', _i64 * 10), ('work', C.c_void_p)]
+
+
+PHASE_ASSIGN, PHASE_ALPHA, PHASE_PARAMS, PHASE_ERRORS, PHASE_RECORD = range(5)
+NEED_NONE, NEED_MOVE, NEED_GIBBS, NEED_PARAMS, NEED_ERRORS, NEED_RECORD = \
+    range(6)
+STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
+    'merge_rejected', 'dp_alpha', 'parameters', 'error_rates', 'record')
+
+
 # the version bnpc_abi_version() of a matching library reports (bumped with
 # every change of a structure or signature of include/bnpc_hip.h)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
@@ -237,6 +279,16 @@ SIGNATURES = {
     'bnpc_post_destroy': (C.c_int, [C.c_void_p]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
+    'bnpc_mt_gamma': (C.c_int, [C.POINTER(MT19937), C.c_void_p, C.c_double,
+        C.c_double, C.POINTER(C.c_double)]),
+    'bnpc_chain_open': (C.c_int, [C.POINTER(ChainState)]),
+    'bnpc_chain_close': (C.c_int, [C.POINTER(ChainState)]),
+    'bnpc_chain_step': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
+        C.POINTER(ChainState)]),
+    'bnpc_chain_update_alpha': (C.c_int, [C.c_void_p, C.POINTER(MT19937),
+        C.POINTER(ChainState)]),
+    'bnpc_gamma_logpdf_scalar': (C.c_int, [C.c_void_p, C.c_double, C.c_double,
+        C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -1082,6 +1134,51 @@ def move_propose(kernels, move, ids, sizes, assignment):
         return None
     return (cells[:n_cells.value].copy(), n_first.value, picked,
         size_data.value, others[:ids.size - 1].copy())
+
+
+def gamma(shape, scale):
+    """np.random.gamma(shape, scale), one draw, natively on the global stream
+    (bnpc_mt_gamma)."""
+    out = C.c_double(0.0)
+    with NumpyGaussStream() as (rng, g):
+        check(load().bnpc_mt_gamma(rng, g, float(shape), float(scale),
+            C.byref(out)), 'mt_gamma')
+    return out.value
+
+
+def gamma_logpdf_scalar(kernels, x, a, loc):
+    """scipy.stats.gamma.logpdf(x, a, loc) on the kernel table (the prior of
+    DP_a as bnpc_chain_step evaluates it), or None (left to SciPy)."""
+    out, status = C.c_double(0.0), C.c_int(0)
+    check(load().bnpc_gamma_logpdf_scalar(C.addressof(kernels), float(x),
+        float(a), float(loc), C.byref(out), C.byref(status)),
+        'gamma_logpdf_scalar')
+    return None if status.value else out.value
+
+
+class NativeChain:
+    """A bnpc_chain with its work area (bnpc_chain_open / _close) and the
+    arrays it points at: the live clusters in dict order (capacity N)."""
+
+    def __init__(self, N, M):
+        self.st = ChainState()
+        self.st.N, self.st.M = N, M
+        self.ids = np.zeros(N, dtype=np.int64)
+        self.sizes = np.zeros(N, dtype=np.int64)
+        self.st.ids, self.st.sizes = ptr(self.ids), ptr(self.sizes)
+        self.keep = []          # arrays the structure points at
+        self._lib = load()
+        check(self._lib.bnpc_chain_open(C.byref(self.st)), 'chain_open')
+
+    def close(self):
+        if getattr(self, 'st', None) is not None and self.st.work:
+            self._lib.bnpc_chain_close(C.byref(self.st))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
 
 
 def tn_ppf_scalar(kernels, q, a, b, loc, scale):

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(PKG)
 SOURCES = [os.path.join(PKG, 'csrc', 'bnpc_kernels.hip'),
     os.path.join(PKG, 'csrc', 'bnpc_sweeps.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_moves.cpp'),
+    os.path.join(PKG, 'csrc', 'bnpc_step.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_hostmath.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_mt.cpp'),
     os.path.join(PKG, 'csrc', 'bnpc_ingest.cpp'),

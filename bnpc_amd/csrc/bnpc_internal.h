@@ -29,6 +29,22 @@ void bnpc_legacy_beta_row(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t M,
                           const unsigned long long *row, double p, double q,
                           double tmin, double tmax, float *theta);
 
+// bnpc_kernels.hip: bumped by every bnpc_colcounts_by_label on the context -
+// whoever remembers "the resident per-cluster counts are those of state X"
+// (bnpc_chain_step) remembers this number with it
+uint64_t bnpc_ctx_label_counts_generation(const bnpc_ctx *c);
+// bnpc_sweeps.cpp: a cluster for `cell` opened by the caller of
+// bnpc_gibbs_sweep when the sweep returned the cell through st->new_cell (no
+// spare column was left; the caller has made room): exactly what the sweep
+// does itself while it has room (libs/CRP.py:281-282, 291-299, 183-188)
+int bnpc_sweep_open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
+                            int64_t cell, double *ll, int64_t *assignment,
+                            int64_t *col_of_id, int64_t *col_id,
+                            int64_t *col_size, int64_t *order);
+// bnpc_mt.cpp: np.random.gamma(shape, scale) of the legacy stream
+double bnpc_legacy_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
+                         double scale);
+
 // bnpc_kernels.hip: counts of the two launch clusters of a restricted scan +
 // the (screened) parameter batch on one stream synchronisation
 int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
@@ -112,5 +128,86 @@ static inline double bnpc_log_diff_pi1(double log_p, double log_q)
     const double im = E * sin_pi;
     return (log(hypot(re, im)) + 0.0) + log_p;
 }
+
+
+#ifdef __cplusplus
+#include <algorithm>
+#include <vector>
+// ---------------------------------------------------------------------------
+// NumPy expressions restated for the native moves / steps (bnpc_moves.cpp,
+// bnpc_step.cpp): NumPy's own float64 log loop, np.sum's pairwise order, the
+// legacy np.random.choice(p=...)
+// ---------------------------------------------------------------------------
+static inline void np_loop(bnpc_uloop f, void *data, const double *in,
+                           double *out, intptr_t n)
+{
+    if (n <= 0) return;
+    char *args[2] = {(char *)in, (char *)out};
+    intptr_t dims[1] = {n};
+    intptr_t steps[2] = {(intptr_t)sizeof(double), (intptr_t)sizeof(double)};
+    f(args, dims, steps, data);
+}
+
+static inline double np_log1(const bnpc_host_kernels *k, double x)
+{
+    double out;
+    np_loop(k->np_log, k->np_log_data, &x, &out, 1);
+    return out;
+}
+
+// NumPy's pairwise summation of a contiguous float64 run
+// (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum): plain loop
+// below 8 elements, 8 interleaved partial sums up to 128, halves (the first
+// a multiple of 8) above.
+static inline double np_pairwise(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = -0.0;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3]))
+                     + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+// np.sum(a) of a contiguous float64 vector: the reduction starts from the
+// additive identity and adds the pairwise sum of every run of 8192 elements
+// (the iterator's buffer size) in turn
+static inline double np_sum(const double *a, int64_t n)
+{
+    double out = 0.0;
+    for (int64_t at = 0; at < n; at += 8192)
+        out = out + np_pairwise(a + at, n - at < 8192 ? n - at : 8192);
+    return out;
+}
+
+// np.random.choice(K, p=p) of the legacy RandomState given its uniform u:
+// cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, side='right')
+static inline int64_t np_choice_p(const double *p, int64_t K,
+                                  std::vector<double> &cdf, double u)
+{
+    cdf.resize((size_t)K);
+    double s = 0.0;
+    for (int64_t k = 0; k < K; k++) {
+        s = k ? s + p[k] : p[0];
+        cdf[k] = s;
+    }
+    const double last = cdf[K - 1];
+    for (int64_t k = 0; k < K; k++) cdf[k] /= last;
+    return std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin();
+}
+#endif
 
 #endif

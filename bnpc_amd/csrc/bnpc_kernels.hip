@@ -52,7 +52,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 6; }
+extern "C" int bnpc_abi_version(void) { return 7; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -166,6 +166,7 @@ struct bnpc_ctx {
     // resident per-cluster counts of the last bnpc_colcounts_by_label
     DevBuf lab_cnt;
     int64_t lab_K = 0;
+    uint64_t lab_gen = 0;       // bumped by every bnpc_colcounts_by_label
     int64_t cnt_rows = 0;       // segments of the last bnpc_view_counts (c->cnt)
     // pinned host buffers: the sweep's ll matrix / small reductions
     void *pin = nullptr;
@@ -2935,6 +2936,7 @@ static int colcounts_by_label_impl(bnpc_ctx *c, const int64_t *assignment,
 {
     if (defer) *defer = nullptr;
     ARGCHK(c && assignment && ids, "NULL argument");
+    c->lab_gen++;
     ARGCHK(K > 0, "K must be positive");
     HIPCHK(hipSetDevice(c->device));
     // counting sort of the cells by the position of their label in ids[]
@@ -2982,6 +2984,11 @@ static int colcounts_by_label_impl(bnpc_ctx *c, const int64_t *assignment,
         d2h_finish(b);
     }
     return 0;
+}
+
+uint64_t bnpc_ctx_label_counts_generation(const bnpc_ctx *c)
+{
+    return c ? c->lab_gen : 0;
 }
 
 extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,

@@ -24,77 +24,6 @@
 
 namespace {
 
-inline void np_loop(bnpc_uloop f, void *data, const double *in, double *out,
-                    intptr_t n)
-{
-    if (n <= 0) return;
-    char *args[2] = {(char *)in, (char *)out};
-    intptr_t dims[1] = {n};
-    intptr_t steps[2] = {(intptr_t)sizeof(double), (intptr_t)sizeof(double)};
-    f(args, dims, steps, data);
-}
-
-inline double np_log1(const bnpc_host_kernels *k, double x)
-{
-    double out;
-    np_loop(k->np_log, k->np_log_data, &x, &out, 1);
-    return out;
-}
-
-// NumPy's pairwise summation of a contiguous float64 run
-// (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum): plain loop
-// below 8 elements, 8 interleaved partial sums up to 128, halves (the first
-// a multiple of 8) above.
-double pairwise(const double *a, int64_t n)
-{
-    if (n < 8) {
-        double res = -0.0;
-        for (int64_t i = 0; i < n; i++) res += a[i];
-        return res;
-    }
-    if (n <= 128) {
-        double r[8];
-        for (int j = 0; j < 8; j++) r[j] = a[j];
-        int64_t i;
-        for (i = 8; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; j++) r[j] += a[i + j];
-        double res = ((r[0] + r[1]) + (r[2] + r[3]))
-                     + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; i++) res += a[i];
-        return res;
-    }
-    int64_t n2 = n / 2;
-    n2 -= n2 % 8;
-    return pairwise(a, n2) + pairwise(a + n2, n - n2);
-}
-
-// np.sum(a) of a contiguous float64 vector: the reduction starts from the
-// additive identity and adds the pairwise sum of every run of 8192 elements
-// (the iterator's buffer size) in turn
-inline double np_sum(const double *a, int64_t n)
-{
-    double out = 0.0;
-    for (int64_t at = 0; at < n; at += 8192)
-        out = out + pairwise(a + at, n - at < 8192 ? n - at : 8192);
-    return out;
-}
-
-// np.random.choice(K, p=p) of the legacy RandomState given its uniform u:
-// cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, side='right')
-int64_t choice_p(const double *p, int64_t K, std::vector<double> &cdf,
-                 double u)
-{
-    cdf.resize((size_t)K);
-    double s = 0.0;
-    for (int64_t k = 0; k < K; k++) {
-        s = k ? s + p[k] : p[0];
-        cdf[k] = s;
-    }
-    const double last = cdf[K - 1];
-    for (int64_t k = 0; k < K; k++) cdf[k] /= last;
-    return std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin();
-}
-
 struct Scratch {
     std::vector<int64_t> cells, others, rg, labels, perm, target;
     std::vector<double> probs, cdf, work, L, ll, tmp, U, u, A, std2;
@@ -148,7 +77,7 @@ bool propose_split(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         s.probs[i] = (double)st->sizes[i] / (double)tot;
     int64_t pos;
     for (;;) {
-        pos = choice_p(s.probs.data(), K, s.cdf, mt_double(rng));
+        pos = np_choice_p(s.probs.data(), K, s.cdf, mt_double(rng));
         if (pos >= K) return false;
         s.cells.clear();
         gather_cells(st->assignment, st->N, st->ids[pos], s.cells);
@@ -190,14 +119,14 @@ bool propose_merge(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     // both looked up in the same cdf; a repeated pick is redrawn with the
     // first one's probability zeroed
     const double u0 = mt_double(rng), u1 = mt_double(rng);
-    int64_t a = choice_p(s.probs.data(), K, s.cdf, u0);
+    int64_t a = np_choice_p(s.probs.data(), K, s.cdf, u0);
     int64_t b = std::upper_bound(s.cdf.begin(), s.cdf.end(), u1)
                 - s.cdf.begin();
     if (a >= K || b >= K) return false;
     while (a == b) {
         std::vector<double> p(s.probs);
         p[(size_t)a] = 0.0;
-        b = choice_p(p.data(), K, s.cdf, mt_double(rng));
+        b = np_choice_p(p.data(), K, s.cdf, mt_double(rng));
         if (b >= K) return false;
     }
     s.cells.clear();

@@ -442,6 +442,28 @@ inline double lg_beta(Words &w, bnpc_legacy_gauss *g, double a, double b)
 
 }  // namespace
 
+// np.random.gamma(shape, scale) of the legacy stream
+// (numpy/random/src/legacy/legacy-distributions.c: legacy_gamma = scale *
+// legacy_standard_gamma): the two draws of CRP.update_DP_alpha
+// (libs/CRP.py:386-410)
+double bnpc_legacy_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
+                         double scale)
+{
+    Words w(rng);
+    return scale * lg_standard_gamma(w, g, shape);
+}
+
+extern "C" int bnpc_mt_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g,
+                             double shape, double scale, double *out)
+{
+    if (!rng || !g || !out || !(shape >= 0.0) || !(scale >= 0.0)) {
+        bnpc_set_error("bad argument: mt_gamma");
+        return 2;
+    }
+    *out = bnpc_legacy_gamma(rng, g, shape, scale);
+    return 0;
+}
+
 // One profile row from the {ones, zeros} words of ONE cell's observations
 // (a cluster it opens, libs/CRP.py:183-188): theta[m] = float32(clip(Beta(p +
 // [x_m = 1], q + [x_m = 0]))).

@@ -327,6 +327,22 @@ static int open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng, int64_t cell,
     return 0;
 }
 
+int bnpc_sweep_open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
+                            int64_t cell, double *ll, int64_t *assignment,
+                            int64_t *col_of_id, int64_t *col_id,
+                            int64_t *col_size, int64_t *order)
+{
+    if (!st || !rng || !ll || !assignment || !col_of_id || !col_id
+        || !col_size || !order || !st->birth_ctx || st->n_cols >= st->ld
+        || st->n_born >= st->born_cap) {
+        bnpc_set_error("bad argument: sweep_open_cluster");
+        return 2;
+    }
+    int64_t free_hint = 0;
+    return open_cluster(st, rng, cell, ll, assignment, col_of_id, col_id,
+                        col_size, order, &free_hint);
+}
+
 // A cell torn between two live entries (`top`, the first maximum, and `sec`,
 // d2 = runner-up - top <= 0 apart), every other of the A + 1 entries on the
 // 1e-15 floor: which entry does the uniform u pick?  Only WHICH interval of

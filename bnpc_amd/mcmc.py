@@ -176,6 +176,28 @@ class TraceStore:
         d['FP'][slot] = model.FP
         d['assignments'][slot] = model.assignment
 
+    def record_target(self, slot, with_params):
+        """Where a natively made step (CRP.native_step) writes the state it
+        records: (addresses of the ML / MAP / DP_alpha / FN / FP slots,
+        address of the assignment row, address of the parameter block of the
+        slot or 0 - the block does not exist before the first post-burn-in
+        sample -, its capacity in clusters)."""
+        from bnpc_amd._lib import ptr
+        d = self.data
+        scalars = [ptr(d[key]) + 8 * slot for key in self.SCALARS]
+        labels = d['assignments']
+        if labels.dtype != np.int64 or not labels.flags['C_CONTIGUOUS']:
+            return None
+        block, cap = 0, 0
+        params = d.get('params') if with_params else None
+        if params is not None and params.dtype == np.float32 \
+                and params.flags['C_CONTIGUOUS']:
+            row = slot - (self.slots - params.shape[0])
+            if 0 <= row < params.shape[0]:
+                cap = params.shape[1]
+                block = ptr(params) + 4 * row * cap * self.n_muts
+        return scalars, ptr(labels) + 8 * slot * self.n_cells, block, cap
+
     def put_params(self, slot, model):
         """MCMC.py:260-282: parameter rows of the populated clusters, zero
         padded to the largest cluster count seen.  The array is allocated a
@@ -364,11 +386,16 @@ class Chain:
         return self.trace.slots
 
     def do_step(self):
+        native = getattr(self.model, 'native_step', None)
+        if native is not None:
+            done = native(self.mcmc, self.fix_assign, self.learning_errors)
+            if done is not None:
+                self._tally_native(done)
+                return
         advance(self.model, self.mcmc, self.tally, self.fix_assign,
             self.learning_errors)
 
-    def update_results(self, step, burn_in=True):
-        """Record the state after `step` (MCMC.py:242-282)."""
+    def _slot(self, step, burn_in):
         trace = self.trace
         if step == trace.slots:     # open-ended runs outgrow their traces
             try:
@@ -376,9 +403,55 @@ class Chain:
             except MemoryError:     # wrap around; nothing is burn-in any more
                 step %= trace.slots
                 self.burn_in = np.nan
+        return step
+
+    def update_results(self, step, burn_in=True):
+        """Record the state after `step` (MCMC.py:242-282)."""
+        trace = self.trace
+        step = self._slot(step, burn_in)
         trace.put_state(step, self.model)
         if not burn_in:
             trace.put_params(step, self.model)
+
+    def _tally_native(self, done):
+        tally = self.tally
+        if done['sm'] is not None:
+            tally.add('splits' if done['move'] == 'split' else 'merges',
+                done['sm'])
+        declined, accepted = done['parameters']
+        tally.add('parameters', (accepted, declined))
+        if done['errors'] is not None:
+            tally.add('FP', done['errors'][0])
+            tally.add('FN', done['errors'][1])
+
+    def step(self, step, burn_in=True):
+        """do_step + update_results(step, burn_in): ONE native call when the
+        model offers it (CRP.native_step: the moves, the updates and the
+        recorded likelihood / prior without the interpreter in between), else
+        the two calls."""
+        native = getattr(self.model, 'native_step', None)
+        if native is None:
+            self.do_step()
+            self.update_results(step, burn_in)
+            return
+        trace = self.trace
+        slot = self._slot(step, burn_in)
+        target = trace.record_target(slot, not burn_in)
+        done = native(self.mcmc, self.fix_assign, self.learning_errors,
+            target) if target is not None else None
+        if done is None:
+            self.do_step()
+            self.update_results(slot, burn_in)
+            return
+        self._tally_native(done)
+        if not done['recorded']:
+            trace.put_state(slot, self.model)
+        if not burn_in:
+            if done.get('params_recorded'):
+                trace._k_seen = max(getattr(trace, '_k_seen', 0),
+                    len(self.model.cells_per_cluster))
+            else:
+                trace.put_params(slot, self.model)
 
     def _report(self, headline):
         print(f'\t{self}\tstep:\t{headline}\n\t\tmean MH accept. ratio:')
@@ -407,9 +480,7 @@ class Chain_steps(Chain):
         for step in range(1, todo + 1):
             if step % interval == 0 and self.verbosity > 1:
                 self._report(f'{step + init_steps: >3} / {todo + init_steps}')
-            self.do_step()
-            self.update_results(step + init_steps,
-                _before(step, self.burn_in))
+            self.step(step + init_steps, _before(step, self.burn_in))
         self.trace.finish()
         self.trace.data['burn_in'] = self.burn_in
 
@@ -431,8 +502,7 @@ class Chain_time(Chain):
                 left = (end - now).seconds / 60
                 self._report(f'{step: >3}\t(remaining: {left:.1f} mins.)')
             step += 1
-            self.do_step()
-            self.update_results(step, _before(now, self.burn_in))
+            self.step(step, _before(now, self.burn_in))
             now = datetime.now()
         self.trace.drop_unused_tail()
         self.trace.finish()

@@ -309,6 +309,79 @@ def _overrides_a_move_step(model):
     return not plain or not _MOVE_STEP_SET.isdisjoint(model.__dict__)
 
 
+# the methods a native STEP (bnpc_chain_step) stands for, on top of the moves'
+_STEP_METHODS = _MOVE_STEPS + ('update_assignments_Gibbs', '_gibbs_window',
+    '_sweep_order', '_new_cluster_ll', 'get_lpost_single_new_cluster',
+    'update_assignments_split_merge', 'do_split_move', 'do_merge_move',
+    '_native_move', 'update_DP_alpha', 'init_DP_prior', 'log_CRP_prior',
+    'update_parameters', '_label_counts', '_known_prior', '_remember_prior',
+    '_prior_density_sum', 'get_ll_full', 'get_ll_full_deferred', '_ll_total',
+    'get_lprior_full', '_memo', 'update_error_rates', 'MH_error_rates',
+    'get_ll_full_error', '_error_prior_logpdf')
+_STEP_SET = frozenset(_STEP_METHODS)
+_plain_step_classes = {}
+
+
+def _overrides_a_step_method(model):
+    """Whether the model's class (or the instance itself) replaces one of the
+    methods a native step is made of: only the two classes of this module as
+    they are take the one-call step."""
+    cls = type(model)
+    plain = _plain_step_classes.get(cls)
+    if plain is None:
+        base = CRP_errors_learning if issubclass(cls, CRP_errors_learning) \
+            else CRP
+        plain = _plain_step_classes[cls] = all(
+            getattr(cls, name, None) is getattr(base, name, None)
+            for name in _STEP_METHODS)
+    return not plain or not _STEP_SET.isdisjoint(model.__dict__)
+
+
+_STEP = {}
+
+
+def _native_step_allowed():
+    """Whether whole steps may be made natively in this process
+    (bnpc_chain_step): BNPC_NATIVE_STEP != 0, the kernel table with SciPy's
+    gammaln, the native Beta sampler, and the scalar pieces the step restates
+    on its own - np.random.gamma on the stream, the Gamma log-density of the
+    concentration parameter - bit-identical to NumPy's / SciPy's here."""
+    pid = os.getpid()
+    if _STEP.get('pid') != pid:
+        _STEP.clear()
+        _STEP.update(pid=pid, ok=False)
+        table = _native_kernels()
+        if table is not None and table.gammaln and _native_beta() \
+                and _lib.rng_live() is not None:
+            saved = np.random.get_state()
+            try:
+                ok = True
+                for shape, scale in ((71.7, 3.2), (.4, 1.), (1., 2.5),
+                        (5000.2, .11), (2.5, 7.)):
+                    for pre in (0, 1):
+                        np.random.seed(4242 + pre)
+                        if pre:
+                            np.random.normal()
+                        start = np.random.get_state()
+                        want = np.random.gamma(shape, scale)
+                        end = np.random.get_state()
+                        np.random.set_state(start)
+                        got = _lib.gamma(shape, scale)
+                        now = np.random.get_state()
+                        ok &= want == got and now[2:] == end[2:] \
+                            and np.array_equal(now[1], end[1])
+                for x, a, loc in ((70.71, 70.71, 1), (1 + 1e-15, 31.6, 1),
+                        (3.7, 2.0, 0.5), (224.0, 223.6, 1), (12.5, 100.0, 1)):
+                    ok &= _lib.gamma_logpdf_scalar(table, x, a, loc) \
+                        == float(fastdist.gamma_logpdf(x, a, loc))
+                _STEP['ok'] = bool(ok)
+            except Exception:       # noqa: BLE001
+                _STEP['ok'] = False
+            finally:
+                np.random.set_state(saved)
+    return _STEP['ok']
+
+
 class CRP:
     """DPMM of Bernoulli profiles with fixed error rates (libs/CRP.py:17)."""
 
@@ -348,6 +421,7 @@ class CRP:
         self._ctx = None
         self._newcl = None          # ((FP, FN), per-cell sums)
         self._lab = None            # per-cluster column counts cache
+        self._nat = None            # the native chain (bnpc_chain_step)
 
     def __getstate__(self):
         """Pickle / deepcopy (libs/MCMC.py:115-128): the device context and
@@ -360,6 +434,7 @@ class CRP:
         state['_ctx'] = None
         state['_newcl'] = None
         state['_lab'] = None
+        state['_nat'] = None
         state['_prior_rows'] = None
         state['_rg_view'] = None
         data = state.pop('data')
@@ -415,6 +490,8 @@ class CRP:
         return hit
 
     def close(self):
+        if getattr(self, '_nat', None) is not None:
+            self._nat.close()
         if self._ctx is not None:
             self._ctx.close()
         self._reset_device_state()
@@ -961,6 +1038,200 @@ class CRP:
         while i in self.cells_per_cluster:
             i += 1
         return i
+
+    # ------------------------------------------------------- a whole step
+    def native_step(self, knobs, fix_assign, learning, record=None):
+        """One step of the sampler - the move schedule of libs/MCMC.py:320-342
+        and the recording of :242-258 - as ONE native call (bnpc_chain_step),
+        when nothing stands in the way: a real device context, the kernel
+        table, the native samplers, no overridden method.  Returns None when
+        the step is not made here (nothing was drawn or changed: the caller
+        walks the schedule itself), else a dict:
+
+            move        None | 'split' | 'merge' | 'gibbs'
+            sm          [accepted, declined] of a split / merge move
+            parameters  (declined, accepted)
+            errors      None | (FP [acc, dec], FN [acc, dec])
+            recorded    whether `record` was served (ML, MAP, ... written)
+
+        record = (addresses of the ML / MAP / DP_alpha / FN / FP slots,
+        address of the assignment row, address of the parameter block or 0,
+        its capacity in clusters), or None: no recording (do_step alone).
+        Phases the library hands back (first steps with thousands of clusters,
+        an element left to SciPy) run through the methods of this class in
+        between, on the same stream."""
+        table = _native_kernels()
+        if table is None or _lib.env('BNPC_NATIVE_STEP', '1') == '0' \
+                or _lib.env('BNPC_TIMING') or not _native_step_allowed() \
+                or not _native_beta() or _overrides_a_step_method(self):
+            return None
+        ctx = self._dev()
+        theta = self.parameters
+        if not getattr(ctx, '_h', None) or theta is None \
+                or theta.dtype != np.float32 or not theta.flags['C_CONTIGUOUS'] \
+                or theta.shape != (self.cells_total, self.muts_total) \
+                or self.CRP_prior is None \
+                or self.CRP_prior.dtype != np.float64 \
+                or self.CRP_prior.size != self.cells_total + 2:
+            return None
+        nat = self._nat
+        if nat is None:
+            nat = self._nat = self._native_chain(learning)
+        st = nat.st
+        lib = nat._lib
+        # ---- the state as it is now ----
+        assignment = self.assignment
+        if assignment.dtype != np.int64 \
+                or not assignment.flags['C_CONTIGUOUS']:
+            assignment = self.assignment = np.ascontiguousarray(
+                assignment, dtype=np.int64)
+        self._state_to_chain(nat)
+        st.sm_prob = knobs['sm_prob']
+        st.dpa_prob = knobs['dpa_prob']
+        st.error_prob = knobs['error_prob'] if learning else 0.0
+        st.sm_ratios[0], st.sm_ratios[1] = knobs['sm_ratios']
+        st.sm_steps = knobs['sm_steps']
+        st.fix_assign = 1 if fix_assign else 0
+        st.learning = 1 if learning else 0
+        st.threads = _lib.host_threads()
+        st.threads_wide = _lib.threads_for(1 << 40)
+        if record is None:
+            for i in range(5):
+                st.rec_scalars[i] = None
+            st.rec_assignment = st.rec_params = None
+            st.rec_params_cap = 0
+        else:
+            scalars, labels, params, cap = record
+            for i in range(5):
+                st.rec_scalars[i] = scalars[i]
+            st.rec_assignment = labels
+            st.rec_params = params or None
+            st.rec_params_cap = cap
+        st.phase = _lib.PHASE_ASSIGN
+        out = {'move': None, 'sm': None, 'parameters': None, 'errors': None,
+            'recorded': False}
+        addr = C.addressof(table)
+        while True:
+            with _lib.NumpyGaussStream() as (rng, gauss):
+                st.gauss = gauss
+                _lib.check(lib.bnpc_chain_step(ctx._h, addr, rng,
+                    C.byref(st)), 'chain_step')
+            need = st.need
+            if st.phase == _lib.PHASE_ASSIGN and st.move >= 0:
+                out['move'] = ('split', 'merge', 'gibbs')[st.move]
+                if st.move < 2 and need != _lib.NEED_MOVE:
+                    out['sm'] = [1, 0] if st.sm_accepted else [0, 1]
+                    self._rg_view = None    # the move's view was overwritten
+            if need == _lib.NEED_NONE:
+                break
+            # a phase for the methods of this class: the model as the
+            # library left it, the phase, the model back
+            self._chain_to_state(nat)
+            if need == _lib.NEED_MOVE:
+                out['sm'] = self.do_split_move(st.sm_steps) if st.move == 0 \
+                    else self.do_merge_move(st.sm_steps)
+                st.phase = _lib.PHASE_ALPHA
+            elif need == _lib.NEED_GIBBS:
+                self.update_assignments_Gibbs()
+                st.phase = _lib.PHASE_ALPHA
+            elif need == _lib.NEED_PARAMS:
+                out['parameters'] = self.update_parameters()
+                st.phase = _lib.PHASE_ERRORS
+            elif need == _lib.NEED_ERRORS:
+                out['errors'] = self.update_error_rates()
+                st.phase = _lib.PHASE_RECORD
+            else:                   # NEED_RECORD: the caller records
+                self._native_steps = getattr(self, '_native_steps', 0) + 1
+                return out
+            self._state_to_chain(nat)
+        self._chain_to_state(nat)
+        if out['parameters'] is None:
+            out['parameters'] = (st.par_declined, st.par_accepted)
+        if st.errors_updated and out['errors'] is None:
+            out['errors'] = (
+                [1, 0] if st.FP_accepted else [0, 1],
+                [1, 0] if st.FN_accepted else [0, 1])
+        if st.move in (0, 1) and st.sm_cells:
+            self._note_move('merge' if st.move else 'split', st.sm_cells,
+                st.sm_accepted)
+        out['recorded'] = record is not None
+        out['params_recorded'] = bool(st.rec_params_done)
+        out['ML'], out['lprior'] = st.ML, st.lprior
+        self._native_steps = getattr(self, '_native_steps', 0) + 1
+        return out
+
+    def _native_chain(self, learning):
+        """The bnpc_chain of this model: everything that does not change from
+        step to step."""
+        nat = _lib.NativeChain(self.cells_total, self.muts_total)
+        st = nat.st
+        st.param_stride = self.muts_total
+        st.dpa_shape = float(self.DP_a_gamma[0])
+        st.dpa_rate = float(self.DP_a_gamma[1])
+        st.p, st.q = float(self.p), float(self.q)
+        st.tmin, st.tmax = TMIN, TMAX
+        st.mix0 = float(self._beta_mix_const[0])
+        st.mix1 = float(self._beta_mix_const[1])
+        st.uniform_prior = int(self.beta_prior_uniform)
+        sd = np.ascontiguousarray(self.param_proposal_sd, dtype=np.float64)
+        nat.keep.append(sd)
+        st.sd, st.n_sd = _lib.ptr(sd), sd.size
+        if learning:
+            for i in range(4):
+                st.FP_prior[i] = float(self.FP_prior.args[i])
+                st.FN_prior[i] = float(self.FN_prior.args[i])
+            for i in range(3):
+                st.FP_sd[i] = float(self.FP_sd[i])
+                st.FN_sd[i] = float(self.FN_sd[i])
+        st.wide_from = int(_lib.env('BNPC_MH_WIDE_FROM', '65536')) \
+            if _lib.env('BNPC_HOST_THREADS') is None else 1 << 62
+        st.sweep_bytes = int(_lib.env('BNPC_SWEEP_BYTES', 256 << 20))
+        st.view_move = VIEW_MOVE
+        st.sweep_hint = int(_lib.env('BNPC_SWEEP_HINT', '1') != '0')
+        return nat
+
+    def _state_to_chain(self, nat):
+        """Model -> bnpc_chain: what a step reads and the binding may have
+        changed since the last one."""
+        st = nat.st
+        clusters = self.cells_per_cluster
+        K = len(clusters)
+        nat.ids[:K] = np.fromiter(clusters.keys(), np.int64, K)
+        nat.sizes[:K] = np.fromiter(clusters.values(), np.int64, K)
+        st.K = K
+        st.assignment = _lib.ptr(self.assignment)
+        st.parameters = _lib.ptr(self.parameters)
+        st.crp_prior = _lib.ptr(self.CRP_prior)
+        st.DP_a = self.DP_a
+        st.FP, st.FN = self.FP, self.FN
+
+    def _chain_to_state(self, nat):
+        """bnpc_chain -> model (the arrays were updated in place)."""
+        st = nat.st
+        K = st.K
+        self.cells_per_cluster = dict(zip(nat.ids[:K].tolist(),
+            nat.sizes[:K].tolist()))
+        if st.alpha_updated:
+            self.DP_a = st.DP_a
+        if st.errors_updated:
+            self.FP, self.FN = st.FP, st.FN
+
+    def host_stats(self):
+        """Counters of the sweeps and moves made so far (bench.py): cells
+        swept / decided from the device's hint / between two / among three
+        columns, moves made natively, steps made natively."""
+        out = {'swept': getattr(self, '_swept', 0),
+            'hint_used': getattr(self, '_hint_used', 0),
+            'pair_used': getattr(self, '_pair_used', 0),
+            'triple_used': getattr(self, '_triple_used', 0),
+            'native_moves': getattr(self, '_native_moves', 0),
+            'native_steps': getattr(self, '_native_steps', 0)}
+        nat = getattr(self, '_nat', None)
+        if nat is not None:
+            for key in ('swept', 'hint_used', 'pair_used', 'triple_used',
+                    'native_moves'):
+                out[key] += getattr(nat.st, key)
+        return out
 
     # ------------------------------------------------- cluster parameters
     def update_parameters(self, step_no=None):

@@ -339,6 +339,12 @@ int bnpc_mt_beta_theta(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, int64_t M,
                        const int32_t *n0, double fkt, double tmin,
                        double tmax, float *theta);
 
+/* np.random.gamma(shape, scale) on the same stream (legacy_gamma = scale *
+ * legacy_standard_gamma): the draws of CRP.update_DP_alpha
+ * (libs/CRP.py:386-410). */
+int bnpc_mt_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
+                  double scale, double *out);
+
 /* log(exp(log_p[i]) - exp(log_q[i])) for log_q <= log_p, evaluated with the
  * arithmetic of scipy.special.logsumexp([log_p, log_q + pi*1j], axis=0).real
  * - which is how scipy.stats.truncnorm computes the Gaussian mass of an
@@ -699,6 +705,120 @@ int bnpc_move_propose(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                       int64_t *n_cells, int64_t *n_first, int64_t *picked,
                       double *size_data, int64_t *others, int *status);
 int bnpc_np_sum(const double *a, int64_t n, double *out);
+
+/* ---- a whole MCMC step in one call -----------------------------------------
+ * Chain_steps.do_step + Chain.update_results (libs/MCMC.py:320-342, 242-282):
+ *
+ *   [u < sm_prob ? split/merge : Gibbs] -> [u < dpa_prob ? DP alpha]
+ *   -> update_parameters -> [learning & u < error_prob ? error rates]
+ *   -> record (ML = get_ll_full, MAP = ML + get_lprior_full, alpha, FN, FP,
+ *      the assignment, the parameter rows of the populated clusters)
+ *
+ * on the caller's stream, in the reference's draw order, without the
+ * interpreter in between.  Nothing here is new arithmetic: the call strings
+ * together bnpc_sm_move, bnpc_gibbs_sweep (on bnpc_ll_theta_pinned_top2_issue),
+ * bnpc_label_counts_and_batch / bnpc_mh_batch_dev, bnpc_ll_total(_issue),
+ * bnpc_beta_logpdf_f32, bnpc_tn_ppf_scalar / bnpc_tn_logpdf_scalar exactly as
+ * the binding (bnpc_amd/model.py, bnpc_amd/mcmc.py) strings them together, and
+ * restates the scalar NumPy / SciPy expressions between them - CRP.update_DP_alpha
+ * (libs/CRP.py:386-410: legacy beta / gamma draws, init_DP_prior :191-194),
+ * CRP_errors_learning.MH_error_rates (libs/CRP_learning_errors.py:66-111),
+ * CRP.get_lprior_full (libs/CRP.py:241-251; the Gamma log-density of alpha on
+ * SciPy's xlogy / gammaln) - on the kernel table.
+ *
+ * The model's state lives in the CALLER's arrays, updated in place:
+ * assignment, parameters, the live clusters (ids / sizes, in the insertion
+ * order of the reference's cells_per_cluster dict; capacity N), CRP_prior,
+ * DP_a, FP, FN.  A phase the call does not make itself - a Gibbs sweep over
+ * more than 64 clusters or one that does not fit `sweep_bytes` (first steps),
+ * a parameter batch of more than 64 clusters, a move / batch / scalar the
+ * kernel table leaves to SciPy - ends the call BEFORE that phase, with the
+ * stream where the reference would have it at that point: `need` names the
+ * phase, the binding runs it through its own methods and calls again with
+ * `phase` = the next one.  need == 0: the step is complete and recorded.
+ */
+#define BNPC_PHASE_ASSIGN 0     /* split/merge or Gibbs */
+#define BNPC_PHASE_ALPHA 1      /* the DP-alpha draw and update */
+#define BNPC_PHASE_PARAMS 2
+#define BNPC_PHASE_ERRORS 3
+#define BNPC_PHASE_RECORD 4
+#define BNPC_NEED_NONE 0
+#define BNPC_NEED_MOVE 1        /* do_split_move (move 0) / do_merge_move (1) */
+#define BNPC_NEED_GIBBS 2       /* update_assignments_Gibbs */
+#define BNPC_NEED_PARAMS 3      /* update_parameters */
+#define BNPC_NEED_ERRORS 4      /* update_error_rates */
+#define BNPC_NEED_RECORD 5      /* get_ll_full / get_lprior_full + the traces */
+#define BNPC_STEP_CLOCKS 10
+
+typedef struct bnpc_chain {
+    /* ---- the model (caller-owned, updated in place) ---- */
+    int64_t N, M;
+    int64_t *assignment;        /* N */
+    float *parameters;          /* row = cluster id, param_stride floats apart */
+    int64_t param_stride;
+    int64_t *ids, *sizes;       /* capacity N; [0, K) = the live clusters */
+    int64_t K;
+    double *crp_prior;          /* N + 2 (CRP.CRP_prior) */
+    double DP_a, dpa_shape, dpa_rate;   /* DP_a_gamma (libs/CRP.py:47-56) */
+    double FP, FN;
+    double p, q, tmin, tmax;
+    double mix0, mix1;          /* _beta_mix_const (libs/CRP.py:42-44) */
+    int32_t uniform_prior, learning;
+    const double *sd;           /* param_proposal_sd */
+    int64_t n_sd;
+    double FP_prior[4], FN_prior[4];    /* a, b, mean, sd of the priors */
+    double FP_sd[3], FN_sd[3];          /* proposal sds of the error rates */
+    /* ---- move schedule (libs/MCMC.py:26-60) ---- */
+    double sm_prob, dpa_prob, error_prob, sm_ratios[2];
+    int32_t sm_steps, fix_assign;
+    /* ---- host resources ---- */
+    int32_t threads, threads_wide;      /* team ranks; for >= wide_from */
+    int64_t wide_from;                  /* ... batch entries */
+    int64_t sweep_bytes;                /* budget of a whole-matrix sweep */
+    int32_t view_move, sweep_hint;      /* slot view of the moves; hints on */
+    void *gauss;                        /* the stream's bnpc_legacy_gauss */
+    /* ---- control ---- */
+    int32_t phase;                      /* in: BNPC_PHASE_* to (re)start at */
+    int32_t need;                       /* out: BNPC_NEED_* */
+    /* ---- where the recorded state goes (NULL: nowhere) ---- */
+    double *rec_scalars[5];             /* ML, MAP, DP_alpha, FN, FP slots */
+    int64_t *rec_assignment;            /* N labels */
+    float *rec_params;                  /* rec_params_cap x M, or NULL */
+    int64_t rec_params_cap;
+    /* ---- what the step did ---- */
+    int32_t move;               /* -1 none, 0 split, 1 merge, 2 Gibbs */
+    int32_t sm_accepted;
+    int64_t sm_cells;
+    int32_t alpha_updated, errors_updated, FP_accepted, FN_accepted;
+    int64_t par_declined, par_accepted;
+    int32_t rec_params_done, pad_;
+    double ML, lprior;
+    /* ---- running statistics ---- */
+    int64_t swept, hint_used, pair_used, triple_used, native_moves, steps;
+    /* wall time by part of the step, ns / calls: 0 Gibbs, 1 split accepted,
+     * 2 split rejected, 3 merge accepted, 4 merge rejected, 5 DP alpha,
+     * 6 parameters, 7 error rates, 8 record, 9 unused */
+    int64_t clock_ns[BNPC_STEP_CLOCKS], clock_calls[BNPC_STEP_CLOCKS];
+    void *work;                 /* bnpc_chain_open / bnpc_chain_close */
+} bnpc_chain;
+
+/* ch->work: the step's private caches (the new-cluster term per (FP, FN), the
+ * label counts with the state they belong to, the prior-density cache, scratch).
+ * open once after filling N and M; close releases them. */
+int bnpc_chain_open(bnpc_chain *ch);
+int bnpc_chain_close(bnpc_chain *ch);
+int bnpc_chain_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                    bnpc_mt19937 *rng, bnpc_chain *ch);
+/* Checker hook: CRP.update_DP_alpha + init_DP_prior (libs/CRP.py:386-410,
+ * 191-194) alone, as the step makes them: reads K, DP_a, dpa_shape, dpa_rate,
+ * N; writes DP_a and crp_prior.  Host only. */
+int bnpc_chain_update_alpha(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
+                            bnpc_chain *ch);
+/* Checker hook: scipy.stats.gamma.logpdf(x, a, loc) (scale 1) on the kernel
+ * table - xlogy(a - 1, x - loc) - (x - loc) - gammaln(a) - as the step
+ * evaluates the prior of DP_a (libs/CRP.py:245); *status = 1: left to SciPy. */
+int bnpc_gamma_logpdf_scalar(const bnpc_host_kernels *k, double x, double a,
+                             double loc, double *out, int *status);
 
 /* ---- data ingest ---------------------------
  * Body scanner for the reference's text matrix format (libs/dpmmIO.py:27-98):

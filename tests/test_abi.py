@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.load()
-    assert lib.bnpc_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.bnpc_abi_version() == _lib.ABI_VERSION == 7
     assert lib.bnpc_last_error() is not None
 
 
@@ -72,3 +72,39 @@ def test_header_is_plain_c(tmp_path):
         '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
         capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """The ctypes mirrors of the header's structures (bnpc_amd/_lib.py) have
+    the size and the field offsets a C compiler gives them."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    pairs = (('bnpc_chain', _lib.ChainState), ('bnpc_gibbs_state',
+        _lib.GibbsState), ('bnpc_move_state', _lib.MoveState),
+        ('bnpc_mh_args', _lib.MHArgs), ('bnpc_accept_args', _lib.LogAArgs),
+        ('bnpc_mt19937', _lib.MT19937), ('bnpc_legacy_gauss',
+        _lib.LegacyGauss))
+    lines = ['#include <stdio.h>', '#include <stddef.h>',
+        '#include "bnpc_hip.h"', 'int main(void) {']
+    want = []
+    for cname, mirror in pairs:
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        want.append(ctypes.sizeof(mirror))
+        for field in mirror._fields_:
+            lines.append(
+                f'printf("%zu\\n", offsetof({cname}, {field[0]}));')
+            want.append(getattr(mirror, field[0]).offset)
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    res = subprocess.run([gcc, '-std=c99', '-I', os.path.join(ROOT, 'include'),
+        str(src), '-o', str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True,
+        text=True, check=True).stdout.split()]
+    assert got == want
+    assert _lib.TOP2.itemsize == 64

@@ -1263,3 +1263,113 @@ def test_native_moves_change_nothing(pb, monkeypatch):
             assert a[4] == other[4], rnd
         accepted[int(a[0][1])] += a[0][0][0]
     assert accepted[0] > 0 and accepted[1] > 0, accepted
+
+
+def _chain_by_steps(mod, kind, data, steps, seed, pb, native, monkeypatch,
+        knobs=None, peek=True):
+    """A chain stepped one Chain.step at a time; after every step: the state
+    (labels, cluster table in dict order, parameter rows, alpha, FN, FP), the
+    recorded scalars and one uniform peeked off the stream (the stream is put
+    back).  Returns (trace, model statistics)."""
+    from bnpc_amd.mcmc import Chain_steps
+    monkeypatch.setenv('BNPC_NATIVE_STEP', native)
+    np.random.seed(seed)
+    m = H.make(mod, kind, data, pb)
+    m.init()
+    params = dict(sm_prob=.33, dpa_prob=.25, error_prob=.25 if kind == 'learn'
+        else 0., sm_ratios=[.75, .25], sm_steps=3,
+        param_proposal_sd=np.array([.1, .25, .5]))
+    params.update(knobs or {})
+    chain = Chain_steps(m, 1, steps, steps // 3, params, 0, False)
+    trace = []
+    for i in range(1, steps + 1):
+        chain.step(i, i < steps // 3)
+        ids = list(m.cells_per_cluster)
+        state = np.random.get_state()
+        u = np.random.random() if peek else 0.
+        np.random.set_state(state)
+        res = chain.results
+        trace.append((m.assignment.copy(),
+            [(int(a), int(b)) for a, b in m.cells_per_cluster.items()],
+            m.parameters[ids].copy(), float(m.DP_a), float(m.FN),
+            float(m.FP), m.CRP_prior.copy(), float(res['ML'][i]),
+            float(res['MAP'][i]), float(res['DP_alpha'][i]),
+            float(res['FN'][i]), float(res['FP'][i]),
+            res['assignments'][i].copy(), u))
+    chain.trace.finish()
+    out = (trace, m.host_stats() if hasattr(m, 'host_stats') else {},
+        {key: np.array(val) for key, val in chain.results.items()
+            if isinstance(val, np.ndarray)},
+        {name: chain.tally.counts[name].copy() for name in chain.tally.MOVES})
+    if hasattr(m, 'close'):
+        m.close()
+    return out
+
+
+@pytest.mark.parametrize('kind,pb,knobs', [
+    ('learn', (.25, .25), None),
+    ('fixed', (1, 1), None),
+    ('learn', (.75, 2.), dict(sm_prob=.6, sm_steps=2, dpa_prob=.6,
+        error_prob=.7, sm_ratios=[.4, .6])),
+])
+def test_native_steps_change_nothing(kind, pb, knobs, monkeypatch):
+    """A whole step as ONE native call (bnpc_chain_step, the default) against
+    the same steps walked method by method by the binding
+    (BNPC_NATIVE_STEP=0): after EVERY one of 150 steps - the first sweeps
+    from hundreds of clusters (handed back to the binding), then the
+    converged regime - the labels, the cluster table in dict order, the
+    parameter rows, alpha with its N + 2 prior vector, FN, FP, the recorded
+    ML / MAP / traces and the stream position are bit-identical; the
+    acceptance tallies and the parameter trace too; and the oracle agrees on
+    the labels (ML to 1e-9)."""
+    data = H.synth(33, 900, 220, 7, 0.15)
+    steps = 150
+    nat = _chain_by_steps(P, kind, data, steps, 77, pb, '1', monkeypatch, knobs)
+    ref = _chain_by_steps(P, kind, data, steps, 77, pb, '0', monkeypatch, knobs)
+    assert nat[1]['native_steps'] >= steps - 5, nat[1]
+    assert ref[1]['native_steps'] == 0
+    assert nat[1]['native_moves'] > 10
+    for i, (a, b) in enumerate(zip(nat[0], ref[0])):
+        for x, y in zip(a, b):
+            if isinstance(x, np.ndarray):
+                assert x.dtype == y.dtype and np.array_equal(x, y), i
+            else:
+                assert x == y, (i, x, y)
+    assert sorted(nat[2]) == sorted(ref[2])
+    for key in nat[2]:
+        assert nat[2][key].dtype == ref[2][key].dtype, key
+        assert np.array_equal(nat[2][key], ref[2][key]), key
+    for name in nat[3]:
+        assert np.array_equal(nat[3][name], ref[3][name]), name
+    assert nat[3]['parameters'].sum() > 0 and nat[3]['splits'].sum() > 0
+    orc = _chain_by_steps(O, kind, data, steps, 77, pb, '0', monkeypatch,
+        knobs, peek=False)
+    for i, (a, c) in enumerate(zip(nat[0], orc[0])):
+        assert np.array_equal(a[0], c[0]), i
+        assert a[1] == c[1], i
+        np.testing.assert_allclose(a[7], c[7], rtol=1e-9)
+
+
+def test_native_step_hands_phases_back_and_resumes(monkeypatch):
+    """Phases the library hands back to the binding (ch->need) and resumes
+    after: without the sweep's hints, or with a sweep budget too small for one
+    matrix, every Gibbs sweep goes back to update_assignments_Gibbs
+    (NEED_GIBBS) while the rest of each step stays native - the chain is the
+    same chain, state by state."""
+    data = H.synth(34, 600, 150, 5, 0.1)
+    base = _chain_by_steps(P, 'learn', data, 60, 5, (.25, .25), '0',
+        monkeypatch)
+    for env in ({'BNPC_SWEEP_HINT': '0'}, {'BNPC_SWEEP_BYTES': '90000'}):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        got = _chain_by_steps(P, 'learn', data, 60, 5, (.25, .25), '1',
+            monkeypatch)
+        for key in env:
+            monkeypatch.delenv(key)
+        assert got[1]['native_steps'] >= 55
+        for i, (a, b) in enumerate(zip(got[0], base[0])):
+            for x, y in zip(a, b):
+                if isinstance(x, np.ndarray):
+                    assert np.array_equal(x, y), (env, i)
+                else:
+                    assert x == y, (env, i, x, y)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import crp_numpy as O
-from bnpc_amd import _lib
+from bnpc_amd import _lib, model as P
 
 i64, f64 = C.c_int64, C.c_double
 
@@ -459,7 +459,7 @@ def test_loop_shortcuts_change_nothing(monkeypatch):
 _STRESS = r'''
 import ctypes as C, os, sys
 sys.path.insert(0, %(root)r)
-from bnpc_amd import _lib
+from bnpc_amd import _lib, model as P
 lib = _lib.load()
 
 def batch(jobs, tasks, ranks, seed):
@@ -976,3 +976,72 @@ def test_quick_pick_among_three_equals_the_scan_around_every_boundary():
             quick = triple(1, q, a, A, u)
             assert quick < 0 or quick == triple(0, q, a, A, u), (q, a, A, u)
     assert decided > 50000 and declined > 50000
+
+
+# ------------------------------------------------------ pieces of the native step
+def test_native_step_scalars_pass_their_start_up_comparison():
+    """np.random.gamma on the stream and the Gamma log-density of the
+    concentration parameter as bnpc_chain_step restates them are NumPy's /
+    SciPy's bits on this stack (else whole steps are not made natively)."""
+    assert P._native_step_allowed()
+    table = P._native_kernels()
+    from bnpc_amd import fastdist
+    rng = np.random.RandomState(5)
+    for _ in range(200):
+        a = float(rng.uniform(1.5, 300))
+        x = float(rng.uniform(1 + 1e-15, 2 * a))
+        assert _lib.gamma_logpdf_scalar(table, x, a, 1) \
+            == float(fastdist.gamma_logpdf(x, a, 1))
+    assert _lib.gamma_logpdf_scalar(table, 0.5, 3.0, 1) is None   # x <= loc
+    for seed in range(40):
+        shape = float(rng.choice([.3, 1., 1.7, 40.2, 5000.7]))
+        scale = float(rng.uniform(.05, 9))
+        np.random.seed(seed)
+        if seed % 3 == 0:
+            np.random.normal()          # a cached Gaussian on entry
+        state = np.random.get_state()
+        want = (np.random.gamma(shape, scale), np.random.random())
+        np.random.set_state(state)
+        got = (_lib.gamma(shape, scale), np.random.random())
+        assert want == got, (seed, shape, scale)
+
+
+@pytest.mark.parametrize('neg_alpha', [True, False])
+def test_native_alpha_update_is_the_bindings(neg_alpha):
+    """CRP.update_DP_alpha + init_DP_prior (libs/CRP.py:386-410, 191-194) as
+    the native step makes them (bnpc_chain_update_alpha): the same DP_a, the
+    same N + 2 prior vector bit for bit, the stream and the cached Gaussian
+    left where NumPy leaves them - over 300 updates in a row."""
+    import ctypes as C
+    N, M = 777, 5
+    data = np.zeros((N, M))
+    model = P.CRP(data, DP_alpha=[-1, -1] if neg_alpha else [3.5, 0.25],
+        param_beta=[.25, .25], FN_error=0.1, FP_error=0.01)
+    table = P._native_kernels()
+    nat = _lib.NativeChain(N, M)
+    st = nat.st
+    st.dpa_shape = float(model.DP_a_gamma[0])
+    st.dpa_rate = float(model.DP_a_gamma[1])
+    model.init_DP_prior()
+    prior = model.CRP_prior.copy()
+    st.crp_prior = _lib.ptr(prior)
+    st.DP_a = model.DP_a
+    rng = np.random.RandomState(3)
+    np.random.seed(99)
+    for it in range(300):
+        K = int(rng.randint(1, 60))
+        model.cells_per_cluster = {i: 1 for i in range(K)}
+        st.K = K
+        state = np.random.get_state()
+        model.update_DP_alpha()
+        after = np.random.get_state()
+        np.random.set_state(state)
+        with _lib.NumpyGaussStream() as (r, gauss):
+            st.gauss = gauss
+            _lib.check(nat._lib.bnpc_chain_update_alpha(C.addressof(table), r,
+                C.byref(st)), 'chain_update_alpha')
+        now = np.random.get_state()
+        assert st.DP_a == model.DP_a, it
+        assert np.array_equal(prior, model.CRP_prior), it
+        assert now[2:] == after[2:] and np.array_equal(now[1], after[1]), it
+    nat.close()
