@@ -322,10 +322,16 @@ def load():
     return lib
 
 
+class DeviceMemoryError(RuntimeError):
+    """An entry point reports that its working set does not fit the device
+    (return code 5): the one failure a caller may answer with another route."""
+
+
 def check(rc, what=''):
     if rc != 0:
         msg = load().bnpc_last_error().decode('utf-8', 'replace')
-        raise RuntimeError(f'libbnpc_hip {what} failed (code {rc}): {msg}')
+        kind = DeviceMemoryError if rc == 5 else RuntimeError
+        raise kind(f'libbnpc_hip {what} failed (code {rc}): {msg}')
 
 
 _from_buffer = C.c_char.from_buffer
@@ -622,12 +628,17 @@ def rng_live():
     this NumPy does not expose it as expected (then callers exchange a copy).
     Checked once per process against np.random.get_state()."""
     pid = os.getpid()
-    if _live.get('pid') != pid:
+    rs = np.random.mtrand._rand
+    # (np.random.set_bit_generator / a replaced _rand give the stream another
+    # state block: the pointer is looked up again whenever the owners change)
+    if _live.get('pid') != pid or _live.get('rs') is not rs \
+            or _live.get('bg') is not getattr(rs, '_bit_generator', None):
         _live.clear()
         _live['pid'] = pid
         _live['ptr'] = None
+        _live['rs'] = rs
         try:
-            bg = np.random.mtrand._rand._bit_generator
+            bg = _live['bg'] = rs._bit_generator
             if type(bg).__name__ == 'MT19937':
                 p = C.cast(bg.ctypes.state_address, C.POINTER(MT19937))
                 kind, key, pos = np.random.get_state()[:3]
@@ -635,7 +646,6 @@ def rng_live():
                         np.array_equal(np.frombuffer(p.contents.key,
                             dtype=np.uint32), key):
                     _live['ptr'] = p
-                    _live['bg'] = bg        # keep the owner alive
         except Exception:
             _live['ptr'] = None
     return _live['ptr']
@@ -663,10 +673,14 @@ def gauss_live():
     get_state().  Anything unexpected: None, and the callers exchange the
     pair through get_state / set_state instead."""
     pid = os.getpid()
-    if _gauss_live.get('pid') == pid:
+    rs_now = np.random.mtrand._rand
+    if _gauss_live.get('pid') == pid and _gauss_live.get('owner') is rs_now \
+            and _gauss_live.get('bg') is getattr(rs_now, '_bit_generator',
+                None):
         return _gauss_live['ptr']
     _gauss_live.clear()
-    _gauss_live.update(pid=pid, ptr=None)
+    _gauss_live.update(pid=pid, ptr=None, owner=rs_now,
+        bg=getattr(rs_now, '_bit_generator', None))
     if os.environ.get('BNPC_GAUSS_LIVE', '1') == '0':
         return None
     saved = np.random.get_state()
@@ -698,7 +712,6 @@ def gauss_live():
         if back[3] != 1 or back[4] != 1.2509765625:
             return None
         _gauss_live['ptr'] = ptr
-        _gauss_live['owner'] = rs
     except Exception:       # noqa: BLE001 - any surprise means "not live"
         _gauss_live['ptr'] = None
     finally:

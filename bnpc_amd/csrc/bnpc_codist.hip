@@ -603,6 +603,21 @@ extern "C" int bnpc_post_ward(bnpc_post *p, double *Z_raw)
     const long long n = p->N;
     double *d_D = nullptr, *d_Z = nullptr;
     int *d_size = nullptr, *d_chain = nullptr, *d_err = nullptr;
+    // the full symmetric matrix: 8 N^2 bytes (20 GB at 50 000 cells).  Not
+    // fitting is the ONE failure the caller may answer with SciPy's routine
+    // on the condensed vector: it gets a return code of its own (5).
+    {
+        size_t free_b = 0, total_b = 0;
+        PCK(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = (size_t)n * n * sizeof(double)
+            + (size_t)n * 48 + ((size_t)1 << 20);
+        if (need > free_b) {
+            bnpc_set_error("ward linkage: the %lld x %lld distance matrix "
+                           "needs %.1f GB, %.1f GB of device memory are free",
+                           n, n, need / 1e9, free_b / 1e9);
+            return 5;
+        }
+    }
     hipError_t e = hipMalloc((void **)&d_D, (size_t)n * n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d_Z, (size_t)(n - 1) * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d_size, (size_t)n * sizeof(int));

@@ -309,6 +309,74 @@ def _overrides_a_move_step(model):
     return not plain or not _MOVE_STEP_SET.isdisjoint(model.__dict__)
 
 
+_MOVES_OK = {}
+
+
+def _native_moves_allowed():
+    """Whether split / merge moves may be made natively in this process
+    (bnpc_sm_move restates NumPy behaviour that is not part of any interface:
+    np.sum's pairwise order inside the iterator's 8192-element buffer, the
+    legacy choice with p / without replacement, permutation, randint):
+    np_sum equals np.sum around every change of regime and the proposals of
+    both moves equal the binding's own (_propose_split / _propose_merge) from
+    the same stream - compared once per process, the stream put back."""
+    pid = os.getpid()
+    if _MOVES_OK.get('pid') != pid:
+        _MOVES_OK.clear()
+        _MOVES_OK.update(pid=pid, ok=False)
+        table = _native_kernels()
+        if table is not None and table.gammaln:
+            saved = np.random.get_state()
+            try:
+                rng = np.random.RandomState(77)
+                ok = True
+                for n in (1, 7, 8, 9, 127, 128, 129, 1000, 8192, 8193, 20001):
+                    a = rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)
+                    ok &= _lib.np_sum(a) == float(np.sum(a))
+                probe = CRP.__new__(CRP)
+                for trial in range(6):
+                    K = (2, 3, 5, 9, 14, 40)[trial]
+                    N = 60 + 25 * trial
+                    labels = np.concatenate([np.arange(K),
+                        rng.randint(0, K, N - K)])
+                    rng.shuffle(labels)
+                    ids = rng.permutation(K)
+                    probe.assignment = np.ascontiguousarray(
+                        ids[labels], dtype=np.int64)
+                    order = rng.permutation(K)
+                    probe.cells_per_cluster = {int(ids[k]):
+                        int((labels == k).sum()) for k in order}
+                    for move in (0, 1):
+                        np.random.seed(900 + trial)
+                        if move == 0:
+                            _, cells, (lt, others) = probe._propose_split()
+                            want = (cells, float(lt[0]), list(others))
+                        else:
+                            _, _, _, cells, sd = probe._propose_merge()
+                            want = (cells, float(sd), None)
+                        end = np.random.get_state()
+                        np.random.seed(900 + trial)
+                        got = _lib.move_propose(table, move,
+                            np.fromiter(probe.cells_per_cluster.keys(),
+                                np.int64),
+                            np.fromiter(probe.cells_per_cluster.values(),
+                                np.int64), probe.assignment)
+                        now = np.random.get_state()
+                        ok &= got is not None \
+                            and np.array_equal(got[0], want[0]) \
+                            and got[3] == want[1] \
+                            and (want[2] is None
+                                or list(got[4]) == want[2]) \
+                            and now[2] == end[2] \
+                            and np.array_equal(now[1], end[1])
+                _MOVES_OK['ok'] = bool(ok)
+            except Exception:       # noqa: BLE001
+                _MOVES_OK['ok'] = False
+            finally:
+                np.random.set_state(saved)
+    return _MOVES_OK['ok']
+
+
 # the methods a native STEP (bnpc_chain_step) stands for, on top of the moves'
 _STEP_METHODS = _MOVE_STEPS + ('update_assignments_Gibbs', '_gibbs_window',
     '_sweep_order', '_new_cluster_ll', 'get_lpost_single_new_cluster',
@@ -1063,7 +1131,9 @@ class CRP:
         table = _native_kernels()
         if table is None or _lib.env('BNPC_NATIVE_STEP', '1') == '0' \
                 or _lib.env('BNPC_TIMING') or not _native_step_allowed() \
-                or not _native_beta() or _overrides_a_step_method(self):
+                or not _native_beta() or not _native_moves_allowed() \
+                or _lib.env('BNPC_NATIVE_MOVES', '1') == '0' \
+                or _overrides_a_step_method(self):
             return None
         ctx = self._dev()
         theta = self.parameters
@@ -1528,6 +1598,7 @@ class CRP:
         if table is None or not table.gammaln \
                 or not getattr(ctx, '_h', None) or not _native_beta() \
                 or _lib.env('BNPC_NATIVE_MOVES', '1') == '0' \
+                or not _native_moves_allowed() \
                 or _overrides_a_move_step(self):
             return None
         ids = np.fromiter(self.cells_per_cluster.keys(), dtype=np.int64)

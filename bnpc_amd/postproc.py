@@ -213,52 +213,67 @@ def get_MPEAR(assignments, dist=None):
     from bnpc_amd import _lib
     assignments = np.asarray(assignments)
     post = None
-    if dist is None:
-        import os
-        post = _lib.Posterior(assignments)
-        tree = None
-        if os.environ.get('BNPC_WARD_DEVICE', '1') != '0':
-            # the linkage on the device too: the distance vector (10 GB at
-            # 50 000 cells) is never brought to the host
-            try:
-                tree = post.ward()
-            except RuntimeError as err:
-                # the full distance matrix (8 N^2 bytes) did not fit the
-                # device: SciPy's own routine on the condensed vector - the
-                # reference's call, the same tree
-                print(f'[bnpc] Ward linkage on the device failed ({err}); '
-                    'falling back to scipy.cluster.hierarchy.linkage')
-        if tree is None:
-            dist = post.dist()
+    try:
+        if dist is None:
+            import os
+            post = _lib.Posterior(assignments)
+            tree = None
+            if os.environ.get('BNPC_WARD_DEVICE', '1') != '0':
+                # the linkage on the device too: the distance vector (10 GB at
+                # 50 000 cells) is never brought to the host
+                try:
+                    tree = post.ward()
+                except _lib.DeviceMemoryError as err:
+                    # the full distance matrix (8 N^2 bytes) does not fit the
+                    # device: SciPy's own routine on the condensed vector -
+                    # the reference's call, the same tree.  Any OTHER failure
+                    # (a device fault, a chain that did not close) is raised.
+                    print(f'[bnpc] Ward linkage on the device: {err}; '
+                        'using scipy.cluster.hierarchy.linkage')
+            if tree is None:
+                dist = post.dist()
+                tree = linkage(dist, method='ward')
+        else:
             tree = linkage(dist, method='ward')
-    else:
-        tree = linkage(dist, method='ward')
-    sizable = [int((np.unique(a, return_counts=True)[1] > 2).sum())
-        for a in assignments]
-    avg = np.mean(sizable)
-    candidates = np.arange(max(2, avg * 0.2),
-        min(avg * 2.5, assignments.shape[1]), dtype=int)
-    # every candidate cut of the tree (cut_tree's labels, without its O(N^2)
-    # replay of the merges: 12 s at 50 000 cells)
-    cuts = cut_tree_labels(tree, candidates)
-    if post is not None:
-        del dist
-        labels = np.ascontiguousarray(cuts.T)
-        try:
+        sizable = [int((np.unique(a, return_counts=True)[1] > 2).sum())
+            for a in assignments]
+        avg = np.mean(sizable)
+        candidates = np.arange(max(2, avg * 0.2),
+            min(avg * 2.5, assignments.shape[1]), dtype=int)
+        if candidates.size == 0:
+            # no candidate cut: the reference's loop does not run and its
+            # best_assignment stays None (utils.py:116-130)
+            return None
+        # every candidate cut of the tree (cut_tree's labels, without its
+        # O(N^2) replay of the merges: 12 s at 50 000 cells)
+        cuts = cut_tree_labels(tree, candidates)
+        if post is not None and cuts.max() < 65534:
+            dist = None
+            labels = np.ascontiguousarray(cuts.T)
             scores = mpear_scores(post.mpear_sums(labels), labels,
                 post.differ_sum, assignments.shape[0])
-        finally:
+            return _first_maximum(cuts, scores)
+        if dist is None:        # labels beyond uint16: the host scores
+            dist = post.dist()
+    finally:
+        if post is not None:
             post.close()
-        # first maximum, as the reference's strict `>` keeps it
-        return np.ascontiguousarray(cuts[:, int(np.argmax(scores))])
     sim = 1 - dist
-    best, best_score = None, -np.inf
-    for col in range(candidates.size):
-        labels = np.ascontiguousarray(cuts[:, col])
-        score = calc_MPEAR(sim, labels)
-        if score > best_score:
-            best, best_score = labels, score
-    return best
+    scores = np.array([calc_MPEAR(sim, np.ascontiguousarray(cuts[:, col]))
+        for col in range(candidates.size)])
+    return _first_maximum(cuts, scores)
+
+
+def _first_maximum(cuts, scores):
+    """The cut the reference's loop keeps (utils.py:119-128: `if score >
+    best: ...` from -inf): the FIRST of the largest scores; a NaN score never
+    passes `>`, so it is skipped, and if nothing passes the result is None."""
+    scores = np.asarray(scores, dtype=np.float64)
+    usable = ~np.isnan(scores) & (scores > -np.inf)
+    if not usable.any():
+        return None
+    best = int(np.argmax(np.where(usable, scores, -np.inf)))
+    return np.ascontiguousarray(cuts[:, best])
 
 
 def mean_hierarchy_assignment(assignments, params_full, dist=None):

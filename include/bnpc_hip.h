@@ -861,7 +861,10 @@ int bnpc_post_mpear(bnpc_post *post, const uint16_t *labels, int64_t C,
  * (scipy/cluster/_hierarchy.pyx nn_chain + _ward) inside one launch, the
  * float64 distance vector never leaving the device.  Z_raw[(N - 1) x 4]: the
  * merges in the order the chain makes them (slot indices x < y, height, size);
- * the binding applies SciPy's final stable sort by height and relabelling. */
+ * the binding applies SciPy's final stable sort by height and relabelling.
+ * Return code 5 (and nothing else): the working set does not fit the device's
+ * free memory - the caller may take SciPy's routine on the condensed vector;
+ * every other failure is an error. */
 int bnpc_post_ward(bnpc_post *post, double *Z_raw);
 int bnpc_post_destroy(bnpc_post *post);
 

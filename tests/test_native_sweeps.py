@@ -1045,3 +1045,47 @@ def test_native_alpha_update_is_the_bindings(neg_alpha):
         assert np.array_equal(prior, model.CRP_prior), it
         assert now[2:] == after[2:] and np.array_equal(now[1], after[1]), it
     nat.close()
+
+
+def test_live_stream_pointers_follow_a_replaced_bit_generator():
+    """np.random.set_bit_generator gives the global stream another state
+    block: the cached in-place pointers (rng_live, gauss_live) are looked up
+    again, native draws keep equalling NumPy's."""
+    if not hasattr(np.random, 'set_bit_generator'):
+        pytest.skip('NumPy without set_bit_generator')
+    old = np.random.get_bit_generator()
+    try:
+        np.random.seed(1)
+        _lib.beta(np.array([2.5]), np.array([3.5]))     # pointers cached
+        first = _lib.rng_live()
+        np.random.set_bit_generator(np.random.MT19937(123))
+        for seed in (5, 6):
+            np.random.seed(seed)
+            if seed == 6:
+                np.random.normal()
+            state = np.random.get_state()
+            want = (np.random.beta(2.5, 3.5), np.random.random())
+            np.random.set_state(state)
+            got = (_lib.beta(np.array([2.5]), np.array([3.5]))[0],
+                np.random.random())
+            assert want == got
+        assert _lib.rng_live() is not first
+    finally:
+        np.random.set_bit_generator(old)
+    np.random.seed(3)
+    state = np.random.get_state()
+    want = np.random.beta(.5, .25)
+    np.random.set_state(state)
+    assert _lib.beta(np.array([.5]), np.array([.25]))[0] == want
+
+
+def test_native_moves_pass_their_start_up_comparison():
+    """The run-time gate of bnpc_sm_move: np.sum's order and the
+    legacy proposals as the library restates them equal NumPy's on this
+    stack, and the comparison leaves the stream where it was."""
+    np.random.seed(8)
+    state = np.random.get_state()
+    P._MOVES_OK.clear()
+    assert P._native_moves_allowed()
+    now = np.random.get_state()
+    assert now[2:] == state[2:] and np.array_equal(now[1], state[1])

@@ -224,3 +224,21 @@ def test_codist_full_size_properties():
         assert np.array_equal(d[start:start + N - i - 1], row)
     # a permutation of the samples changes nothing
     assert np.array_equal(_lib.codist(a[rng.permutation(S)]), d)
+
+
+def test_mpear_cut_choice_follows_the_references_loop():
+    """utils.py:116-130 keeps the FIRST of the largest scores, skips NaN
+    scores (`score > best` is False for NaN) and returns None when no
+    candidate passes - the vectorised choice does the same."""
+    from bnpc_amd import postproc
+    cuts = np.arange(12).reshape(4, 3)
+    pick = postproc._first_maximum
+    assert np.array_equal(pick(cuts, [0.1, 0.7, 0.7]), cuts[:, 1])
+    assert np.array_equal(pick(cuts, [np.nan, 0.2, 0.1]), cuts[:, 1])
+    assert np.array_equal(pick(cuts, [0.3, np.nan, 0.3]), cuts[:, 0])
+    assert pick(cuts, [np.nan, np.nan, np.nan]) is None
+    assert pick(cuts, [-np.inf, -np.inf, -np.inf]) is None
+    # no cluster of more than two cells in any sample: the candidate range
+    # np.arange(2, 0) is empty, the reference's loop does not run
+    alone = np.tile(np.arange(6), (5, 1))
+    assert postproc.get_MPEAR(alone, dist=np.full(6 * 5 // 2, 0.5)) is None

@@ -43,9 +43,15 @@ for name in _lib.SIGNATURES:
     setattr(lib, name, timed)
 
 wall = {}
+# the default path makes a whole step as ONE native call (bnpc_chain_step):
+# wrapping the model's methods would switch that off - they are only wrapped
+# for the method-by-method path (BNPC_NATIVE_STEP=0)
+by_method = os.environ.get('BNPC_NATIVE_STEP', '1') == '0'
 for name in ('update_assignments_Gibbs', 'update_assignments_split_merge',
         'update_parameters', 'update_error_rates', 'update_DP_alpha',
         'get_lprior_full', 'get_ll_full_deferred'):
+    if not by_method:
+        break
     fn = getattr(model, name)
 
     def wrap(*a, _fn=fn, _n=name, **k):
@@ -74,6 +80,14 @@ for n, (t, c) in sorted(wall.items(), key=lambda kv: -kv[1][0]):
         f'{1e6 * li / c:7.1f}, interpreter {1e6 * (t - li) / c:7.1f}  '
         f'| per step: {1e3 * t / steps:.3f} = {1e3 * li / steps:.3f} + '
         f'{1e3 * (t - li) / steps:.3f}')
+if not by_method:
+    inside = sum(lib_in.values())
+    print(f'  whole steps as one native call: {model.host_stats()["native_steps"]} '
+        f'of {steps + 10} steps so far')
+    print(f'  step = library {1e3 * inside / steps:.3f} + interpreter '
+        f'{1e3 * (el - inside) / steps:.3f} ms (binding: state in / out, '
+        'tallies, trace bookkeeping)')
+    sys.exit(0)
 rest = el - tot_w
 print(f'  outside the moves (driver, traces, pick-up of the total): '
     f'{1e3 * rest / steps:.3f} ms/step of which library '
