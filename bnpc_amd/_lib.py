@@ -276,6 +276,8 @@ SIGNATURES = {
     'bnpc_post_fetch': (C.c_int, [C.c_void_p, _pi32, _pd]),
     'bnpc_post_mpear': (C.c_int, [C.c_void_p, C.c_void_p, _i64, _pi64]),
     'bnpc_post_ward': (C.c_int, [C.c_void_p, _pd]),
+    'bnpc_post_ward_stats': (C.c_int, [C.c_void_p, C.POINTER(_i64),
+        C.POINTER(_i64)]),
     'bnpc_post_destroy': (C.c_int, [C.c_void_p]),
     'bnpc_rg_scan': (C.c_int, [C.POINTER(MT19937), C.c_int, _i64, _pd,
         C.c_double, _pi64, _pi64, _pd]),
@@ -591,6 +593,13 @@ class Posterior:
         raw = np.empty((n - 1, 4), dtype=np.float64)
         check(load().bnpc_post_ward(self._h, ptr(raw)), 'post_ward')
         return ward_finish(raw, n)
+
+    def ward_stats(self):
+        """(full row scans, chain steps) of the last ward()"""
+        scans, steps = _i64(0), _i64(0)
+        check(load().bnpc_post_ward_stats(self._h, C.byref(scans),
+            C.byref(steps)), 'post_ward_stats')
+        return scans.value, steps.value
 
     def mpear_sums(self, labels):
         """labels: (C, N) integer array of C candidate clusterings ->

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 #include <algorithm>
 
 #include "bnpc_hip.h"
@@ -236,6 +237,8 @@ struct bnpc_post {
     int64_t S = 0, N = 0;
     int *differ = nullptr;                  // condensed, device
     unsigned long long *sums = nullptr;     // device scratch
+    long long ward_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // row scans / chain steps of the
+                                            // last bnpc_post_ward
 };
 
 #define PCK(expr)                                                            \
@@ -246,6 +249,19 @@ struct bnpc_post {
             return 1;                                                        \
         }                                                                    \
     } while (0)
+
+// row scans and chain steps of the last bnpc_post_ward (diagnostic)
+extern "C" int bnpc_post_ward_stats(const bnpc_post *p, int64_t *scans,
+                                    int64_t *steps)
+{
+    if (!p || !scans || !steps) {
+        bnpc_set_error("bad argument: NULL");
+        return 2;
+    }
+    *scans = p->ward_stats[0];
+    *steps = p->ward_stats[1];
+    return 0;
+}
 
 extern "C" int bnpc_post_destroy(bnpc_post *p)
 {
@@ -393,33 +409,78 @@ extern "C" int bnpc_post_mpear(bnpc_post *p, const uint16_t *labels, int64_t C,
 // At 50 000 cells the condensed distance vector is 10 GB and SciPy spends 62 s
 // walking it row by row on one core; here the distances never leave the device
 // (float64 from the resident pair counts, the same IEEE division, kept as a
-// full symmetric matrix so that a row is contiguous), and the
-// chain - inherently sequential: every step needs the previous one's result -
-// runs inside ONE launch of ONE 1024-thread workgroup, so a step is two
-// barriers, not a launch: the row scan for the nearest active neighbour
-// (strictly smaller than the chain's previous element, smallest index among
-// equals: the sequential scan's choice) as a workgroup reduction, the
-// Lance-Williams pass over the merged cluster's row in parallel, the chain
-// bookkeeping on thread 0.  Same merges, same heights bit for bit (sqrt, mul,
-// add, div are IEEE on both sides, compiled without contraction); the final
-// stable sort by height and the relabelling are done by the binding as SciPy
-// does them.
+// full symmetric matrix so that a row is contiguous).
+//
+// The chain is sequential - every step needs the previous one's result - but
+// the work inside a step is not, and ONE workgroup (round 3) cannot carry it:
+// measured at 50 000 cells, 1.2 s of row scans and 4.2 s of Lance-Williams
+// passes - a pass scatters an 8-byte store per cluster down a column of the
+// matrix, and one compute unit hands the L2 one cache line per clock.  Round 4
+// splits a step in two kernels that alternate on one stream (captured once as
+// a graph of 128 pairs and replayed; the kernel boundary is the hand-off, all
+// state lives in device memory, so there is no inter-workgroup protocol
+// inside a launch to get wrong):
+//
+//   k_ward_chain   ONE wave takes in what the last piece of work left (the
+//                  partial minima), walks the chain - a handful of dependent
+//                  loads per step - until it needs work, posts it and ends:
+//                  a merge, or the nearest neighbour of a stale row;
+//   k_ward_work    the whole chip does it: ceil(N / 256) workgroups the
+//                  Lance-Williams pass of the merge (row y contiguous,
+//                  columns x and y scattered over every CU's path to the L2),
+//                  ~N / 1500 workgroups a slice each of the row to be scanned
+//                  - with a merge, the row the chain returns to (its
+//                  neighbour was one of the two merged clusters, always), as
+//                  the merge leaves it: column x gone, column y at the new
+//                  distance, computed from values the chain kernel read
+//                  beforehand, so the scan does not race with the pass.
+//
+// Work per step is cut as well:
+//  * a row scan is a pure (minimum, smallest index) reduction: the diagonal,
+//    the padding and the columns of merged-away clusters hold +inf, so there
+//    is no activity test, 16-byte loads;
+//  * every row keeps its nearest neighbour (nn_d, nn_i) = (minimum, smallest
+//    index among equals) of its CURRENT entries, initialised for all rows by
+//    one chip-wide pass (k_ward_init).  The Lance-Williams pass keeps that
+//    exact - a row whose neighbour was one of the two merged clusters is
+//    marked stale, any other row takes the merged cluster as its neighbour
+//    iff (new distance, its index) is lexicographically smaller - and
+//    computes the merged row's own neighbour on the way.  A chain step whose
+//    top row has a valid neighbour needs no scan; a stale row is scanned when
+//    (and only if) it reaches the top.  (With the many exact ties of
+//    co-clustering distances the neighbours of a cluster's rows all point at
+//    its smallest index, and its merges make them stale over and over: 2.6
+//    scans per merge remain, 1 of them riding on the merge's own launch.
+//    Keeping the k nearest per row instead was simulated: k = 8 still needs
+//    1.3 scans per merge - not worth its bookkeeping.)
+//
+// N = 50 000: 4.2 s (round 3) -> 1.5 s; what is left is latency - 130 000
+// launches of each kernel, ~5 us of dependent loads apiece.
+//
+// The sequential scan's choices are kept exactly: the nearest neighbour is
+// the first index of the row's minimum, unless the chain's previous element
+// is as near (`dist < current_min` is strict: the previous element wins
+// ties); the distance to the previous element is the one recorded when it
+// pushed the current top (neither has been merged since, so the entry is
+// unchanged).  Same merges, same heights bit for bit (sqrt, mul, add, div are
+// IEEE on both sides, compiled without contraction); the final stable sort by
+// height and the relabelling are done by the binding as SciPy does them.
 // ---------------------------------------------------------------------------
-#define WARD_T 1024
 #define WARD_NONE 0x7fffffff
 
-// the mean distances as a FULL symmetric matrix (rows contiguous: a row scan
-// of the chain is coalesced; 20 GB at 50 000 cells), from the pair counts
+// the mean distances as a FULL symmetric matrix, rows `pitch` doubles apart
+// (pitch even: rows are 16-byte aligned; 20 GB at 50 000 cells), from the
+// pair counts; +inf on the diagonal and in the padding
 __global__ __launch_bounds__(256) void k_differ_to_square(
-    const int *__restrict__ differ, long long n, double S,
+    const int *__restrict__ differ, long long n, long long pitch, double S,
     double *__restrict__ F)
 {
-    const long long total = n * n;
+    const long long total = n * pitch;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
          e += (long long)gridDim.x * 256) {
-        const long long i = e / n, j = e - i * n;
-        double v = 0.0;
-        if (i != j) {
+        const long long i = e / pitch, j = e - i * pitch;
+        double v = INFINITY;
+        if (i != j && j < n) {
             const long long a = i < j ? i : j, b = i < j ? j : i;
             v = (double)differ[a * (2 * n - a - 1) / 2 + (b - a - 1)] / S;
         }
@@ -427,166 +488,328 @@ __global__ __launch_bounds__(256) void k_differ_to_square(
     }
 }
 
-__global__ __launch_bounds__(WARD_T) void k_ward_nnchain(
-    double *__restrict__ F, long long n, int *__restrict__ size,
-    int *__restrict__ chain, double *__restrict__ Z, int *__restrict__ err)
+// (d, i) < (bd, bi) lexicographically
+__device__ __forceinline__ void ward_take(double d, int i, double &bd, int &bi)
 {
-    __shared__ double r_d[WARD_T / 64];
-    __shared__ int r_i[WARD_T / 64];
-    __shared__ int s_x, s_y, s_done, s_nx, s_ny, s_len;
-    __shared__ double s_min;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (long long i = tid; i < n; i += WARD_T) size[i] = 1;
-    if (tid == 0) s_len = 0;
+    if (d < bd || (d == bd && i < bi)) {
+        bd = d;
+        bi = i;
+    }
+}
+
+// scipy's _ward: the distance of cluster i (ni cells) to the union of x and y
+__device__ __forceinline__ double ward_lw(int ni, int nx, int ny, double dxi,
+                                          double dyi, double dxy)
+{
+    const double t = 1.0 / (double)(nx + ny + ni);
+    return sqrt((double)(ni + nx) * t * dxi * dxi
+                + (double)(ni + ny) * t * dyi * dyi
+                - (double)ni * t * dxy * dxy);
+}
+
+// state of the chain between launches (device memory)
+struct WardState {
+    long long merges, steps, scans, first_alive;
+    int len, err, done;
+    // the work k_ward_chain posted for k_ward_work: 1 = the merge (x, y) -> y,
+    // x < y, plus - if b >= 0 - the nearest neighbour of row b AS THE MERGE
+    // LEAVES IT (column x gone, column y at the new distance, computed from
+    // nb, dxb, dyb); 2 = the nearest neighbour of row b as it stands
+    int cmd, x, y, nx, ny, b, nb, pad_;
+    double dxy, dxb, dyb;
+};
+
+#define WARD_B 256          // threads of a k_ward_work / k_ward_init workgroup
+#define WARD_SCAN_U 4       // 16-byte loads per thread of a row-scan slice
+
+__device__ __forceinline__ void ward_reduce_b(double &bd, int &bi, double *r_d,
+                                              int *r_i)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_down(bd, off);
+        const int oi = __shfl_down(bi, off);
+        ward_take(od, oi, bd, bi);
+    }
+    if (lane == 0) {
+        r_d[wave] = bd;
+        r_i[wave] = bi;
+    }
     __syncthreads();
-    long long first_alive = 0;          // thread 0: sizes only ever drop to 0
-    long long scans = 0;
-    for (long long k = 0; k < n - 1; k++) {
-        if (tid == 0 && s_len == 0) {
+    if (threadIdx.x == 0)
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+            ward_take(r_d[w], r_i[w], bd, bi);
+}
+
+// (minimum, first index) of columns [2 * j0, 2 * j1) of one row: inactive
+// columns, the diagonal and the padding hold +inf; columns skip_x / sub_y (or
+// -1) are taken as +inf / sub_v instead of what memory holds
+__device__ __forceinline__ void ward_scan_slice(
+    const double *F, long long pitch, long long r, long long j0, long long j1,
+    int skip_x, int sub_y, double sub_v, double &bd, int &bi)
+{
+    const double2 *row = (const double2 *)(F + (size_t)r * pitch);
+    const double2 inf2 = {INFINITY, INFINITY};
+    bd = INFINITY;
+    bi = WARD_NONE;
+    for (long long base = j0; base < j1;
+         base += (long long)WARD_SCAN_U * blockDim.x) {
+        double2 v[WARD_SCAN_U];
+#pragma unroll
+        for (int u = 0; u < WARD_SCAN_U; u++) {
+            const long long j = base + (long long)u * blockDim.x + threadIdx.x;
+            v[u] = j < j1 ? row[j] : inf2;
+        }
+#pragma unroll
+        for (int u = 0; u < WARD_SCAN_U; u++) {
+            const long long j = base + (long long)u * blockDim.x + threadIdx.x;
+            const int c0 = (int)(2 * j), c1 = c0 + 1;
+            double a0 = v[u].x, a1 = v[u].y;
+            if (c0 == skip_x) a0 = INFINITY;
+            if (c1 == skip_x) a1 = INFINITY;
+            if (c0 == sub_y) a0 = sub_v;
+            if (c1 == sub_y) a1 = sub_v;
+            // (this thread's indices ascend: strict < keeps the first)
+            if (a0 < bd) {
+                bd = a0;
+                bi = c0;
+            }
+            if (a1 < bd) {
+                bd = a1;
+                bi = c1;
+            }
+        }
+    }
+}
+
+// every row's nearest neighbour, every cluster's size: one workgroup per row
+__global__ __launch_bounds__(WARD_B) void k_ward_init(
+    const double *__restrict__ F, long long n, long long pitch,
+    int *__restrict__ size, double *__restrict__ nn_d, int *__restrict__ nn_i)
+{
+    __shared__ double r_d[WARD_B / 64];
+    __shared__ int r_i[WARD_B / 64];
+    for (long long r = blockIdx.x; r < n; r += gridDim.x) {
+        double bd;
+        int bi;
+        ward_scan_slice(F, pitch, r, 0, pitch >> 1, -1, -1, 0.0, bd, bi);
+        ward_reduce_b(bd, bi, r_d, r_i);
+        if (threadIdx.x == 0) {
+            size[r] = 1;
+            nn_d[r] = bd;
+            nn_i[r] = bi == WARD_NONE ? -1 : bi;
+        }
+        __syncthreads();
+    }
+}
+
+// ONE wave: take in what the last k_ward_work left, then walk the chain until
+// the next piece of work is known (a merge, or the scan of a stale row)
+__global__ __launch_bounds__(64) void k_ward_chain(
+    const double *__restrict__ F, long long n, long long pitch,
+    int *__restrict__ size, int *__restrict__ chain,
+    double *__restrict__ chain_d, double *__restrict__ nn_d,
+    int *__restrict__ nn_i, double *__restrict__ Z,
+    const double *__restrict__ pm_d, const int *__restrict__ pm_i, int Gm,
+    const double *__restrict__ ps_d, const int *__restrict__ ps_i, int Gs,
+    WardState *__restrict__ ws)
+{
+    const int lane = threadIdx.x;
+    if (ws->err || ws->done) return;
+    const int last = ws->cmd;
+    if (last) {
+        // the minima of the partial minima the workgroups left
+        double md = INFINITY, sd = INFINITY;
+        int mi = WARD_NONE, si = WARD_NONE;
+        if (last == 1)
+            for (int q = lane; q < Gm; q += 64) ward_take(pm_d[q], pm_i[q], md, mi);
+        const int row = ws->b;
+        if (row >= 0)
+            for (int q = lane; q < Gs; q += 64) ward_take(ps_d[q], ps_i[q], sd, si);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double od = __shfl_down(md, off), pd = __shfl_down(sd, off);
+            const int oi = __shfl_down(mi, off), pi = __shfl_down(si, off);
+            ward_take(od, oi, md, mi);
+            ward_take(pd, pi, sd, si);
+        }
+        if (lane == 0) {
+            if (last == 1) {
+                nn_d[ws->y] = md;
+                nn_i[ws->y] = mi == WARD_NONE ? -1 : mi;
+            }
+            if (row >= 0) {
+                nn_d[row] = sd;
+                nn_i[row] = si == WARD_NONE ? -2 : si;
+                if (si == WARD_NONE) ws->err = 1;   // nothing to merge with
+            }
+        }
+    }
+    if (lane != 0) return;
+    if (ws->err) return;
+    long long first_alive = ws->first_alive, steps = ws->steps,
+        merges = ws->merges;
+    int len = ws->len, cmd = 0;
+    while (cmd == 0) {
+        if (merges == n - 1) {
+            ws->done = 1;
+            break;
+        }
+        if (len == 0) {
             while (first_alive < n && size[first_alive] == 0) first_alive++;
             chain[0] = (int)first_alive;
-            s_len = 1;
+            len = 1;
         }
-        for (;;) {
-            if (tid == 0) {
-                const int len = s_len;
-                const int x = chain[len - 1];
-                s_x = x;
-                if (len > 1) {
-                    s_y = chain[len - 2];
-                    s_min = F[(size_t)x * n + s_y];
-                } else {
-                    s_y = -1;
-                    s_min = INFINITY;
-                }
-            }
-            __syncthreads();
-            const int x = s_x;
-            const double cmin = s_min;
-            // nearest active neighbour of x: strictly below cmin, the
-            // smallest index among equal distances.  Row x is contiguous;
-            // four independent loads in flight per thread.
-            const double *__restrict__ row = F + (size_t)x * n;
-            double bd = cmin;
-            int bi = WARD_NONE;
-            long long i = tid;
-            for (; i + 3 * WARD_T < n; i += 4 * WARD_T) {
-                const int z0 = size[i], z1 = size[i + WARD_T],
-                    z2 = size[i + 2 * WARD_T], z3 = size[i + 3 * WARD_T];
-                const double d0 = row[i], d1 = row[i + WARD_T],
-                    d2 = row[i + 2 * WARD_T], d3 = row[i + 3 * WARD_T];
-                if (z0 && i != x && d0 < bd) {
-                    bd = d0;
-                    bi = (int)i;
-                }
-                if (z1 && i + WARD_T != x && d1 < bd) {
-                    bd = d1;
-                    bi = (int)(i + WARD_T);
-                }
-                if (z2 && i + 2 * WARD_T != x && d2 < bd) {
-                    bd = d2;
-                    bi = (int)(i + 2 * WARD_T);
-                }
-                if (z3 && i + 3 * WARD_T != x && d3 < bd) {
-                    bd = d3;
-                    bi = (int)(i + 3 * WARD_T);
-                }
-            }
-            for (; i < n; i += WARD_T) {
-                if (size[i] == 0 || i == x) continue;
-                const double d = row[i];
-                if (d < bd) {           // (this thread's i ascend)
-                    bd = d;
-                    bi = (int)i;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_down(bd, off);
-                const int oi = __shfl_down(bi, off);
-                if (od < bd || (od == bd && oi < bi)) {
-                    bd = od;
-                    bi = oi;
-                }
-            }
-            if (lane == 0) {
-                r_d[wave] = bd;
-                r_i[wave] = bi;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < WARD_T / 64; w++)
-                    if (r_d[w] < bd || (r_d[w] == bd && r_i[w] < bi)) {
-                        bd = r_d[w];
-                        bi = r_i[w];
-                    }
-                int y = s_y;
-                if (bi != WARD_NONE) {
-                    y = bi;
-                    s_min = bd;
-                }
-                s_y = y;
-                const int len = s_len;
-                if (len > 1 && y == chain[len - 2]) {
-                    s_done = 1;
-                } else {
-                    chain[len] = y;
-                    s_len = len + 1;
-                    s_done = 0;
-                }
-                if (++scans > 8 * n + 64 || y < 0) {   // cannot happen
-                    *err = 1;
-                    s_done = 2;
-                }
-            }
-            __syncthreads();
-            if (s_done) break;
+        // (independent loads side by side: every one of them is an L2 round
+        // trip, and the walk is nothing but their latencies)
+        const int x = chain[len - 1];
+        const int prev = chain[len > 1 ? len - 2 : 0];
+        const int under = chain[len > 2 ? len - 3 : 0];
+        const double dprev = chain_d[len - 1];
+        const int cand = nn_i[x];
+        const double dc = nn_d[x];
+        if (cand < 0) {             // stale: scanned chip-wide
+            ws->b = x;
+            ws->scans++;
+            cmd = 2;
+            break;
         }
-        if (s_done == 2) return;
-        if (tid == 0) {
-            s_len -= 2;
-            int x = s_x, y = s_y;
-            if (x > y) {
-                const int t = x;
-                x = y;
-                y = t;
-            }
-            const int nx = size[x], ny = size[y];
-            Z[k * 4 + 0] = (double)x;
-            Z[k * 4 + 1] = (double)y;
-            Z[k * 4 + 2] = s_min;
-            Z[k * 4 + 3] = (double)(nx + ny);
-            size[x] = 0;
-            size[y] = nx + ny;
-            s_x = x;
-            s_y = y;
-            s_nx = nx;
-            s_ny = ny;
+        int y = cand;
+        double dmin = dc;
+        if (len > 1 && !(dc < dprev)) {     // the previous element wins ties
+            y = prev;
+            dmin = dprev;
         }
-        __syncthreads();
-        {
-            // Lance-Williams pass: rows x and y read and row y written
-            // contiguously, column y (the symmetric entries) scattered
-            const int x = s_x, y = s_y, nx = s_nx, ny = s_ny;
-            const double dxy = s_min;
-            const double *__restrict__ rx = F + (size_t)x * n;
-            double *__restrict__ ry = F + (size_t)y * n;
-            for (long long i = tid; i < n; i += WARD_T) {
-                const int ni = size[i];
-                if (ni == 0 || i == y) continue;
-                const double dxi = rx[i];
-                const double dyi = ry[i];
-                // scipy's _ward
-                const double t = 1.0 / (double)(nx + ny + ni);
-                const double v = sqrt((double)(ni + nx) * t * dxi * dxi
-                                      + (double)(ni + ny) * t * dyi * dyi
-                                      - (double)ni * t * dxy * dxy);
-                ry[i] = v;
-                F[(size_t)i * n + y] = v;
+        if (++steps > 8 * n + 64 || y < 0 || y >= n) {
+            ws->err = 1;            // cannot happen
+            break;
+        }
+        if (len > 1 && y == prev) {
+            len -= 2;
+            int a = x, b = y;
+            if (a > b) {
+                const int t = a;
+                a = b;
+                b = t;
+            }
+            const bool back = len > 0 && merges + 1 < n - 1;
+            const int na = size[a], nb = size[b];
+            const int top_n = back ? size[under] : 0;
+            const double top_dx = back ? F[(size_t)a * pitch + under] : 0.0;
+            const double top_dy = back ? F[(size_t)b * pitch + under] : 0.0;
+            Z[merges * 4 + 0] = (double)a;
+            Z[merges * 4 + 1] = (double)b;
+            Z[merges * 4 + 2] = dmin;
+            Z[merges * 4 + 3] = (double)(na + nb);
+            size[a] = 0;
+            size[b] = na + nb;
+            merges++;
+            ws->x = a;
+            ws->y = b;
+            ws->nx = na;
+            ws->ny = nb;
+            ws->dxy = dmin;
+            // the row the chain returns to: its neighbour was one of the two
+            ws->b = -1;
+            if (back) {
+                ws->b = under;
+                ws->nb = top_n;
+                ws->dxb = top_dx;
+                ws->dyb = top_dy;
+                ws->scans++;
+            }
+            cmd = 1;
+            break;
+        }
+        chain[len] = y;
+        chain_d[len] = dmin;
+        len++;
+    }
+    ws->cmd = cmd;
+    ws->first_alive = first_alive;
+    ws->steps = steps;
+    ws->merges = merges;
+    ws->len = len;
+}
+
+// The posted work, on the whole chip.  Workgroups [0, Gm): the Lance-Williams
+// pass of the merge (x, y) -> y, one cluster i per thread - rows x and y are
+// read and row y written contiguously, columns x (now +inf) and y (the
+// symmetric entries) are scattered over every compute unit's path to the L2;
+// every row's nearest neighbour is kept exact on the way.  Workgroups
+// [Gm, Gm + Gs): a slice each of the row whose neighbour is asked for.
+__global__ __launch_bounds__(WARD_B) void k_ward_work(
+    double *__restrict__ F, long long n, long long pitch,
+    const int *__restrict__ size, double *__restrict__ nn_d,
+    int *__restrict__ nn_i, double *__restrict__ pm_d,
+    int *__restrict__ pm_i, int Gm, double *__restrict__ ps_d,
+    int *__restrict__ ps_i, int Gs, const WardState *__restrict__ ws)
+{
+    __shared__ double r_d[WARD_B / 64];
+    __shared__ int r_i[WARD_B / 64];
+    const int cmd = ws->cmd;
+    if (!cmd || ws->err || ws->done) return;
+    const int x = ws->x, y = ws->y, nx = ws->nx, ny = ws->ny, rb = ws->b;
+    const double dxy = ws->dxy;
+    double bd = INFINITY;
+    int bi = WARD_NONE;
+    if ((int)blockIdx.x >= Gm) {
+        if (rb < 0) return;
+        const int s = (int)blockIdx.x - Gm;
+        const long long n2 = pitch >> 1;
+        const long long per = (n2 + Gs - 1) / Gs;
+        const long long j0 = s * per, j1 = j0 + per < n2 ? j0 + per : n2;
+        double vb = 0.0;
+        if (cmd == 1) vb = ward_lw(ws->nb, nx, ny, ws->dxb, ws->dyb, dxy);
+        ward_scan_slice(F, pitch, rb, j0, j1, cmd == 1 ? x : -1,
+                        cmd == 1 ? y : -1, vb, bd, bi);
+        ward_reduce_b(bd, bi, r_d, r_i);
+        if (threadIdx.x == 0) {
+            ps_d[s] = bd;
+            ps_i[s] = bi;
+        }
+        return;
+    }
+    if (cmd != 1) return;
+    const double *__restrict__ rx = F + (size_t)x * pitch;
+    double *__restrict__ ry = F + (size_t)y * pitch;
+    for (long long i = (long long)blockIdx.x * WARD_B + threadIdx.x; i < n;
+         i += (long long)Gm * WARD_B) {
+        if (i == x) {
+            ry[i] = INFINITY;           // x is gone
+            continue;
+        }
+        const int ni = size[i];
+        if (ni == 0 || i == y) continue;
+        const double v = ward_lw(ni, nx, ny, rx[i], ry[i], dxy);
+        ry[i] = v;
+        double *__restrict__ ri = F + (size_t)i * pitch;
+        ri[y] = v;
+        ri[x] = INFINITY;
+        ward_take(v, (int)i, bd, bi);
+        if (i == rb) continue;          // its neighbour is being recomputed
+        // row i's nearest neighbour, kept exact
+        const int ci = nn_i[i];
+        if (ci == x || ci == y) {
+            // its minimum was one of the merged entries: still the minimum
+            // only if the new entry is no larger
+            if (ci == y && v <= nn_d[i])
+                nn_d[i] = v;
+            else
+                nn_i[i] = -1;
+        } else if (ci >= 0) {
+            const double cd = nn_d[i];
+            if (v < cd || (v == cd && y < ci)) {
+                nn_d[i] = v;
+                nn_i[i] = y;
             }
         }
-        __syncthreads();
+    }
+    ward_reduce_b(bd, bi, r_d, r_i);
+    if (threadIdx.x == 0) {
+        pm_d[blockIdx.x] = bd;
+        pm_i[blockIdx.x] = bi;
     }
 }
 
@@ -601,16 +824,19 @@ extern "C" int bnpc_post_ward(bnpc_post *p, double *Z_raw)
     }
     PCK(hipSetDevice(p->device));
     const long long n = p->N;
-    double *d_D = nullptr, *d_Z = nullptr;
-    int *d_size = nullptr, *d_chain = nullptr, *d_err = nullptr;
+    if (n < 2) return 0;
+    const long long pitch = (n + 1) & ~1ll;
+    const int Gm = (int)std::min<long long>((n + WARD_B - 1) / WARD_B, 1024);
+    const int Gs = (int)std::max<long long>(1, std::min<long long>(
+        ((pitch >> 1) + WARD_B * 3 - 1) / (WARD_B * 3), 256));
     // the full symmetric matrix: 8 N^2 bytes (20 GB at 50 000 cells).  Not
     // fitting is the ONE failure the caller may answer with SciPy's routine
     // on the condensed vector: it gets a return code of its own (5).
     {
         size_t free_b = 0, total_b = 0;
         PCK(hipMemGetInfo(&free_b, &total_b));
-        const size_t need = (size_t)n * n * sizeof(double)
-            + (size_t)n * 48 + ((size_t)1 << 20);
+        const size_t need = (size_t)n * pitch * sizeof(double)
+            + (size_t)n * 72 + ((size_t)1 << 20);
         if (need > free_b) {
             bnpc_set_error("ward linkage: the %lld x %lld distance matrix "
                            "needs %.1f GB, %.1f GB of device memory are free",
@@ -618,33 +844,107 @@ extern "C" int bnpc_post_ward(bnpc_post *p, double *Z_raw)
             return 5;
         }
     }
-    hipError_t e = hipMalloc((void **)&d_D, (size_t)n * n * sizeof(double));
+    double *d_D = nullptr, *d_Z = nullptr, *d_cd = nullptr, *d_nd = nullptr,
+        *d_pd = nullptr;
+    int *d_size = nullptr, *d_chain = nullptr, *d_ni = nullptr,
+        *d_pi = nullptr;
+    WardState *d_ws = nullptr;
+    hipStream_t st = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const int G = Gm + Gs;
+    hipError_t e = hipMalloc((void **)&d_D, (size_t)n * pitch * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d_Z, (size_t)(n - 1) * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d_size, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&d_chain, (size_t)(n + 1) * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_err, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(d_err, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cd, (size_t)(n + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_nd, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ni, (size_t)n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_pd, (size_t)G * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_pi, (size_t)G * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ws, sizeof(WardState));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ws, 0, sizeof(WardState), st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_differ_to_square, dim3(4096), dim3(256), 0, 0,
-                           p->differ, n, (double)p->S, d_D);
+        hipLaunchKernelGGL(k_differ_to_square, dim3(4096), dim3(256), 0, st,
+                           p->differ, n, pitch, (double)p->S, d_D);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_ward_nnchain, dim3(1), dim3(WARD_T), 0, 0, d_D, n,
-                           d_size, d_chain, d_Z, d_err);
+        hipLaunchKernelGGL(k_ward_init,
+                           dim3((unsigned)std::min<long long>(n, 4096)),
+                           dim3(WARD_B), 0, st, d_D, n, pitch, d_size, d_nd,
+                           d_ni);
         e = hipGetLastError();
     }
-    int err = 0;
-    if (e == hipSuccess)
-        e = hipMemcpy(&err, d_err, sizeof(int), hipMemcpyDeviceToHost);
+    // chain, work, chain, work ... on one stream: a graph of WARD_BATCH such
+    // pairs, replayed until the chain reports that everything is merged (a
+    // launch that finds nothing to do returns at once)
+    const int WARD_BATCH = 128;
+    auto pair = [&](hipStream_t s) {
+        hipLaunchKernelGGL(k_ward_chain, dim3(1), dim3(64), 0, s, d_D, n,
+                           pitch, d_size, d_chain, d_cd, d_nd, d_ni, d_Z,
+                           d_pd, d_pi, Gm, d_pd + Gm, d_pi + Gm, Gs, d_ws);
+        hipLaunchKernelGGL(k_ward_work, dim3((unsigned)G), dim3(WARD_B), 0, s,
+                           d_D, n, pitch, d_size, d_nd, d_ni, d_pd, d_pi, Gm,
+                           d_pd + Gm, d_pi + Gm, Gs, d_ws);
+    };
+    bool graphed = false;
+    // (BNPC_WARD_GRAPH=0: plain launches - rocprofv3's kernel trace does not
+    // survive the replay of a captured graph on this stack)
+    const char *wg = getenv("BNPC_WARD_GRAPH");
+    if (e == hipSuccess && !(wg && wg[0] == '0')
+        && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)
+            == hipSuccess) {
+        for (int k = 0; k < WARD_BATCH; k++) pair(st);
+        if (hipStreamEndCapture(st, &graph) == hipSuccess && graph
+            && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)
+                == hipSuccess)
+            graphed = true;
+    }
+    (void)hipGetLastError();
+    WardState ws;
+    memset(&ws, 0, sizeof ws);
+    // about 2.6 pieces of work per merge (measured: the merge itself and 1.6
+    // scans of stale rows); the state is looked at after every `look` batches
+    long long batches = 0;
+    const long long look = std::max<long long>(1, (n / WARD_BATCH) / 8);
+    const long long cap = 16 * (n / WARD_BATCH + 2) + 64;
+    while (e == hipSuccess && !ws.done && !ws.err && batches < cap) {
+        const long long burst = batches == 0
+            ? std::max<long long>(1, 2 * n / WARD_BATCH) : look;
+        for (long long q = 0; q < burst && e == hipSuccess; q++) {
+            if (graphed) {
+                e = hipGraphLaunch(exec, st);
+            } else {
+                for (int k = 0; k < WARD_BATCH; k++) pair(st);
+                e = hipGetLastError();
+            }
+        }
+        batches += burst;
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&ws, d_ws, sizeof ws, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
     if (e == hipSuccess)
         e = hipMemcpy(Z_raw, d_Z, (size_t)(n - 1) * 4 * sizeof(double),
                       hipMemcpyDeviceToHost);
+    p->ward_stats[0] = ws.scans;
+    p->ward_stats[1] = ws.steps;
+    const int err = ws.err || (e == hipSuccess && ws.merges != n - 1);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (st) (void)hipStreamDestroy(st);
     if (d_D) (void)hipFree(d_D);
     if (d_Z) (void)hipFree(d_Z);
     if (d_size) (void)hipFree(d_size);
     if (d_chain) (void)hipFree(d_chain);
-    if (d_err) (void)hipFree(d_err);
+    if (d_cd) (void)hipFree(d_cd);
+    if (d_nd) (void)hipFree(d_nd);
+    if (d_ni) (void)hipFree(d_ni);
+    if (d_pd) (void)hipFree(d_pd);
+    if (d_pi) (void)hipFree(d_pi);
+    if (d_ws) (void)hipFree(d_ws);
     if (e != hipSuccess) {
         bnpc_set_error("ward linkage: %s", hipGetErrorString(e));
         return 1;

@@ -866,6 +866,10 @@ int bnpc_post_mpear(bnpc_post *post, const uint16_t *labels, int64_t C,
  * free memory - the caller may take SciPy's routine on the condensed vector;
  * every other failure is an error. */
 int bnpc_post_ward(bnpc_post *post, double *Z_raw);
+/* diagnostic: full row scans and chain steps of the last bnpc_post_ward (a
+ * chain step whose row still knows its nearest neighbour needs no scan) */
+int bnpc_post_ward_stats(const bnpc_post *post, int64_t *scans,
+                         int64_t *steps);
 int bnpc_post_destroy(bnpc_post *post);
 
 #ifdef __cplusplus

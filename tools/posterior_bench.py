@@ -34,7 +34,10 @@ t0 = t_all = time.perf_counter()
 post = _lib.Posterior(a)
 t0 = lap('pair counts on the device (k_codist) + their sum', t0)
 tree = post.ward()
-t0 = lap('Ward linkage on the device (k_ward_nnchain) + relabel', t0)
+t0 = lap('Ward linkage on the device (k_ward_chain|work) + relabel', t0)
+scans, steps = post.ward_stats()
+print(f'    ({scans} full row scans for {N - 1} merges and {steps} chain '
+    'steps: the other steps took the row\'s cached nearest neighbour)')
 if os.environ.get('WARD_CHECK'):
     dist = post.dist()
     t0 = lap('mean distance divided on the device -> host f64', t0)
