@@ -461,6 +461,10 @@ def main():
             'threads_wide_batches': _lib.threads_for(K_end * M),
             'native_mh_batch': pmodel._native_kernels() is not None,
             'native_beta': pmodel._native_beta(),
+            # the private interfaces / start-up comparisons the fast paths
+            # rest on (False = the documented fallback ran; all of them forced
+            # off: BNPC_STREAM_LIVE=0 BNPC_NATIVE_MH=0 BNPC_NATIVE_BETA=0)
+            'fast_paths': pmodel.fast_paths(),
             'numa_node': getattr(model._dev(), 'numa_node', None),
             'cpus': len(os.sched_getaffinity(0)),
             # CPU time of ALL threads of the chain's process per timed step

@@ -637,6 +637,8 @@ def rng_live():
     this NumPy does not expose it as expected (then callers exchange a copy).
     Checked once per process against np.random.get_state()."""
     pid = os.getpid()
+    if env('BNPC_STREAM_LIVE', '1') == '0':     # copies through get_state
+        return None
     rs = np.random.mtrand._rand
     # (np.random.set_bit_generator / a replaced _rand give the stream another
     # state block: the pointer is looked up again whenever the owners change)
@@ -690,7 +692,7 @@ def gauss_live():
     _gauss_live.clear()
     _gauss_live.update(pid=pid, ptr=None, owner=rs_now,
         bg=getattr(rs_now, '_bit_generator', None))
-    if os.environ.get('BNPC_GAUSS_LIVE', '1') == '0':
+    if os.environ.get('BNPC_STREAM_LIVE', '1') in ('0', 'rng'):
         return None
     saved = np.random.get_state()
     try:
@@ -889,9 +891,12 @@ def _mh_buffers(G, M):
     return buf
 
 
+MH_WIDE_FROM = 65536        # batch entries from which up to 32 ranks are used
+
+
 def threads_for(elements):
     """Team ranks for a parameter batch of `elements` matrix entries: from
-    65536 entries on (BNPC_MH_WIDE_FROM; round 3: the device screens the
+    65536 entries on (MH_WIDE_FROM; round 3: the device screens the
     batches of a converged step, a config-3 chain runs as fast on 4 ranks as
     on 32, and every extra rank that is woken costs) up to 32 ranks,
     unless BNPC_HOST_THREADS pins the number or the node is shared with other
@@ -901,8 +906,7 @@ def threads_for(elements):
     interleaved pairs: median 826 -> 869 steps/s.  (The sweeps' team scan does
     not gain from more than 16.)"""
     n = host_threads()
-    wide_from = int(env('BNPC_MH_WIDE_FROM', '65536'))
-    if elements >= wide_from and env('BNPC_HOST_THREADS') is None:
+    if elements >= MH_WIDE_FROM and env('BNPC_HOST_THREADS') is None:
         n = max(n, min(_default_team(32), _host_cores() // 2))
     return n
 

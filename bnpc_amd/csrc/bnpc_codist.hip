@@ -890,10 +890,10 @@ extern "C" int bnpc_post_ward(bnpc_post *p, double *Z_raw)
                            d_pd + Gm, d_pi + Gm, Gs, d_ws);
     };
     bool graphed = false;
-    // (BNPC_WARD_GRAPH=0: plain launches - rocprofv3's kernel trace does not
-    // survive the replay of a captured graph on this stack)
-    const char *wg = getenv("BNPC_WARD_GRAPH");
-    if (e == hipSuccess && !(wg && wg[0] == '0')
+    // (BNPC_WARD_DEVICE=plain: plain launches - rocprofv3's kernel trace does
+    // not survive the replay of a captured graph on this stack)
+    const char *wg = getenv("BNPC_WARD_DEVICE");
+    if (e == hipSuccess && !(wg && !strcmp(wg, "plain"))
         && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)
             == hipSuccess) {
         for (int k = 0; k < WARD_BATCH; k++) pair(st);

@@ -565,7 +565,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
 
     for (int64_t g = 0; g < G; g++) a->declined[g] = 0;
-    static const bool trace = getenv("BNPC_MH_TRACE") != nullptr;
+    // BNPC_TIMING=mh: phase times of every parameter batch on stderr
+    static const bool trace = [] {
+        const char *e = getenv("BNPC_TIMING");
+        return e && strstr(e, "mh");
+    }();
     timespec ts0;
     long t_draws = 0;
     if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -638,13 +642,20 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                     // evaluated
                     memcpy(a->prior_out + row, a->known_prior + row,
                            (size_t)M * sizeof(double));
+                    // (64 bytes at a time: nearly every entry of a running
+                    // chain is a hit - a compare per element was 1 ns each,
+                    // a quarter of a millisecond per config-5 batch)
                     const float *kt = a->known_theta + row;
-                    for (int64_t i = 0; i < M; i++) {
-                        uint32_t x, y;
-                        memcpy(&x, kt + i, 4);
-                        memcpy(&y, old + i, 4);
-                        if (x != y && !sc[i]) miss.push_back((int32_t)i);
+                    int64_t i = 0;
+                    for (; i + 16 <= M; i += 16) {
+                        if (!memcmp(kt + i, old + i, 64)) continue;
+                        for (int64_t j = i; j < i + 16; j++)
+                            if (memcmp(kt + j, old + j, 4) && !sc[j])
+                                miss.push_back((int32_t)j);
                     }
+                    for (; i < M; i++)
+                        if (memcmp(kt + i, old + i, 4) && !sc[i])
+                            miss.push_back((int32_t)i);
                 } else {
                     for (int64_t i = 0; i < M; i++)
                         if (!sc[i]) miss.push_back((int32_t)i);
@@ -684,11 +695,9 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         const int32_t *sure_p = sure.data();
         // a thread per ~12 tasks: waking a parked team costs more than
         // several hundred elements
-        static const int64_t per = [] {
-            const char *e = getenv("BNPC_MH_TASKS_PER_RANK");
-            const long v = e ? atol(e) : 0;
-            return (int64_t)(v >= 1 && v <= 1024 ? v : 12);
-        }();
+        // (4 gave 130 against 180 us per update_parameters under the
+        // profiler and nothing on the bench line)
+        const int64_t per = 12;
         if (threads > (n_tasks + per - 1) / per)
             threads = (int)((n_tasks + per - 1) / per);
         if (threads < 1) threads = 1;
@@ -745,11 +754,7 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     // 2 tasks is worth 10-25 us per move; waking a PARKED rank still costs as
     // much as 256-512 entries - 2000 entries on 31 ranks were no faster than
     // on one when the team was asleep between the batches of a step)
-    static const int64_t dense_per = [] {
-        const char *e = getenv("BNPC_MH_DENSE_TASKS_PER_RANK");
-        const long v = e ? atol(e) : 0;
-        return (int64_t)(v >= 1 && v <= 1024 ? v : 2);
-    }();
+    const int64_t dense_per = 2;
     if (threads > (tasks + dense_per - 1) / dense_per)
         threads = (int)((tasks + dense_per - 1) / dense_per);
     if (threads < 1) threads = 1;
@@ -844,11 +849,18 @@ extern "C" int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x,
     if (threads > chunks) threads = (int)chunks;
     // cache hits are a compare and a copy: not worth waking anybody
     int64_t misses = 0;
-    if (known_theta)
-        for (int64_t i = 0; i < n; i++)
+    if (known_theta) {
+        int64_t i = 0;
+        for (; i + 16 <= n; i += 16) {      // 64 bytes at a time
+            if (!memcmp(known_theta + i, x + i, 64)) continue;
+            for (int64_t j = i; j < i + 16; j++)
+                misses += memcmp(known_theta + j, x + j, sizeof(float)) != 0;
+        }
+        for (; i < n; i++)
             misses += memcmp(known_theta + i, x + i, sizeof(float)) != 0;
-    else
+    } else {
         misses = n;
+    }
     // (large arrays go to the team anyway: the pass is memory traffic)
     if (misses < 4096 && n < 65536) threads = 1;
     std::atomic<int64_t> next(0);
@@ -857,7 +869,18 @@ extern "C" int bnpc_beta_logpdf_f32(const bnpc_host_kernels *k, const float *x,
             const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
             if (t >= chunks) break;
             const int64_t i1 = (t + 1) * 4 * BLK < n ? (t + 1) * 4 * BLK : n;
-            for (int64_t i = t * 4 * BLK; i < i1; i++) {
+            int64_t i = t * 4 * BLK;
+            if (known_theta)
+                for (; i + 16 <= i1; i += 16) {
+                    if (!memcmp(known_theta + i, x + i, 64)) {
+                        memcpy(out + i, known_prior + i, 16 * sizeof(double));
+                        continue;
+                    }
+                    for (int64_t j = i; j < i + 16; j++)
+                        out[j] = !memcmp(known_theta + j, x + j, sizeof(float))
+                            ? known_prior[j] : beta_logpdf1(k, x[j], p, q, bl);
+                }
+            for (; i < i1; i++) {
                 if (known_theta
                     && !memcmp(known_theta + i, x + i, sizeof(float)))
                     out[i] = known_prior[i];
@@ -1008,16 +1031,8 @@ extern "C" int bnpc_log_accept(const bnpc_host_kernels *k, const bnpc_accept_arg
     const double bl = a->uniform_prior ? 0.0 : k->betaln(a->p, a->q, 0);
     const int64_t chunks = (a->M + BLK - 1) / BLK, tasks = a->G * chunks;
     int threads = a->threads;
-    static const int64_t accept_per = [] {
-        const char *e = getenv("BNPC_ACCEPT_TASKS_PER_RANK");
-        const long v = e ? atol(e) : 0;
-        return (int64_t)(v >= 1 && v <= 1024 ? v : 2);
-    }();
-    static const int64_t accept_min = [] {
-        const char *e = getenv("BNPC_ACCEPT_TEAM_FROM");
-        const long v = e ? atol(e) : 0;
-        return (int64_t)(v >= 1 ? v : 1024);
-    }();
+    // a rank per 2 tasks, the team from 1024 entries on
+    const int64_t accept_per = 2, accept_min = 1024;
     if (threads > (tasks + accept_per - 1) / accept_per)
         threads = (int)((tasks + accept_per - 1) / accept_per);
     if (tasks * BLK < accept_min || threads < 1) threads = 1;

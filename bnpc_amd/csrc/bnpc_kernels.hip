@@ -87,27 +87,28 @@ struct View {
 };
 
 // Switches, read from the environment when a context is created and again
-// by bnpc_reload_options (A/B tools and tests); never on the launch path.
+// by bnpc_reload_options (tests); never on the launch path.  README lists
+// them; the tuning constants that used to be switches (chunking of split
+// launches, zero-copy sizes, the screen's minimum batch ...) are the measured
+// values below.
 struct Tunables {
-    int msplit = 1, msplit_waves = 0, msplit_max = 64;  // waves 0 = auto
-    int xcd_remap = 1, ll_asm = 2, asm2_min_wgs = 448;
-    int tables_flat_max = 1 << 20, force_kw = 0;
-    int zero_copy = 1;              // small payloads are read / written in
-    int64_t zc_in_max = 256 << 10;  // place in pinned host memory
-    int64_t zc_out_max = 512 << 10;
-    int64_t zc_sweep_max = 0;       // the sweep's matrix (pinned) in place
-    int mask_counts_max = 64;       // segments for the mask-popcount counts
-    int ll_prefetch = -1;           // k_ll8_asm L2 prefetch: -1 auto, 0, 1
-    int seq_kernel = 2;             // caller-built tables: 2 = k_ll_seqp
-                                    // (pipeline), 1 = k_ll_seq, 0 = k_ll
-    int seq_stage = 1;              // k_ll_seqp: tables copied to the device
-    int seq_kc = 1;                 // clusters per wave in k_ll_seq
-    int lazy_matrix = 1;            // sweep matrix copied behind the hints
-    int eager_matrix = 1;           // queue the sweep matrix's copy when the
-                                    // previous sweep needed it
-    int mh_screen = 1;              // device screen of the parameter batches
-    int mh_screen_min = 512;        // ... from this many elements on
+    int msplit = 1;                 // BNPC_MSPLIT: mutation-split small launches
+    int force_kw = 0;               // BNPC_KW: force the cluster tile (tests)
+    int zero_copy = 1;              // BNPC_ZERO_COPY: small payloads are read /
+                                    // written in place in pinned host memory
+    int mask_counts_max = 64;       // BNPC_MASK_COUNTS_MAX: segments for the
+                                    // mask-popcount counts (tests lower it)
+    int mh_screen = 1;              // BNPC_MH_SCREEN: device screen of the
+                                    // parameter batches
 };
+
+#define MSPLIT_MAX 64               // chunks of a split launch at most
+#define ASM2_MIN_WGS 448            // workgroups from which a wave takes 2 blocks
+#define TABLES_FLAT_MAX (1 << 20)   // table elements up to which one thread
+                                    // builds one element
+#define ZC_IN_MAX ((int64_t)256 << 10)      // zero-copy inputs / results up to
+#define ZC_OUT_MAX ((int64_t)512 << 10)
+#define MH_SCREEN_MIN 512           // batch entries from which the screen pays
 
 static int env_int(const char *name, int dflt)
 {
@@ -118,29 +119,13 @@ static int env_int(const char *name, int dflt)
 static void read_tunables(Tunables &t)
 {
     t.msplit = env_int("BNPC_MSPLIT", 1);
-    t.msplit_waves = env_int("BNPC_MSPLIT_WAVES", 0);
-    t.msplit_max = env_int("BNPC_MSPLIT_MAX", 64);
-    t.xcd_remap = env_int("BNPC_XCD_REMAP", 1);
-    t.ll_asm = env_int("BNPC_LL_ASM", 2);       // 0 C++, 1 asm, 2 asm x2
-    t.asm2_min_wgs = env_int("BNPC_ASM2_MIN_WGS", 448);
-    t.tables_flat_max = env_int("BNPC_TABLES_FLAT_MAX", 1 << 20);
     t.force_kw = env_int("BNPC_KW", 0);
     if (t.force_kw != 1 && t.force_kw != 2 && t.force_kw != 4
         && t.force_kw != 8)
         t.force_kw = 0;
     t.zero_copy = env_int("BNPC_ZERO_COPY", 1);
-    t.zc_in_max = (int64_t)env_int("BNPC_ZC_IN_KB", 256) << 10;
-    t.zc_out_max = (int64_t)env_int("BNPC_ZC_OUT_KB", 512) << 10;
-    t.zc_sweep_max = (int64_t)env_int("BNPC_ZC_SWEEP_KB", 0) << 10;
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
-    t.ll_prefetch = env_int("BNPC_LL_PREFETCH", -1);
-    t.seq_kernel = env_int("BNPC_SEQ_KERNEL", 2);
-    t.seq_stage = env_int("BNPC_SEQ_STAGE", 1);
-    t.seq_kc = env_int("BNPC_SEQ_KC", 1);
-    t.lazy_matrix = env_int("BNPC_LAZY_MATRIX", 1);
-    t.eager_matrix = env_int("BNPC_EAGER_MATRIX", 1);
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
-    t.mh_screen_min = env_int("BNPC_MH_SCREEN_MIN", 512);
 }
 
 struct bnpc_ctx {
@@ -273,8 +258,6 @@ static int ensure(DevBuf &b, size_t bytes)
 static bool thp_available()
 {
     static const bool ok = [] {
-        if (const char *e = getenv("BNPC_PIN_HUGE"))
-            if (e[0] == '0') return false;
         FILE *f = fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r");
         if (!f) return false;
         char line[128] = {0};
@@ -395,7 +378,7 @@ static int arena_reset(bnpc_ctx *c)
 // that uses the arena ends with a stream synchronisation.
 static const void *stage_in_place(bnpc_ctx *c, const void *src, size_t bytes)
 {
-    if (!c->tun.zero_copy || (int64_t)bytes > c->tun.zc_in_max) return nullptr;
+    if (!c->tun.zero_copy || (int64_t)bytes > ZC_IN_MAX) return nullptr;
     void *slot = stage_slot(c, bytes);
     if (!slot || !c->stage_dev) return nullptr;
     memcpy(slot, src, bytes);
@@ -407,7 +390,7 @@ static const void *stage_in_place(bnpc_ctx *c, const void *src, size_t bytes)
 // not available for this size.
 static void *zc_result(bnpc_ctx *c, size_t bytes, void **dev)
 {
-    if (!c->tun.zero_copy || (int64_t)bytes > c->tun.zc_out_max
+    if (!c->tun.zero_copy || (int64_t)bytes > ZC_OUT_MAX
         || bytes > ZC_OUT_BYTES)
         return nullptr;
     if (!c->zc_out) {
@@ -991,134 +974,15 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
 }
 
 // ---------------------------------------------------------------------------
-// K2s: the same sums over CALLER-BUILT tables in strict mutation order - the
+// K2p: the same sums over CALLER-BUILT tables in strict mutation order - the
 // bit-exact path of CRP._rg_init_split (libs/CRP.py:547-561, whose
 // `ll_j > ll_i` is the one discrete decision on the path) and of the
 // new-cluster term (libs/CRP.py:230-234); K is 1 or 2 there and the launch
-// has a handful of waves, so what matters is the latency of ONE wave's chain
-// of M dependent adds, not throughput:
-//   wave <-> (block of 64 slots, ONE cluster); workgroup <-> 4 blocks of the
-//   same cluster, whose table {L1, L0}[m] is staged once into LDS straight
-//   from the caller's layout (no re-layout launch);
-//   the lane masks of 64 mutations arrive with ONE coalesced vector load
-//   (lane j holds mutation m0 + j), the next 64 are in flight meanwhile;
-//   mutation m0 + j: v_readlane the mask pair into SGPRs -> EXEC, the table
-//   pair by a broadcast LDS read, two exec-masked v_add_f64.
-// No scalar-memory round trip inside the loop (k_ll<KW> waits ~0.3 us for one
-// every stage when nothing else runs on the CU).  Same order, same bits.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long readlane_u64(
-    unsigned long long v, int lane)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v,
-                                                            lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(
-        (int)(unsigned)(v >> 32), lane);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// KC = clusters per wave: 2 shares the mask fetch and the EXEC writes between
-// two independent add chains (the launch clusters of a split: K = 2) and
-// hides each chain's add latency behind the other; 1 otherwise.
-template <int KC>
-__global__ __launch_bounds__(256) void k_ll_seq(
-    const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
-    long long nblk, const double *__restrict__ L1,
-    const double *__restrict__ L0, int K, long long ldo,
-    double *__restrict__ out)
-{
-    // [KC][Mpad + 8] {L1, L0} of clusters k0 .. k0 + KC - 1
-    extern __shared__ double2 seq_tab[];
-    const int k0 = blockIdx.y * KC;
-    const int stride = Mpad + 8;
-    for (int i = threadIdx.x; i < KC * stride; i += 256) {
-        const int kk = i / stride, m = i - kk * stride;
-        const int k = k0 + kk;
-        seq_tab[i] = (m < M && k < K)
-            ? make_double2(L1[(size_t)k * M + m], L0[(size_t)k * M + m])
-            : make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const long long blk = (long long)blockIdx.x * 4 + wave;
-    if (blk >= nblk) return;            // whole wave, after the barrier
-    const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
-    double acc[KC];
-#pragma unroll
-    for (int kk = 0; kk < KC; kk++) acc[kk] = 0.0;
-    ulonglong2 cur = mk[lane];
-    // table pairs of 8 mutations at a time, ping-pong: the LDS reads of the
-    // next 8 are in flight while the masked adds of these 8 issue (the asm
-    // blocks keep program order, so the prefetch is spelled out)
-    double2 ta[KC][8], tb[KC][8];
-#pragma unroll
-    for (int kk = 0; kk < KC; kk++)
-#pragma unroll
-        for (int u = 0; u < 8; u++) ta[kk][u] = seq_tab[kk * stride + u];
-#define SEQ_STEP(T, U, J)                                                     \
-    {                                                                         \
-        const unsigned long long ones = readlane_u64(cur.x, (J));             \
-        const unsigned long long zeros = readlane_u64(cur.y, (J));            \
-        if constexpr (KC == 1) {                                              \
-            asm volatile(                                                     \
-                "s_mov_b64 exec, %1\n\t"                                      \
-                "v_add_f64 %0, %0, %3\n\t"                                    \
-                "s_mov_b64 exec, %2\n\t"                                      \
-                "v_add_f64 %0, %0, %4\n\t"                                    \
-                "s_mov_b64 exec, -1"                                          \
-                : "+v"(acc[0])                                                \
-                : "s"(ones), "s"(zeros), "v"((T)[0][U].x), "v"((T)[0][U].y)); \
-        } else {                                                              \
-            asm volatile(                                                     \
-                "s_mov_b64 exec, %2\n\t"                                      \
-                "v_add_f64 %0, %0, %4\n\t"                                    \
-                "v_add_f64 %1, %1, %6\n\t"                                    \
-                "s_mov_b64 exec, %3\n\t"                                      \
-                "v_add_f64 %0, %0, %5\n\t"                                    \
-                "v_add_f64 %1, %1, %7\n\t"                                    \
-                "s_mov_b64 exec, -1"                                          \
-                : "+v"(acc[0]), "+v"(acc[KC - 1])                             \
-                : "s"(ones), "s"(zeros), "v"((T)[0][U].x), "v"((T)[0][U].y),  \
-                  "v"((T)[KC - 1][U].x), "v"((T)[KC - 1][U].y));              \
-        }                                                                     \
-    }
-    for (int m0 = 0; m0 < Mpad; m0 += 64) {
-        ulonglong2 nxt = make_ulonglong2(0ull, 0ull);
-        if (m0 + 64 < Mpad) nxt = mk[m0 + 64 + lane];
-#pragma unroll
-        for (int sb = 0; sb < 8; sb += 2) {
-#pragma unroll
-            for (int kk = 0; kk < KC; kk++)
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    tb[kk][u] = seq_tab[kk * stride + m0 + 8 * (sb + 1) + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) SEQ_STEP(ta, u, 8 * sb + u)
-#pragma unroll
-            for (int kk = 0; kk < KC; kk++)
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    ta[kk][u] = seq_tab[kk * stride + m0 + 8 * (sb + 2) + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) SEQ_STEP(tb, u, 8 * (sb + 1) + u)
-        }
-        cur = nxt;
-    }
-#undef SEQ_STEP
-    const long long slot = blk * 64 + lane;
-    if (slot < n) {
-#pragma unroll
-        for (int kk = 0; kk < KC; kk++)
-            if (k0 + kk < K) out[(size_t)slot * ldo + k0 + kk] = acc[kk];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K2p: K2s as a producer/consumer pipeline - same sums, same order, same bits.
-// A launch of K2s has a handful of (block, cluster) chains and a thousand
-// idle SIMDs, and what a chain costs is the instruction stream of its ONE
-// wave (selection AND add).  Here a workgroup is one chain on four SIMDs:
+// has a handful of (block, cluster) chains on a chip with a thousand idle
+// SIMDs, so what matters is the latency of ONE chain of M dependent adds.
+// (Rounds 1-2 ran a chain on one wave - k_ll<2>: 144 us, then k_ll_seq with
+// v_readlane'd masks and LDS tables: 34 us; both are gone, the pipeline
+// below takes 9 us.)  A workgroup is one chain on four SIMDs:
 //   waves 1-3 (producers), lane <-> MUTATION m0 + j of the current 64-chunk:
 //     the lane masks {ones, zeros}[m0 + j] and the table pair {L1, L0}[m0 + j]
 //     arrive by coalesced loads (4 chunks ahead); for each of its ~21 cells c
@@ -1129,7 +993,7 @@ __global__ __launch_bounds__(256) void k_ll_seq(
 //   wave 0 (consumer), lane <-> CELL c: reads its row x[c][0..63] two values
 //     per ds_read_b128 (row stride 66 doubles: conflict-free) and performs the
 //     chain's adds, one v_add_f64 per mutation in mutation order.
-// Adding +0.0 where K2s adds nothing is exact (a partial sum is never -0.0:
+// Adding +0.0 where the reference adds nothing is exact (a partial sum is never -0.0:
 // it starts at +0.0 and +0.0 + -0.0 = +0.0).  Two x stages: the producers
 // fill chunk i + 1 while the consumer adds chunk i; one s_barrier per chunk,
 // with an LDS-only wait so that the global prefetch stays in flight.
@@ -2015,7 +1879,8 @@ static int pick_kw(int64_t K)
 // hold at least 16 mutations, a multiple of 8 (stage sizes divide 8).
 static int64_t msplit_limit(const Tunables &tun)
 {
-    return tun.msplit_waves > 0 ? tun.msplit_waves : 8192;
+    (void)tun;
+    return 8192;
 }
 
 static void pick_msplit(const Tunables &tun, int64_t waves, int Mt,
@@ -2024,11 +1889,10 @@ static void pick_msplit(const Tunables &tun, int64_t waves, int Mt,
     *MS = 1;
     *m_chunk = Mt;
     if (!allowed || waves >= msplit_limit(tun)) return;
-    const int64_t target = tun.msplit_waves > 0 ? tun.msplit_waves
-        : (waves >= 512 && waves < 2048 ? 16384 : 8192);
+    const int64_t target = waves >= 512 && waves < 2048 ? 16384 : 8192;
     int64_t want = (target + waves - 1) / waves;
     want = (want + 3) / 4 * 4;
-    const int64_t cap = tun.msplit_max;
+    const int64_t cap = MSPLIT_MAX;
     if (want > cap) want = cap;
     int chunk = (int)((Mt + want - 1) / want);
     chunk = (chunk + 7) / 8 * 8;
@@ -2049,14 +1913,12 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     const int64_t G = (K + KW - 1) / KW;
     const int64_t nwg = ((v.nblk + 3) / 4) * G * MS;
     ARGCHK(nwg < (1ll << 31), "launch too large");
-    const int xcd = c->tun.xcd_remap;
-    const int impl = c->tun.ll_asm;                 // 0 C++, 1 asm, 2 asm x2
+    const int xcd = 1;      // XCD-aware tile order (ll_tile_coords)
     // L2 prefetch of the mask / table streams: when they cannot all sit in
-    // one XCD's 4 MiB L2 (BNPC_LL_PREFETCH: 0 never, 1 always, default auto)
+    // one XCD's 4 MiB L2, and on split launches
     const size_t stream_bytes = (size_t)v.nblk * c->Mpad * 16
         + (size_t)G * c->Mt * 2 * KW * sizeof(double) / 8;
-    const int pf = c->tun.ll_prefetch < 0
-        ? (stream_bytes > (3u << 20) || MS > 1) : c->tun.ll_prefetch;
+    const int pf = stream_bytes > (3u << 20) || MS > 1;
     double *dst = d_out;
     if (MS > 1) {
         if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double))) return 1;
@@ -2079,7 +1941,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        pf ? (const ulonglong2 *)v.masks.p : nullptr,         \
                        pf ? (const double *)c->tabs.p : nullptr)
     const char *combine = "";
-    if (KW == 8 && impl == 2 && wg2 >= c->tun.asm2_min_wgs) {
+    if (KW == 8 && wg2 >= ASM2_MIN_WGS) {
         if (MS > 1) {
             if (MSq == 1) dst = d_out;  // the workgroup already holds the sum
             LAUNCH_ASM(2, true, split2);
@@ -2092,7 +1954,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
             snprintf(c->last_name, sizeof(c->last_name),
                      "k_ll8_asm<2, false>");
         }
-    } else if (KW == 8 && impl >= 1) {
+    } else if (KW == 8) {
         if (MS > 1) {
             if (MSq == 1) dst = d_out;
             LAUNCH_ASM(1, true, split1);
@@ -2144,7 +2006,7 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     constexpr int TMB = 256 / (2 * KW);
     dim3 tgrid_e((unsigned)((c->Mt + TMB - 1) / TMB), (unsigned)G);
     if (from_theta && G * KW * (int64_t)c->Mt
-            <= c->tun.tables_flat_max) {
+            <= TABLES_FLAT_MAX) {
         const int64_t threads = G * KW * (int64_t)c->Mt;
         hipLaunchKernelGGL(k_tables_theta_flat<KW>,
                            dim3((unsigned)((threads + 255) / 256)), dim3(256),
@@ -2169,8 +2031,6 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     return 0;
 }
 
-#define SEQ_LDS_MAX ((size_t)144 << 10)
-
 // K2p on the caller's tables (c->tab_src: L1 [K][M] then L0 [K][M])
 static int issue_seqp(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                       double *d_out)
@@ -2184,7 +2044,7 @@ static int issue_seqp(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     }
     const double *tabs = c->tab_src;
     const size_t n2 = (size_t)K * c->M;         // double2 elements: 2 K M / 2
-    if (c->tun.seq_stage && (const void *)tabs != c->tab_in.p) {
+    if ((const void *)tabs != c->tab_in.p) {
         // staged in the pinned arena: every chain of the launch would pull
         // its table over the host link again - one copy kernel instead
         if (ensure(c->tab_in, 2 * n2 * sizeof(double))) return 1;
@@ -2199,44 +2059,6 @@ static int issue_seqp(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.n, (long long)v.nblk, tabs,
                        tabs + (size_t)K * c->M, (int)K, (long long)ldo, d_out);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// K2s on the caller's tables
-static int issue_seq(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
-                     double *d_out)
-{
-    if (c->tun.seq_kernel == 2 && v.nblk <= 0x7fffffff)
-        return issue_seqp(c, v, K, ldo, d_out);
-    static bool lds_raised = false;
-    if (!lds_raised) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq<1>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)SEQ_LDS_MAX));
-        HIPCHK(hipFuncSetAttribute((const void *)k_ll_seq<2>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)SEQ_LDS_MAX));
-        lds_raised = true;
-    }
-    const size_t one = (size_t)(c->Mpad + 8) * sizeof(double2);
-    // one cluster per wave; BNPC_SEQ_KC=2 puts two on a wave (shared mask
-    // fetch and EXEC writes: measured SLOWER, 44 us against 34 us at 500 x 2
-    // x 1000 - the longer instruction stream of the one wave outweighs the
-    // sharing; kept selectable for the A/B)
-    const int KC = (c->tun.seq_kc == 2 && K >= 2 && 2 * one <= SEQ_LDS_MAX)
-        ? 2 : 1;
-    dim3 grid((unsigned)((v.nblk + 3) / 4), (unsigned)((K + KC - 1) / KC));
-    snprintf(c->last_name, sizeof(c->last_name), "k_ll_seq<%d>", KC);
-#define LAUNCH_SEQ(KC_)                                                       \
-    hipLaunchKernelGGL(k_ll_seq<KC_>, grid, dim3(256), KC_ * one, c->stream,  \
-                       (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,     \
-                       (long long)v.n, (long long)v.nblk, c->tab_src,         \
-                       c->tab_src + (size_t)K * c->M, (int)K, (long long)ldo, \
-                       d_out)
-    if (KC == 2) LAUNCH_SEQ(2);
-    else LAUNCH_SEQ(1);
-#undef LAUNCH_SEQ
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2272,10 +2094,10 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     double *d_out = zc_host ? (double *)zc_dev : (double *)c->out.p;
     if (c->dst_override) d_out = c->dst_override;
     int rc;
-    const size_t seq_lds = (size_t)(c->Mpad + 8) * sizeof(double2);
-    if (!from_theta && c->tun.seq_kernel && !c->tun.force_kw
-        && (c->tun.seq_kernel == 2 || seq_lds <= SEQ_LDS_MAX) && K <= 65535) {
-        rc = issue_seq(c, v, K, ldo, d_out);
+    // caller-built tables: the one-chain-on-four-SIMDs pipeline; a forced
+    // cluster tile (BNPC_KW, tests) takes them through k_ll<KW> instead
+    if (!from_theta && !c->tun.force_kw && K <= 65535) {
+        rc = issue_seqp(c, v, K, ldo, d_out);
         kw = -1;
         MS = 1;
     } else
@@ -2374,23 +2196,14 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
            "not available while an issued tile is in flight");
     const size_t bytes = (size_t)c->views[view].n * ldo * sizeof(double);
     if (bytes && ensure_pin(c, bytes)) return 1;
-    // up to BNPC_ZC_SWEEP_KB the kernels write the matrix straight into the
-    // pinned buffer (no copy-engine launch behind them)
-    void *pin_dev = nullptr;
-    if (bytes && c->tun.zero_copy && (int64_t)bytes <= c->tun.zc_sweep_max
-        && hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
-        c->dst_override = (double *)pin_dev;
     int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
-    const bool in_place = c->dst_override != nullptr;
-    c->dst_override = nullptr;
     if (rc) return rc;
     if (bytes == 0) {
         HIPCHK(hipStreamSynchronize(c->stream));
         return 0;
     }
-    if (!in_place)
-        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
-                              c->stream));
+    HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                          c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *host = (double *)c->pin;
     return 0;
@@ -2449,19 +2262,17 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
         // sweep is going to scan are written through by the hint kernel)
         void *pin_dev = nullptr;
         double *rows_dev = nullptr;
-        if (c->tun.lazy_matrix) {
-            if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
-                rows_dev = (double *)pin_dev;
-            else
-                (void)hipGetLastError();    // not mapped: no write-through
-        }
+        if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
+            rows_dev = (double *)pin_dev;
+        else
+            (void)hipGetLastError();        // not mapped: no write-through
         hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->out.p,
                            (long long)n, (long long)ldo, (int)K, pr,
                            (bnpc_top2 *)zc_dev, rows_dev);
         HIPCHK(hipGetLastError());
     }
-    if (hint && c->tun.lazy_matrix) {
+    if (hint) {
         // the caller gets the hints now; the matrix stays on the device and
         // is copied if and when the sweep first needs a row of it
         // (bnpc_matrix_wait) - a converged sweep never does
@@ -2469,7 +2280,7 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
             HIPCHK(hipEventCreateWithFlags(&c->ev_hints,
                                            hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->ev_hints, c->stream));
-        if (c->matrix_eager && c->tun.eager_matrix) {
+        if (c->matrix_eager) {
             HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes,
                                   hipMemcpyDeviceToHost, c->stream));
             c->pin_copy_queued = true;
@@ -2720,7 +2531,7 @@ extern "C" int bnpc_ll_tables(bnpc_ctx *c, int view, const double *L1,
     const size_t bytes = (size_t)K * c->M * sizeof(double);
     if (arena_reset(c)) return 1;
     c->tab_src = nullptr;
-    if (c->tun.zero_copy && (int64_t)(2 * bytes) <= c->tun.zc_in_max) {
+    if (c->tun.zero_copy && (int64_t)(2 * bytes) <= ZC_IN_MAX) {
         // L1 then L0, contiguous in the arena
         void *slot = stage_slot(c, 2 * bytes);
         if (slot && c->stage_dev) {
@@ -2811,7 +2622,7 @@ static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
     unsigned long long *mem = nullptr;
     const unsigned long long *d_mem = nullptr;
     std::vector<unsigned long long> heap;
-    if (c->tun.zero_copy && (int64_t)mem_bytes <= c->tun.zc_in_max) {
+    if (c->tun.zero_copy && (int64_t)mem_bytes <= ZC_IN_MAX) {
         mem = (unsigned long long *)stage_slot(c, mem_bytes);
         if (mem && c->stage_dev)
             d_mem = (const unsigned long long *)(c->stage_dev
@@ -3136,7 +2947,7 @@ extern "C" int bnpc_mh_screen(bnpc_ctx *c, int counts_src,
 static bool mh_screen_applies(const bnpc_ctx *c, const bnpc_mh_args *a)
 {
     return !(a->trans_prob || !c->tun.mh_screen || a->screen
-             || a->G * a->M < c->tun.mh_screen_min);
+             || a->G * a->M < MH_SCREEN_MIN);
 }
 
 static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
@@ -3150,7 +2961,10 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     }
     if (int rc = mh_screen_argchk(c, a)) return rc;
     HIPCHK(hipSetDevice(c->device));
-    static const bool trace = getenv("BNPC_MH_TRACE") != nullptr;
+    static const bool trace = [] {      // BNPC_TIMING=mh
+        const char *e = getenv("BNPC_TIMING");
+        return e && strstr(e, "mh");
+    }();
     timespec ts0, ts1;
     if (trace) clock_gettime(CLOCK_MONOTONIC, &ts0);
     const int64_t G = a->G, M = a->M;
@@ -3268,7 +3082,7 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
             }
     };
     const bool fused = !a->trans_prob && c->tun.mh_screen
-        && a->G * M >= c->tun.mh_screen_min && !c->any_tile_pending();
+        && a->G * M >= MH_SCREEN_MIN && !c->any_tile_pending();
     if (!fused) {
         if (int rc = bnpc_view_counts(c, view, labels, 2, n1, n0)) return rc;
         finish_rows();
@@ -3471,7 +3285,7 @@ extern "C" int bnpc_bench_ll_full(bnpc_ctx *c, int reps, float *ms_per_call)
         const double FP = c->last_FP, FN = c->last_FN;
         const int MS = c->last_ms, mc = c->last_mchunk;
         if (c->last_kw == -1)
-            rc = issue_seq(c, v, K, ldo, o);
+            rc = issue_seqp(c, v, K, ldo, o);
         else
         switch (c->last_kw) {
         case 8: rc = launch_ll<8>(c, v, K, ldo, ft, FP, FN, o, MS, mc); break;
@@ -3501,7 +3315,7 @@ extern "C" int bnpc_bench_ll(bnpc_ctx *c, int reps, float *ms_per_launch)
         int rc;
         double *o = c->last_out;
         if (c->last_kw == -1)
-            rc = issue_seq(c, v, c->last_K, c->last_ldo, o);
+            rc = issue_seqp(c, v, c->last_K, c->last_ldo, o);
         else
         switch (c->last_kw) {
         case 8: rc = issue_ll<8>(c, v, c->last_K, c->last_ldo, o, c->last_ms, c->last_mchunk); break;

@@ -51,6 +51,7 @@ struct Work {
     std::vector<float> pc_theta, kt;
     std::vector<double> pc_prior, kp, prior_out, dens;
     bool pc_set = false;
+    bool pc_is_rows = false;    // ... and they are w.rows as gathered now
     // batch scratch
     std::vector<int32_t> sd_idx;
     std::vector<double> U, u, A, log_prob, cdf;
@@ -98,6 +99,7 @@ inline int team_for(const bnpc_chain *ch, int64_t elements)
 void gather_rows(const bnpc_chain *ch, Work &w)
 {
     if (w.rows_current) return;
+    w.pc_is_rows = false;
     const int64_t M = ch->M;
     w.rows.resize((size_t)ch->K * M);
     for (int64_t g = 0; g < ch->K; g++)
@@ -574,6 +576,7 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         w.pc_theta.assign(w.rows.begin(), w.rows.begin() + E);
         w.pc_prior.swap(w.prior_out);
         w.pc_set = true;
+        w.pc_is_rows = true;        // until the rows are gathered afresh
     } else if (want_prior) {
         w.pc_set = false;
     }
@@ -659,18 +662,29 @@ int record_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_chain *ch,
     }
     lprior = w.alpha_prior.val + csum;
     if (!ch->uniform_prior) {
-        const float *kt;
-        const double *kp;
-        known_prior(ch, w, &kt, &kp);
-        w.dens.resize((size_t)K * M);
         double seq = 0.0;
-        rc = bnpc_beta_logpdf_f32(k, w.rows.data(), K * M, ch->p, ch->q, kt,
-                                  kp, w.dens.data(), &seq,
-                                  team_for(ch, K * M));
-        if (rc) {
-            double drop;
-            (void)bnpc_ll_total_wait(ctx, &drop);
-            return rc;
+        if (w.pc_set && w.pc_is_rows
+                && w.pc_prior.size() == (size_t)K * M) {
+            // the rows are the ones the parameter batch of this step has just
+            // produced, with their densities: the sum in index order is all
+            // that is left (a compare and a copy per element otherwise: the
+            // largest part of recording a config-5 step)
+            const double *d = w.pc_prior.data();
+            seq = d[0];
+            for (int64_t i = 1; i < K * M; i++) seq += d[i];
+        } else {
+            const float *kt;
+            const double *kp;
+            known_prior(ch, w, &kt, &kp);
+            w.dens.resize((size_t)K * M);
+            rc = bnpc_beta_logpdf_f32(k, w.rows.data(), K * M, ch->p, ch->q,
+                                      kt, kp, w.dens.data(), &seq,
+                                      team_for(ch, K * M));
+            if (rc) {
+                double drop;
+                (void)bnpc_ll_total_wait(ctx, &drop);
+                return rc;
+            }
         }
         lprior += seq;
     }
@@ -769,6 +783,7 @@ extern "C" int bnpc_chain_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     bnpc_legacy_gauss *gauss = (bnpc_legacy_gauss *)ch->gauss;
     // the binding may have changed anything between two calls
     w.rows_current = false;
+    w.pc_is_rows = false;
     ch->need = BNPC_NEED_NONE;
     int rc;
     bool done;

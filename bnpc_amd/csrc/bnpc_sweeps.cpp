@@ -594,11 +594,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     const double *fs = floor_sums(ld + 1);
     const double *dom_bound = dominated_bounds(ld + 1);
     const bool shortcuts = loop_shortcuts();
-    static const int64_t ahead_by = [] {
-        const char *e = getenv("BNPC_SWEEP_PREFETCH");
-        const long v = e ? atol(e) : 16;
-        return (int64_t)(v < 0 ? 0 : (v > 64 ? 64 : v));
-    }();
+    const int64_t ahead_by = 16;    // cells the loop prefetches ahead
     for (int64_t c = 0; c < st->n_cols && c < ld; c++) {
         const int64_t sz = col_size[c];
         cpr[c] = (sz >= 0 && sz <= N + 1) ? crp_prior[sz] : 0.0;
@@ -625,15 +621,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     // twentieth of that.
     static thread_local std::vector<bnpc_top2> hint_local;
     static thread_local const bnpc_top2 *hint_local_of = nullptr;
-    static const bool copy_hints = [] {
-        const char *e = getenv("BNPC_SWEEP_HINT_COPY");
-        return !(e && e[0] == '0');
-    }();
     // (up to 1 MiB of hints, 16 384 cells: at config 5's 3.2 MB the pass
     // itself runs at 2 GB/s and costs more than the misses it saves - Gibbs
     // step 3.6-4.5 against 2.05 ms - while 640 KB at config 4 still gain)
-    if (hint && copy_hints
-        && (size_t)N * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
+    if (hint && (size_t)N * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
         if (st->pos == 0 || hint_local_of != hint
             || (int64_t)hint_local.size() != N) {
             hint_local.resize((size_t)N);

@@ -142,3 +142,29 @@ def table():
     except Exception:
         _cache['table'] = None
     return _cache['table']
+
+
+def probe():
+    """Which of the two private interfaces `table()` rests on can be read in
+    this process (bench.py reports them: a box with another NumPy / SciPy
+    drops to the SciPy-level path silently otherwise): the C entry points of
+    scipy.special.cython_special, the float64 inner loops of NumPy's ufuncs."""
+    out = {'scipy_capi': False, 'ufunc_loops': False}
+    try:
+        import scipy.special.cython_special as cs
+        capi = cs.__pyx_capi__
+        for name, sig in (('__pyx_fuse_1ndtr', _F1),
+                ('__pyx_fuse_1log_ndtr', _F1), ('ndtri_exp', _F1),
+                ('__pyx_fuse_1log1p', _F1), ('__pyx_fuse_1xlogy', _F2),
+                ('__pyx_fuse_1xlog1py', _F2), ('betaln', _F2)):
+            _capsule_pointer(capi, name, sig)
+        out['scipy_capi'] = True
+    except Exception:       # noqa: BLE001
+        pass
+    try:
+        for uf in (np.log, np.exp, np.log1p, np.expm1):
+            _ufunc_loop_dd(uf)
+        out['ufunc_loops'] = True
+    except Exception:       # noqa: BLE001
+        pass
+    return out

@@ -450,6 +450,37 @@ def _native_step_allowed():
     return _STEP['ok']
 
 
+def fast_paths():
+    """The private interfaces and start-up comparisons the fast paths of this
+    process rest on, each True (in use) or False (its documented fallback
+    runs: same chain, slower) - what bench.py prints as `host.fast_paths`:
+
+        rng_live      NumPy's MT19937 state addressed in place
+                      (bit_generator.ctypes.state_address), else copies
+                      through get_state / set_state per native call
+        gauss_live    the stream's cached Gaussian located inside the
+                      RandomState object, else copies likewise
+        scipy_capi    scipy.special.cython_special's C entry points
+        ufunc_loops   NumPy's float64 inner loops of log / exp / log1p / expm1
+        native_mh     the parameter batch natively, bit-compared with the
+                      SciPy-level evaluation (else array expressions)
+        native_beta   NumPy's legacy Beta sampler restated natively
+        native_moves  a split / merge move as one native call
+        native_step   a whole step as one native call
+    """
+    out = {'rng_live': _lib.rng_live() is not None,
+        'gauss_live': _lib.gauss_live() is not None}
+    out.update(hostkernels.probe())
+    out['native_mh'] = _native_kernels() is not None
+    out['native_beta'] = bool(_native_beta())
+    out['native_moves'] = bool(_native_moves_allowed()) \
+        and _lib.env('BNPC_NATIVE_MOVES', '1') != '0'
+    out['native_step'] = out['native_moves'] and out['native_beta'] \
+        and bool(_native_step_allowed()) \
+        and _lib.env('BNPC_NATIVE_STEP', '1') != '0'
+    return out
+
+
 class CRP:
     """DPMM of Bernoulli profiles with fixed error rates (libs/CRP.py:17)."""
 
@@ -803,7 +834,7 @@ class CRP:
         proceeds.  Same decisions, same draws, same trajectory either way.
         """
         N = self.cells_total
-        timing = _lib.env('BNPC_TIMING')
+        timing = _lib.env('BNPC_TIMING') in ('1', '2')
         if timing:
             import time
             t_start = time.perf_counter()
@@ -1130,7 +1161,8 @@ class CRP:
         between, on the same stream."""
         table = _native_kernels()
         if table is None or _lib.env('BNPC_NATIVE_STEP', '1') == '0' \
-                or _lib.env('BNPC_TIMING') or not _native_step_allowed() \
+                or _lib.env('BNPC_TIMING') in ('1', '2') \
+                or not _native_step_allowed() \
                 or not _native_beta() or not _native_moves_allowed() \
                 or _lib.env('BNPC_NATIVE_MOVES', '1') == '0' \
                 or _overrides_a_step_method(self):
@@ -1253,7 +1285,7 @@ class CRP:
             for i in range(3):
                 st.FP_sd[i] = float(self.FP_sd[i])
                 st.FN_sd[i] = float(self.FN_sd[i])
-        st.wide_from = int(_lib.env('BNPC_MH_WIDE_FROM', '65536')) \
+        st.wide_from = _lib.MH_WIDE_FROM \
             if _lib.env('BNPC_HOST_THREADS') is None else 1 << 62
         st.sweep_bytes = int(_lib.env('BNPC_SWEEP_BYTES', 256 << 20))
         st.view_move = VIEW_MOVE

@@ -218,7 +218,7 @@ def get_MPEAR(assignments, dist=None):
             import os
             post = _lib.Posterior(assignments)
             tree = None
-            if os.environ.get('BNPC_WARD_DEVICE', '1') != '0':
+            if os.environ.get('BNPC_WARD_DEVICE', '1') != '0':   # ('plain': no graph)
                 # the linkage on the device too: the distance vector (10 GB at
                 # 50 000 cells) is never brought to the host
                 try:

@@ -96,15 +96,19 @@ def test_ll_tables_is_bit_exact(golden_dir):
         ctx.close()
 
 
-@pytest.mark.parametrize('seq', ['2', '1', '0'])
-def test_ll_tables_bits_on_ragged_shapes_and_views(seq, monkeypatch):
-    """bnpc_ll_tables on every kernel it can run through (2: the producer /
-    consumer pipeline, 1: one wave per chain, 0: the scalar-load tiling) at
-    shapes around the 64-slot and 64-mutation tile edges, whole matrix and
-    gathered views, tables holding -inf (an impossible observation) and +0.0:
-    the strict-order sums of the oracle, bit for bit."""
-    monkeypatch.setenv('BNPC_SEQ_KERNEL', seq)
-    rng = np.random.RandomState(int(seq) + 3)
+@pytest.mark.parametrize('kw', ['', '8', '2'])
+def test_ll_tables_bits_on_ragged_shapes_and_views(kw, monkeypatch):
+    """bnpc_ll_tables on both kernels it can run through (default: the
+    producer / consumer pipeline k_ll_seqp; a forced cluster tile BNPC_KW: the
+    scalar-load tiling k_ll / k_ll8_asm on re-laid-out tables) at shapes
+    around the 64-slot and 64-mutation tile edges, whole matrix and gathered
+    views, tables holding -inf (an impossible observation) and +0.0: the
+    strict-order sums of the oracle, bit for bit."""
+    if kw:
+        monkeypatch.setenv('BNPC_KW', kw)
+    else:
+        monkeypatch.delenv('BNPC_KW', raising=False)
+    rng = np.random.RandomState(len(kw) + int(kw or 0) + 3)
     for N, M, K in ((1, 1, 1), (63, 64, 2), (65, 65, 3), (130, 127, 1),
             (517, 1000, 2), (64, 4097, 2), (200, 129, 5)):
         data = (rng.random_sample((N, M)) < 0.35).astype(float)
@@ -1165,23 +1169,6 @@ def test_screened_batch_on_the_device_equals_the_plain_batch():
         ctx.close()
 
 
-def test_queued_matrix_copy_changes_nothing(monkeypatch):
-    """Hinted sweeps with the matrix copy queued behind the hints as soon as
-    a sweep has needed it (the default) and with the copy always made on
-    demand (BNPC_EAGER_MATRIX=0): the same chain - assignments, traces,
-    parameter rows, stream position."""
-    data = H.synth(6, 1500, 260, 8, 0.2)
-    outs = []
-    for eager in ('1', '0'):
-        monkeypatch.setenv('BNPC_EAGER_MATRIX', eager)
-        res = H.run_chain(H.make(P, 'learn', data), 40, 9, eup=.25)
-        outs.append((res['assignments'].copy(), res['ML'].copy(),
-            res['params'].copy(), np.random.random()))
-    a, b = outs
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    assert np.array_equal(a[2], b[2]) and a[3] == b[3]
-
-
 def test_native_births_change_nothing(monkeypatch):
     """Clusters opened inside the native loop (the default) and through the
     Python branch (BNPC_NATIVE_BIRTHS=0), from a state that opens dozens of
@@ -1373,3 +1360,39 @@ def test_native_step_hands_phases_back_and_resumes(monkeypatch):
                     assert np.array_equal(x, y), (env, i)
                 else:
                     assert x == y, (env, i, x, y)
+
+
+@pytest.mark.parametrize('switch,value', [('BNPC_MH_SCREEN', '0'),
+    ('BNPC_NATIVE_BETA', '0'), ('BNPC_STREAM_LIVE', '0'),
+    ('BNPC_STREAM_LIVE', 'rng'), ('BNPC_ZERO_COPY', '0')])
+def test_fallback_switches_walk_the_same_chain(switch, value, monkeypatch):
+    """The documented fallbacks (README, environment switches) that no other
+    test flips: the parameter batches without the device screen, Beta draws
+    through NumPy, the stream exchanged through get_state / set_state instead
+    of addressed in place (whole or the cached Gaussian only), small payloads
+    through the copy engine - the same chain, bit for bit."""
+    data = H.synth(8, 700, 180, 6, 0.15)
+
+    def fresh():
+        for cache in (P._NATIVE, P._BETA, P._STEP, P._MOVES_OK, _lib._live,
+                _lib._gauss_live):
+            cache.clear()
+    monkeypatch.delenv(switch, raising=False)
+    fresh()
+    base = H.run_chain(H.make(P, 'learn', data), 40, 3, eup=.25)
+    paths = P.fast_paths()
+    assert all(paths.values()), paths
+    monkeypatch.setenv(switch, value)
+    fresh()
+    try:
+        got = H.run_chain(H.make(P, 'learn', data), 40, 3, eup=.25)
+        off = P.fast_paths()
+    finally:
+        monkeypatch.delenv(switch)
+        fresh()
+    if switch == 'BNPC_NATIVE_BETA':
+        assert not off['native_beta'] and not off['native_step']
+    if switch == 'BNPC_STREAM_LIVE':
+        assert not off['gauss_live'] and off['rng_live'] == (value == 'rng')
+    for key in ('assignments', 'ML', 'MAP', 'DP_alpha', 'FN', 'FP', 'params'):
+        assert np.array_equal(base[key], got[key]), key

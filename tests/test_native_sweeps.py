@@ -583,7 +583,7 @@ def test_native_beta_equals_numpy_golden(golden_dir, live, monkeypatch):
     AFTERWARDS (they share the cached Gaussian), the cache itself and the
     stream position must come out as in the capture - through the located
     in-place pointer and through the get_state / set_state fallback."""
-    monkeypatch.setenv('BNPC_GAUSS_LIVE', live)
+    monkeypatch.setenv('BNPC_STREAM_LIVE', '1' if live == '1' else 'rng')
     _lib._gauss_live.clear()
     try:
         assert (_lib.gauss_live() is not None) == (live == '1')

@@ -242,3 +242,22 @@ def test_mpear_cut_choice_follows_the_references_loop():
     # np.arange(2, 0) is empty, the reference's loop does not run
     alone = np.tile(np.arange(6), (5, 1))
     assert postproc.get_MPEAR(alone, dist=np.full(6 * 5 // 2, 0.5)) is None
+
+
+@pytest.mark.gpu
+def test_ward_routes_give_the_same_clustering(monkeypatch):
+    """BNPC_WARD_DEVICE: the linkage on the device as a replayed graph (the
+    default), with plain launches ('plain') and SciPy's own routine on the
+    fetched distances ('0') - the same MPEAR clustering."""
+    from bnpc_amd import postproc
+    rng = np.random.RandomState(4)
+    base = rng.randint(0, 6, 900)
+    a = np.tile(base, (120, 1)).astype(np.int32)
+    flip = rng.random_sample(a.shape) < 0.04
+    a[flip] = rng.randint(0, 6, flip.sum())
+    got = {}
+    for route in ('1', 'plain', '0'):
+        monkeypatch.setenv('BNPC_WARD_DEVICE', route)
+        got[route] = postproc.get_MPEAR(a)
+    assert np.array_equal(got['1'], got['plain'])
+    assert np.array_equal(got['1'], got['0'])

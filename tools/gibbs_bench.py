@@ -61,7 +61,6 @@ for _ in range(reps):
     model.update_assignments_Gibbs()
 total = time.perf_counter() - t0
 print(f'cells decided from the hint: {getattr(model, "_hint_used", 0) / reps:.0f} of {N} per sweep')
-print(f'{cfg} K={len(model.cells_per_cluster)} prefetch='
-    f'{os.environ.get("BNPC_SWEEP_PREFETCH", "default")}: sweep '
+print(f'{cfg} K={len(model.cells_per_cluster)}: sweep '
     f'{1e6 * total / reps:7.1f} us | ' + ' | '.join(
         f'{k} {1e6 * v / reps:7.1f}' for k, v in acc.items()))

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Phase times of the screened parameter batches in a running config-3 chain
-(BNPC_MH_TRACE): draws + staging / device screen / exact host arithmetic."""
+(BNPC_TIMING=mh): draws + staging / device screen / exact host arithmetic."""
 import os
 import sys
-os.environ['BNPC_MH_TRACE'] = '1'
+os.environ['BNPC_TIMING'] = 'mh'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
