@@ -158,7 +158,7 @@ STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
 
 # the version bnpc_abi_version() of a matching library reports (bumped with
 # every change of a structure or signature of include/bnpc_hip.h)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
@@ -203,6 +203,10 @@ SIGNATURES = {
     'bnpc_ll_rows_issue': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, C.c_int]),
     'bnpc_ll_rows_wait': (C.c_int, [_ctx, C.c_int, _ppd]),
+    'bnpc_ll_rows_issue_hint': (C.c_int, [_ctx, C.c_int, _pi64, _i64,
+        C.c_double, C.c_double, _i64, C.c_int, _pd]),
+    'bnpc_ll_rows_wait_hint': (C.c_int, [_ctx, C.c_int, _ppd,
+        C.POINTER(C.c_void_p)]),
     'bnpc_ll_tables': (C.c_int, [_ctx, C.c_int, _pd, _pd, _i64, _pd, _i64]),
     'bnpc_colcounts': (C.c_int, [_ctx, _pi64, _pi64, _i64, _pi32, _pi32]),
     'bnpc_view_counts': (C.c_int, [_ctx, C.c_int, _pi64, _i64, _pi32, _pi32]),
@@ -1075,6 +1079,31 @@ def hints_from_matrix(mat, col_prior):
     return hint
 
 
+def wide_hints_from_matrix(mat, col_prior):
+    """The hint records of a tile (k_row_top2_wide): the largest entry of
+    ll + prior over the first len(col_prior) columns, its column (first one on
+    ties) as 32 bits in col | col2 << 16, the largest entry among the other
+    columns - for the CPU stand-in of the device and the tests."""
+    mat = np.asarray(mat)
+    col_prior = np.asarray(col_prior, dtype=np.float64)
+    K = col_prior.size
+    post = mat[:, :K] + col_prior[None, :]
+    n = post.shape[0]
+    rows = np.arange(n)
+    col = np.argmax(post, axis=1)           # first maximum
+    hint = np.zeros(n, dtype=TOP2)
+    hint['best'] = post[rows, col]
+    rest = post.copy()
+    rest[rows, col] = -np.inf
+    hint['second'] = rest.max(axis=1) if K > 1 else -np.inf
+    hint['third'] = hint['fourth'] = -np.inf
+    hint['col'] = (col & 0xffff).astype(np.uint16).view(np.int16)
+    hint['col2'] = (col >> 16).astype(np.uint16).view(np.int16)
+    hint['col3'] = -1
+    hint['row_here'] = 2
+    return hint
+
+
 def np_sum(a):
     """np.sum of a float64 vector as the library restates it (checker)."""
     a = np.ascontiguousarray(a, dtype=np.float64)
@@ -1440,6 +1469,30 @@ class Context:
         check(self._lib.bnpc_ll_rows_issue(self._h, view,
             ptr(rows, C.c_int64), rows.size, float(FP), float(FN), ld, slot),
             'll_rows_issue')
+
+    def ll_rows_issue_hint(self, view, rows, FP, FN, ld, slot, col_prior):
+        """ll_rows_issue with the tile's hints: col_prior[k] = log prior of
+        column k's cluster now."""
+        rows = as_i64(rows)
+        col_prior = np.ascontiguousarray(col_prior, dtype=np.float64)
+        assert col_prior.size == rows.size
+        check(self._lib.bnpc_ll_rows_issue_hint(self._h, view,
+            ptr(rows, C.c_int64), rows.size, float(FP), float(FN), ld, slot,
+            ptr(col_prior)), 'll_rows_issue_hint')
+
+    def ll_rows_wait_hint(self, slot, n_rows, ld):
+        """(matrix, hints) of the tile issued on `slot` with hints: hints is a
+        TOP2 record array (one per row; the column as 32 bits in col | col2)
+        or None."""
+        host = _host_pd()
+        hint = C.c_void_p()
+        check(self._lib.bnpc_ll_rows_wait_hint(self._h, slot, C.byref(host),
+            C.byref(hint)), 'll_rows_wait_hint')
+        mat = np.ctypeslib.as_array(host, shape=(n_rows, ld))
+        if not hint.value:
+            return mat, None
+        raw = (C.c_char * (n_rows * TOP2.itemsize)).from_address(hint.value)
+        return mat, np.frombuffer(raw, dtype=TOP2, count=n_rows)
 
     def ll_rows_wait(self, slot, n_rows, ld):
         """The (n_rows, ld) result of the tile issued on `slot`."""

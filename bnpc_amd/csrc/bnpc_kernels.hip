@@ -52,7 +52,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 7; }
+extern "C" int bnpc_abi_version(void) { return 8; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -109,6 +109,8 @@ struct Tunables {
 #define ZC_IN_MAX ((int64_t)256 << 10)      // zero-copy inputs / results up to
 #define ZC_OUT_MAX ((int64_t)512 << 10)
 #define MH_SCREEN_MIN 512           // batch entries from which the screen pays
+#define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
+#define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
 
 static int env_int(const char *name, int dflt)
 {
@@ -162,6 +164,12 @@ struct bnpc_ctx {
     // issued tile occupies the main stream - they must not queue behind it
     hipStream_t side_stream = nullptr;
     DevBuf side_theta, side_tabs, side_out, side_part;
+    // the stream of the issued tiles: all compute units but a few, which are
+    // the side lane's own - a 10 ms tile kernel fills every CU it may use
+    // with workgroups that run for milliseconds, and a high priority alone
+    // leaves a small kernel waiting for one of them to end (measured at
+    // config 5: 50 births in the first tile, 0.5 ms each instead of 0.1)
+    hipStream_t tile_stream = nullptr;
     // pinned staging arena for small host <-> device payloads (parameter
     // rows, cell lists, counts): a copy from/to pinned memory is a plain DMA
     // enqueue, a copy from/to pageable memory is staged by the runtime at
@@ -208,6 +216,12 @@ struct bnpc_ctx {
     size_t tile_rows_cap[BNPC_TILE_SLOTS] = {};
     void *tile_cells[BNPC_TILE_SLOTS] = {};     // ... and of the tile's cells
     size_t tile_cells_cap[BNPC_TILE_SLOTS] = {};
+    void *tile_hint[BNPC_TILE_SLOTS] = {};      // pinned: the tile's hints
+    size_t tile_hint_cap[BNPC_TILE_SLOTS] = {};
+    void *tile_prior[BNPC_TILE_SLOTS] = {};     // pinned staging of the priors
+    size_t tile_prior_cap[BNPC_TILE_SLOTS] = {};
+    bool tile_hinted[BNPC_TILE_SLOTS] = {};
+    DevBuf tile_prior_dev[2];                   // by parity, like tile_out
     hipEvent_t tile_done[BNPC_TILE_SLOTS] = {}; // copy landed in tile_pin
     bool tile_pending[BNPC_TILE_SLOTS] = {};
     DevBuf tile_out[2];                         // by parity of the issue count
@@ -484,6 +498,67 @@ struct SideLane {
         std::swap(c->part, c->side_part);
     }
 };
+
+// The calls that issue a tile (its view, its tables and sums) run on the tile
+// stream: swap it in for the duration of the call.
+struct TileLane {
+    bnpc_ctx *c;
+    bool on;
+    explicit TileLane(bnpc_ctx *ctx) : c(ctx), on(ctx->tile_stream != nullptr)
+    {
+        if (on) std::swap(c->stream, c->tile_stream);
+    }
+    ~TileLane()
+    {
+        if (on) std::swap(c->stream, c->tile_stream);
+    }
+};
+
+#define SIDE_LANE_CUS 8
+
+// side lane + tile lane, created at the first tile of a context
+static int ensure_lanes(bnpc_ctx *c)
+{
+    if (c->side_stream) return 0;
+    // calls made while tiles are in flight (a column for a cluster just
+    // opened, the columns of clusters born since a tile was issued) run
+    // beside 10 ms kernels that fill the chip.  They get a stream of the
+    // highest priority AND compute units of their own: the tile stream is
+    // masked off the first SIDE_LANE_CUS units, the side stream owns them.
+    int cus = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    if (cus >= 64 && cus <= 1024) {
+        std::vector<uint32_t> tile_mask((cus + 31) / 32, 0u),
+            side_mask((cus + 31) / 32, 0u);
+        for (int cu = 0; cu < cus; cu++)
+            (cu < SIDE_LANE_CUS ? side_mask : tile_mask)[cu >> 5]
+                |= 1u << (cu & 31);
+        hipStream_t tile = nullptr, side = nullptr;
+        if (hipExtStreamCreateWithCUMask(&tile, (uint32_t)tile_mask.size(),
+                                         tile_mask.data()) == hipSuccess
+            && hipExtStreamCreateWithCUMask(&side, (uint32_t)side_mask.size(),
+                                            side_mask.data()) == hipSuccess) {
+            c->tile_stream = tile;
+            c->side_stream = side;
+            return 0;
+        }
+        (void)hipGetLastError();
+        if (tile) (void)hipStreamDestroy(tile);
+        if (side) (void)hipStreamDestroy(side);
+    }
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess
+        || hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking,
+                                       greatest) != hipSuccess) {
+        (void)hipGetLastError();        // no priorities here: a plain stream
+        c->side_stream = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&c->side_stream,
+                                        hipStreamNonBlocking));
+    }
+    return 0;
+}
 
 // ---------------------------------------------------------------------------
 // K1: gather rows of a cell list and transpose 64x64 bit tiles into lane masks
@@ -793,6 +868,170 @@ __device__ __forceinline__ void ll_step8(double (&a)[8],
           "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]), "s"(t[8]), "s"(t[9]),
           "s"(t[10]), "s"(t[11]), "s"(t[12]), "s"(t[13]), "s"(t[14]),
           "s"(t[15]));
+}
+
+// One mutation for 8 clusters, the table values in VGPRs (every lane holds
+// the same 16 doubles: broadcast LDS reads) - the step of k_ll8_lds.
+__device__ __forceinline__ void ll_step8v(double (&a)[8],
+                                          const ulonglong2 &m,
+                                          const double (&t)[16])
+{
+    asm volatile(
+        "s_mov_b64 exec, %8\n\t"
+        "v_add_f64 %0, %0, %10\n\t"
+        "v_add_f64 %1, %1, %11\n\t"
+        "v_add_f64 %2, %2, %12\n\t"
+        "v_add_f64 %3, %3, %13\n\t"
+        "v_add_f64 %4, %4, %14\n\t"
+        "v_add_f64 %5, %5, %15\n\t"
+        "v_add_f64 %6, %6, %16\n\t"
+        "v_add_f64 %7, %7, %17\n\t"
+        "s_mov_b64 exec, %9\n\t"
+        "v_add_f64 %0, %0, %18\n\t"
+        "v_add_f64 %1, %1, %19\n\t"
+        "v_add_f64 %2, %2, %20\n\t"
+        "v_add_f64 %3, %3, %21\n\t"
+        "v_add_f64 %4, %4, %22\n\t"
+        "v_add_f64 %5, %5, %23\n\t"
+        "v_add_f64 %6, %6, %24\n\t"
+        "v_add_f64 %7, %7, %25\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]),
+          "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "s"(m.x), "s"(m.y), "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]),
+          "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]), "v"(t[9]),
+          "v"(t[10]), "v"(t[11]), "v"(t[12]), "v"(t[13]), "v"(t[14]),
+          "v"(t[15]));
+}
+
+// The whole-row form of the 8-cluster kernel for LONG mutation streams
+// (M in the thousands: first-sweep tiles of configs 4 and 5, config 5's
+// sweeps).  k_ll8_asm streams a cluster group's table through the scalar
+// cache; with 640 KB of table per group (M = 5000) and ~28 groups in flight
+// per XCD the streams no longer sit in the XCD's 4 MiB L2, a fifth of the
+// scalar loads go to memory (L2 hits 81 %, SQ_WAIT_ANY 37 %) and the rate
+// falls from 93 % of the two-add issue peak at M = 1000 to 68 % at M = 5000
+// (tools/tile_shape_bench.py).  Here the table reaches the waves through LDS:
+// the 4 waves of a workgroup (4 x CB slot blocks of ONE cluster group) fetch
+// the table of the next-but-one 64 mutations together - 8 KiB, two coalesced
+// 16-byte loads per thread, a whole chunk (~8000 cycles) ahead of its use, so
+// it does not matter where the bytes come from - write it to one of two LDS
+// buffers, and every wave reads a mutation's 16 doubles with broadcast
+// ds_read_b128s into VGPRs (two ping-pong stages).  The lane masks stay on
+// the scalar path (1.3 MB per tile, shared by every workgroup: L2-resident).
+// One s_barrier per 64 mutations.  Same sums, same order, same bits.
+template <int CB>
+__global__ __launch_bounds__(256) void k_ll8_lds(
+    const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
+    long long nblk, const double *__restrict__ T, int K, long long ldo,
+    double *__restrict__ out, int xcd_remap)
+{
+    constexpr int KW = 8;
+    __shared__ double2 tab[2][64 * 8];      // [buffer][mutation][8 x double2]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
+    long long bx, g;
+    ll_tile_coords((unsigned)((nblk + 4 * CB - 1) / (4 * CB)),
+                   (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
+    const long long blk0 = (bx * 4 + wave) * CB;
+    // (a wave without blocks still takes part in the staging and barriers)
+    const bool has_blocks = blk0 < nblk;
+    size_t mo[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+        mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : (has_blocks ? blk0 : 0))
+            * Mpad;
+    const double2 *__restrict__ tg =
+        (const double2 *)(T + (size_t)g * Mt * (2 * KW));
+    const int n_chunks = (Mt + 63) >> 6;
+    const long long t_elems = (long long)Mt * 8;    // double2 of this group
+
+    double acc[CB][KW];
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+#pragma unroll
+        for (int j = 0; j < KW; j++) acc[c][j] = 0.0;
+
+    const double2 zero2 = {0.0, 0.0};
+    // chunk 0 straight into buffer 0, chunk 1 into registers
+    double2 r0, r1;
+    {
+        const long long e0 = tid, e1 = tid + 256;
+        tab[0][tid] = e0 < t_elems ? tg[e0] : zero2;
+        tab[0][tid + 256] = e1 < t_elems ? tg[e1] : zero2;
+        const long long f0 = 512 + tid, f1 = 512 + tid + 256;
+        r0 = f0 < t_elems ? tg[f0] : zero2;
+        r1 = f1 < t_elems ? tg[f1] : zero2;
+    }
+    __syncthreads();
+    for (int ch = 0; ch < n_chunks; ch++) {
+        const int cur = ch & 1;
+        // the next chunk's table (fetched a chunk ago) goes to the other
+        // buffer - free since the barrier that ended the previous chunk -,
+        // the one after it is requested now
+        if (ch + 1 < n_chunks) {
+            tab[cur ^ 1][tid] = r0;
+            tab[cur ^ 1][tid + 256] = r1;
+        }
+        if (ch + 2 < n_chunks) {
+            const long long f0 = (long long)(ch + 2) * 512 + tid,
+                f1 = f0 + 256;
+            r0 = f0 < t_elems ? tg[f0] : zero2;
+            r1 = f1 < t_elems ? tg[f1] : zero2;
+        }
+        const int m0 = ch << 6;
+        const int m_len = (Mt - m0 < 64) ? Mt - m0 : 64;    // multiple of 8
+        const double2 *__restrict__ tb = tab[cur];
+        ulonglong2 ma[CB], mb[CB];
+        double ta[16], tbv[16];
+#pragma unroll
+        for (int c = 0; c < CB; c++) ma[c] = masks[mo[c] + m0];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const double2 v = tb[j];
+            ta[2 * j] = v.x;
+            ta[2 * j + 1] = v.y;
+        }
+        for (int m = 0; m < m_len; m += 2) {
+            // stage B <- mutation m + 1 (loads issued before A's adds)
+#pragma unroll
+            for (int c = 0; c < CB; c++) mb[c] = masks[mo[c] + m0 + m + 1];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double2 v = tb[(m + 1) * 8 + j];
+                tbv[2 * j] = v.x;
+                tbv[2 * j + 1] = v.y;
+            }
+#pragma unroll
+            for (int c = 0; c < CB; c++) ll_step8v(acc[c], ma[c], ta);
+            // stage A <- mutation m + 2 (the row past the chunk's end is the
+            // next buffer's first row or padding: loaded, never added)
+            const int m2 = m + 2 < 64 ? m + 2 : 63;
+#pragma unroll
+            for (int c = 0; c < CB; c++) ma[c] = masks[mo[c] + m0 + m2];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double2 v = tb[m2 * 8 + j];
+                ta[2 * j] = v.x;
+                ta[2 * j + 1] = v.y;
+            }
+#pragma unroll
+            for (int c = 0; c < CB; c++) ll_step8v(acc[c], mb[c], tbv);
+        }
+        __syncthreads();
+    }
+    if (!has_blocks) return;
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+        const long long slot = (blk0 + c) * 64 + lane;
+        if (blk0 + c < nblk && slot < n) {
+            double *o = out + (size_t)slot * ldo + (size_t)g * KW;
+#pragma unroll
+            for (int j = 0; j < KW; j++)
+                if (g * KW + j < K) o[j] = acc[c][j];
+        }
+    }
 }
 
 // 8 clusters x CB slot blocks per wave, two ping-pong stages of one mutation
@@ -1221,6 +1460,71 @@ __global__ __launch_bounds__(256) void k_row_top2(
 // thread <-> mutation; block <-> (chunk of <= 32 cells of one segment, 256
 // mutations); a row word is shared by the 64 lanes of a wave (broadcast load).
 // ---------------------------------------------------------------------------
+// The hint of a first-sweep TILE (thousands of columns): per row the largest
+// entry of ll + prior, its column (first one on ties) and the largest entry
+// among all other columns - enough for the sweep's dominance test.  One
+// workgroup per row; priors from device memory.  The record is bnpc_top2 with
+// the column as 32 bits in (col | col2 << 16), col3 = -1, row_here = 2.
+__global__ __launch_bounds__(256) void k_row_top2_wide(
+    const double *__restrict__ ll, long long ldo, int K,
+    const double *__restrict__ prior, bnpc_top2 *__restrict__ out)
+{
+    __shared__ double s_b[4], s_s[4];
+    __shared__ int s_c[4];
+    const long long slot = blockIdx.x;
+    const double *__restrict__ r = ll + (size_t)slot * ldo;
+    double best = -INFINITY, second = -INFINITY;
+    int col = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const double v = r[k] + prior[k];
+        if (v > best) {                 // (ascending k: the first maximum)
+            second = best;
+            best = v;
+            col = k;
+        } else if (v > second) {
+            second = v;
+        }
+    }
+    auto merge = [&](double ob, int oc, double os) {
+        if (ob > best || (ob == best && oc < col)) {
+            second = os > best ? os : best;
+            best = ob;
+            col = oc;
+        } else {
+            const double m = ob > os ? ob : os;
+            if (m > second) second = m;
+        }
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off), os = __shfl_down(second, off);
+        const int oc = __shfl_down(col, off);
+        merge(ob, oc, os);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_b[wave] = best;
+        s_s[wave] = second;
+        s_c[wave] = col;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) merge(s_b[w], s_c[w], s_s[w]);
+        bnpc_top2 t;
+        t.best = best;
+        t.second = second;
+        t.third = -INFINITY;
+        t.fourth = -INFINITY;
+        t.ll_best = t.ll_second = t.ll_third = 0.0;
+        const unsigned c32 = (unsigned)(col == 0x7fffffff ? 0 : col);
+        t.col = (int16_t)(uint16_t)(c32 & 0xffffu);
+        t.col2 = (int16_t)(uint16_t)(c32 >> 16);
+        t.col3 = -1;
+        t.row_here = 2;
+        out[slot] = t;
+    }
+}
+
 struct Chunk {
     long long begin, end;   // range in the cells[] list
     long long seg;
@@ -1693,9 +1997,11 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    if (c->tile_stream) (void)hipStreamSynchronize(c->tile_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
                       &c->tile_out[0], &c->tile_out[1],
+                      &c->tile_prior_dev[0], &c->tile_prior_dev[1],
                       &c->chunks, &c->cnt, &c->partial, &c->part,
                       &c->lab_cnt, &c->theta_store, &c->row_idx,
                       &c->side_theta, &c->side_tabs, &c->side_out,
@@ -1717,6 +2023,8 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
         pinned_free(c->tile_pin[s], c->tile_cap[s]);
         pinned_free(c->tile_rows[s], c->tile_rows_cap[s]);
         pinned_free(c->tile_cells[s], c->tile_cells_cap[s]);
+        pinned_free(c->tile_hint[s], c->tile_hint_cap[s]);
+        pinned_free(c->tile_prior[s], c->tile_prior_cap[s]);
         if (c->tile_done[s]) (void)hipEventDestroy(c->tile_done[s]);
     }
     for (int s = 0; s < 2; s++) {
@@ -1729,6 +2037,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->tile_stream) (void)hipStreamDestroy(c->tile_stream);
     delete c;
     return 0;
 }
@@ -1822,6 +2131,8 @@ extern "C" int bnpc_view_set_slot(bnpc_ctx *c, int view, const int64_t *cells,
     for (int64_t i = 0; i < n; i++)
         ARGCHK(cells[i] >= 0 && cells[i] < c->N, "cell index out of range");
     HIPCHK(hipSetDevice(c->device));
+    if (ensure_lanes(c)) return 1;
+    TileLane tile_lane(c);
     if (ensure_host(&c->tile_cells[slot], &c->tile_cells_cap[slot],
                     n * sizeof(long long)))
         return 1;
@@ -1920,8 +2231,12 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         + (size_t)G * c->Mt * 2 * KW * sizeof(double) / 8;
     const int pf = stream_bytes > (3u << 20) || MS > 1;
     double *dst = d_out;
-    if (MS > 1) {
-        if (ensure(c->part, (size_t)MS * v.n * K * sizeof(double))) return 1;
+    // partial planes: the hand-placed kernel sums 4 chunks inside a
+    // workgroup (ceil(MS / 4) planes, none for exactly 4), k_ll writes MS
+    const int need_planes = MS > 1 ? (KW == 8 ? (MS + 3) / 4 : MS) : 1;
+    if (need_planes > 1) {
+        if (ensure(c->part, (size_t)need_planes * v.n * K * sizeof(double)))
+            return 1;
         dst = (double *)c->part.p;
     }
     const int64_t wg2 = ((v.nblk + 7) / 8) * G * MS;
@@ -1949,6 +2264,20 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
             combine = MSq > 1 ? " + k_ll_combine" : "";
             snprintf(c->last_name, sizeof(c->last_name),
                      "k_ll8_asm<2, true>%s", combine);
+        } else if (c->Mt >= LDS_TABLE_MIN_M && wg2 >= LDS_TABLE_MIN_WGS) {
+            // long mutation streams, enough workgroups to keep every CU's
+            // LDS pipeline full: the table through LDS (measured, % of the
+            // two-add issue peak, scalar path -> LDS path: 1024 x 5000 x
+            // 31608 68 -> 80, 50000 x 5000 x 512 73 -> 78; but 1024 x 2000
+            // x 31608 76 -> 78 at 1024 rows and 89 -> 81 at 2048+, x 1000
+            // 93 -> 81, and 50000 x 5000 x 100 with its 1300 workgroups
+            // 57 -> 48: tools/tile_shape_bench.py, profiles/r04)
+            hipLaunchKernelGGL((k_ll8_lds<2>), dim3((unsigned)wg2), dim3(256),
+                               0, c->stream, (const ulonglong2 *)v.masks.p,
+                               c->Mpad, c->Mt, (long long)v.n,
+                               (long long)v.nblk, (const double *)c->tabs.p,
+                               (int)K, (long long)ldo, dst, xcd);
+            snprintf(c->last_name, sizeof(c->last_name), "k_ll8_lds<2>");
         } else {
             LAUNCH_ASM(2, false, wg2);
             snprintf(c->last_name, sizeof(c->last_name),
@@ -2423,9 +2752,9 @@ extern "C" int bnpc_ll_rows_pinned(bnpc_ctx *c, int view, const int64_t *rows,
 // on the context's stream and write the device buffer of this issue's parity;
 // the copy into the slot's own pinned buffer follows on the copy stream, so
 // that it runs under the sums of the next tile; an event marks its completion.
-extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
-                                  int64_t K, double FP, double FN, int64_t ldo,
-                                  int slot)
+static int ll_rows_issue_impl(bnpc_ctx *c, int view, const int64_t *rows,
+                              int64_t K, double FP, double FN, int64_t ldo,
+                              int slot, const double *col_prior)
 {
     ARGCHK(c && rows, "NULL argument");
     ARGCHK(slot >= 0 && slot < BNPC_TILE_SLOTS, "slot out of range");
@@ -2454,22 +2783,8 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
         // nothing has read this buffer yet
         HIPCHK(hipEventRecord(c->tile_out_free[par], c->stream));
     }
-    if (!c->side_stream) {
-        // calls made while tiles are in flight (a column for a cluster just
-        // opened, the columns of clusters born since a tile was issued) run
-        // beside 11 ms kernels that fill the chip: on a stream of the highest
-        // priority their few workgroups get the next free slots instead of
-        // waiting for a whole tile
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess
-            || hipStreamCreateWithPriority(&c->side_stream,
-                   hipStreamNonBlocking, greatest) != hipSuccess) {
-            (void)hipGetLastError();    // no priorities here: a plain stream
-            c->side_stream = nullptr;
-            HIPCHK(hipStreamCreateWithFlags(&c->side_stream,
-                                            hipStreamNonBlocking));
-        }
-    }
+    if (ensure_lanes(c)) return 1;
+    TileLane tile_lane(c);
     if (!c->copy_stream)
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream,
                                         hipStreamNonBlocking));
@@ -2494,6 +2809,33 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
     c->dst_override = nullptr;
     c->use_rows = nullptr;
     if (rc) return rc;
+    c->tile_hinted[slot] = false;
+    if (col_prior) {
+        // the tile's hints: one record per row, written in place into pinned
+        // memory by a kernel behind the sums (the priors at issue time travel
+        // through a pinned staging copy)
+        const size_t rows_n = (size_t)c->views[view].n;
+        if (ensure_host(&c->tile_hint[slot], &c->tile_hint_cap[slot],
+                        rows_n * sizeof(bnpc_top2)))
+            return 1;
+        if (ensure_host(&c->tile_prior[slot], &c->tile_prior_cap[slot],
+                        K * sizeof(double)))
+            return 1;
+        memcpy(c->tile_prior[slot], col_prior, K * sizeof(double));
+        if (ensure(c->tile_prior_dev[par], K * sizeof(double))) return 1;
+        HIPCHK(hipMemcpyAsync(c->tile_prior_dev[par].p, c->tile_prior[slot],
+                              K * sizeof(double), hipMemcpyHostToDevice,
+                              c->stream));
+        void *hint_dev = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&hint_dev, c->tile_hint[slot], 0));
+        hipLaunchKernelGGL(k_row_top2_wide, dim3((unsigned)rows_n), dim3(256),
+                           0, c->stream, (const double *)c->tile_out[par].p,
+                           (long long)ldo, (int)K,
+                           (const double *)c->tile_prior_dev[par].p,
+                           (bnpc_top2 *)hint_dev);
+        HIPCHK(hipGetLastError());
+        c->tile_hinted[slot] = true;
+    }
     HIPCHK(hipEventRecord(c->tile_summed[par], c->stream));
     HIPCHK(hipStreamWaitEvent(c->copy_stream, c->tile_summed[par], 0));
     HIPCHK(hipMemcpyAsync(c->tile_pin[slot], c->tile_out[par].p, bytes,
@@ -2503,6 +2845,34 @@ extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
     c->tile_bytes[slot] = bytes;
     c->tile_pending[slot] = true;
     c->tile_seq++;
+    return 0;
+}
+
+extern "C" int bnpc_ll_rows_issue(bnpc_ctx *c, int view, const int64_t *rows,
+                                  int64_t K, double FP, double FN, int64_t ldo,
+                                  int slot)
+{
+    return ll_rows_issue_impl(c, view, rows, K, FP, FN, ldo, slot, nullptr);
+}
+
+extern "C" int bnpc_ll_rows_issue_hint(bnpc_ctx *c, int view,
+                                       const int64_t *rows, int64_t K,
+                                       double FP, double FN, int64_t ldo,
+                                       int slot, const double *col_prior)
+{
+    ARGCHK(col_prior, "col_prior is NULL");
+    return ll_rows_issue_impl(c, view, rows, K, FP, FN, ldo, slot, col_prior);
+}
+
+extern "C" int bnpc_ll_rows_wait_hint(bnpc_ctx *c, int slot, double **host,
+                                      bnpc_top2 **hint)
+{
+    ARGCHK(hint, "NULL argument");
+    *hint = nullptr;
+    const bool hinted = c && slot >= 0 && slot < BNPC_TILE_SLOTS
+        && c->tile_hinted[slot];
+    if (int rc = bnpc_ll_rows_wait(c, slot, host)) return rc;
+    if (hinted) *hint = (bnpc_top2 *)c->tile_hint[slot];
     return 0;
 }
 

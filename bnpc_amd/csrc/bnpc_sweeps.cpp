@@ -600,47 +600,74 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         cpr[c] = (sz >= 0 && sz <= N + 1) ? crp_prior[sz] : 0.0;
     }
 
-    // The hint (include/bnpc_hip.h: bnpc_top2): the two largest entries of
-    // every row under the priors at launch.  `drift` bounds how far any
-    // column's prior has moved since; with it the hint decides a cell without
-    // scanning it when best - drift beats everything else + drift (and the
-    // new-cluster entry, and the columns born since, which are looked at) by
-    // more than the dominance margin.  Whole-matrix sweeps with few clusters.
-    const bnpc_top2 *hint = (st->row_base < 0 && st->hint && st->hint_prior
-                             && st->hint_cols > 0 && st->hint_cols <= 64
+    // The hint (include/bnpc_hip.h: bnpc_top2): the largest entries of every
+    // row under the priors at launch.  `drift` bounds how far any column's
+    // prior has moved since; with it the hint decides a cell without scanning
+    // it when best - drift beats everything else + drift (and the new-cluster
+    // entry, and the columns born since, which are looked at) by more than
+    // the dominance margin.  Two kinds: NARROW hints (<= 64 columns, a
+    // whole-matrix sweep of a converged chain: rows indexed by cell, the pair
+    // / triple tests apply) and WIDE hints (any number of columns, the tiles
+    // of a first sweep: rows indexed by tile position, the column of the
+    // largest entry as a 32-bit number, the dominance test only - from the
+    // moment the true clusters have been born nearly every cell is dominated
+    // by one of them and the 30 000 random ones need not be walked).
+    const bool tile_rows = st->row_base >= 0;
+    const bnpc_top2 *hint = (st->hint && st->hint_prior && st->hint_cols > 0
+                             && (tile_rows || st->hint_cols <= 64)
                              && st->hint_cols <= st->n_cols && FLOOR_STEP > 0)
         ? st->hint : nullptr;
     const int64_t hint_cols = hint ? st->hint_cols : 0;
+    const bool narrow = hint && !tile_rows;
+    const int64_t hint_rows = !hint ? 0
+        : (tile_rows ? st->pos_end - st->row_base : N);
     // The hints sit in pinned memory the device has just written: every line
     // of them is a miss all the way to DRAM, and the loop visits them in
     // permutation order - one exposed miss per cell, which software prefetch
     // hides only in part (measured: 140-230 cycles per decided cell, best at
     // a prefetch distance of 4, against ~40 from a private copy).  One
-    // sequential pass at the start of the sweep (the hardware prefetcher
-    // streams it: 240 KB in 7 us) into a block that stays in L2 costs a
-    // twentieth of that.
+    // sequential pass at the start of the sweep / tile (the hardware
+    // prefetcher streams it: 240 KB in 7 us) into a block that stays in L2
+    // costs a twentieth of that.
     static thread_local std::vector<bnpc_top2> hint_local;
     static thread_local const bnpc_top2 *hint_local_of = nullptr;
     // (up to 1 MiB of hints, 16 384 cells: at config 5's 3.2 MB the pass
     // itself runs at 2 GB/s and costs more than the misses it saves - Gibbs
     // step 3.6-4.5 against 2.05 ms - while 640 KB at config 4 still gain)
-    if (hint && (size_t)N * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
-        if (st->pos == 0 || hint_local_of != hint
-            || (int64_t)hint_local.size() != N) {
-            hint_local.resize((size_t)N);
-            memcpy(hint_local.data(), hint, (size_t)N * sizeof(bnpc_top2));
+    if (hint && (size_t)hint_rows * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
+        // (a sweep resumed after a birth in the caller finds its copy; the
+        // pinned buffers of tiles are re-used, so a tile copies at its start)
+        const int64_t start = tile_rows ? st->row_base : 0;
+        if (st->pos == start || hint_local_of != hint
+            || (int64_t)hint_local.size() != hint_rows) {
+            hint_local.resize((size_t)hint_rows);
+            memcpy(hint_local.data(), hint,
+                   (size_t)hint_rows * sizeof(bnpc_top2));
             hint_local_of = hint;
         }
-        // (a sweep resumed after a birth in the caller finds its copy)
         hint = hint_local.data();
     }
     const double *cpr0 = st->hint_prior;
     double drift = 0.0;
     int64_t pos_of_col[64];
     auto index_live = [&]() {
+        if (!narrow) return;
         for (int64_t c = 0; c < hint_cols; c++) pos_of_col[c] = -1;
         for (int64_t a = 0; a < st->n_active; a++)
             if (order[a] < hint_cols) pos_of_col[order[a]] = a;
+    };
+    // position of a live column in the live list, or -1: a table for narrow
+    // hints, a bisection for wide ones (the list is ascending in column
+    // index; verified by the comparison at the end)
+    auto pos_of = [&](int64_t c) -> int64_t {
+        if (narrow) return pos_of_col[c];
+        int64_t a = 0, b = st->n_active;
+        while (a < b) {
+            const int64_t mid = (a + b) >> 1;
+            if (order[mid] < c) a = mid + 1;
+            else b = mid;
+        }
+        return (a < st->n_active && order[a] == c) ? a : -1;
     };
     if (hint) {
         for (int64_t c = 0; c < hint_cols; c++)
@@ -681,7 +708,8 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                                       : ahead) * ld);
                 if (hint) {
                     // the row itself is only read if the hint is in doubt
-                    __builtin_prefetch(&hint[ahead], 0, 1);
+                    __builtin_prefetch(&hint[tile_rows
+                        ? st->pos + ahead_by - st->row_base : ahead], 0, 1);
                 } else {
                     const size_t bytes = (size_t)st->n_cols * sizeof(double);
                     const char *end = r + (bytes < 512 ? bytes : 512);
@@ -742,21 +770,47 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         double best = -INFINITY;
         double second = -INFINITY;          // largest entry that is not `top`
         bool hinted = false;
-        if (hint && A <= 64) {
-            const bnpc_top2 &h = hint[cell];
-            const int64_t hc = h.col;
-            if (hc >= 0 && hc < hint_cols && col_size[hc] > 0
-                && pos_of_col[hc] >= 0) {
-                double other = h.second + drift;
-                const double pn = post_new[cell];
-                if (pn > other) other = pn;
-                for (int64_t a = A - 1; a >= 0 && order[a] >= hint_cols; a--) {
-                    NEED_MATRIX()
-                    const double v = row[order[a]] + cpr[order[a]];
-                    if (v > other) other = v;
+        const int64_t hrow = tile_rows ? st->pos - st->row_base : cell;
+        if (hint && (narrow ? A <= 64 : true)) {
+            const bnpc_top2 &h = hint[hrow];
+            // (a wide record carries its column as 32 bits in col | col2)
+            const int64_t hc = narrow ? (int64_t)h.col
+                : (int64_t)((uint32_t)(uint16_t)h.col
+                            | ((uint32_t)(uint16_t)h.col2 << 16));
+            const double pn = post_new[cell];
+            // the columns born since the launch: looked at one by one
+            double late1 = -INFINITY, late2 = -INFINITY;
+            int64_t late_at = -1;
+            for (int64_t a = A - 1; a >= 0 && order[a] >= hint_cols; a--) {
+                NEED_MATRIX()
+                const double v = row[order[a]] + cpr[order[a]];
+                if (v >= late1) {       // (>=: the first in list order wins)
+                    late2 = late1;
+                    late1 = v;
+                    late_at = a;
+                } else if (v > late2) {
+                    late2 = v;
                 }
-                if (other - (h.best - drift) < dom_bound[A]) {
-                    top = pos_of_col[hc];
+            }
+            if (hc >= 0 && hc < hint_cols && col_size[hc] > 0) {
+                const int64_t at = pos_of(hc);
+                double other = h.second + drift;
+                if (pn > other) other = pn;
+                if (late1 > other) other = late1;
+                if (at >= 0 && other - (h.best - drift) < dom_bound[A]) {
+                    top = at;
+                    hinted = true;
+                    st->hint_used++;
+                }
+            }
+            if (!hinted && late_at >= 0) {
+                // ... or one of the columns born since dominates everything
+                // the launch knew (its largest entry, widened by the drift)
+                double other = h.best + drift;
+                if (pn > other) other = pn;
+                if (late2 > other) other = late2;
+                if (other - late1 < dom_bound[A]) {
+                    top = late_at;
                     hinted = true;
                     st->hint_used++;
                 }
@@ -774,7 +828,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // decides it, without reading its row.
         bool pair = false;
         int64_t pair_second = 0;
-        if (hint && !hinted && A <= 64 && shortcuts) {
+        if (narrow && !hinted && A <= 64 && shortcuts) {
             const bnpc_top2 &h = hint[cell];
             const int64_t c1 = h.col, c2 = h.col2;
             if (c1 >= 0 && c1 < hint_cols && c2 >= 0 && c2 < hint_cols
@@ -816,7 +870,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         bool triple = false, have_u = false;
         int64_t triple_pick = 0;
         double u_saved = 0.0;
-        if (hint && !hinted && !pair && A <= 64 && A >= 2 && shortcuts) {
+        if (narrow && !hinted && !pair && A <= 64 && A >= 2 && shortcuts) {
             const bnpc_top2 &h = hint[cell];
             const int64_t c[3] = {h.col, h.col2, h.col3};
             bool ok = c[0] != c[1] && c[0] != c[2] && c[1] != c[2];
@@ -863,7 +917,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // - which the hint kernel has written through for the rows it
             // could tell would be scanned - and columns born since, which
             // were written here after the matrix had arrived
-            if (!(hint && hint[cell].row_here == 1
+            if (!(narrow && hint[cell].row_here == 1
                   && (A == 0 || order[A - 1] < hint_cols)))
                 NEED_MATRIX()
         }

@@ -892,6 +892,8 @@ class CRP:
             ahead_max = max(1, min(_lib.TILE_SLOTS - 1,
                 int(_lib.env('BNPC_TILES_AHEAD', 2))))
             born_log = []       # ids born during this sweep, in order
+            tile_hints = _lib.env('BNPC_SWEEP_HINT', '1') != '0' \
+                and hasattr(ctx, 'll_rows_issue_hint')
 
             def issue(start, number):
                 rows = max(64, tile_bytes // (8 * (ids.size + _TILE_SPARE)))
@@ -905,8 +907,17 @@ class CRP:
                     number=number, view=VIEW_SWEEP + slot, cols=ids.copy(),
                     ld=ids.size + _TILE_SPARE, born_mark=len(born_log))
                 ctx.view_set_slot(tile['view'], perm[start:tile['end']], slot)
-                ctx.ll_rows_issue(tile['view'], tile['cols'], self.FP,
-                    self.FN, tile['ld'], slot)
+                if tile_hints:
+                    # with the priors of the clusters as they are now: the
+                    # device also says, per cell, which column is largest and
+                    # by how much - once the true clusters exist the loop
+                    # decides nearly every cell from that one record
+                    tile['prior'] = np.ascontiguousarray(crp_prior[sizes])
+                    ctx.ll_rows_issue_hint(tile['view'], tile['cols'],
+                        self.FP, self.FN, tile['ld'], slot, tile['prior'])
+                else:
+                    ctx.ll_rows_issue(tile['view'], tile['cols'], self.FP,
+                        self.FN, tile['ld'], slot)
                 return tile
 
             opened, tiles = 0, 0
@@ -932,8 +943,15 @@ class CRP:
                     tile = in_flight.pop(0)
                     if timing:
                         t_0 = time.perf_counter()
-                    ll = ctx.ll_rows_wait(tile['slot'],
-                        tile['end'] - tile['pos'], tile['ld'])
+                    tile_hint = None
+                    if 'prior' in tile:
+                        ll, records = ctx.ll_rows_wait_hint(tile['slot'],
+                            tile['end'] - tile['pos'], tile['ld'])
+                        if records is not None:
+                            tile_hint = (records, tile['prior'])
+                    else:
+                        ll = ctx.ll_rows_wait(tile['slot'],
+                            tile['end'] - tile['pos'], tile['ld'])
                     if timing:
                         spent['wait'] += time.perf_counter() - t_0
                     # the slot of `tile` stays ours until it has been walked:
@@ -942,7 +960,7 @@ class CRP:
                     ids, sizes, born = self._gibbs_window(perm, tile['pos'],
                         tile['end'], tile['view'], ll, tile['cols'], ids,
                         sizes, born_log[tile['born_mark']:], assignment,
-                        post_new, crp_prior)
+                        post_new, crp_prior, hint=tile_hint)
                     born_log.extend(born)
                     opened += len(born)
                     tiles += 1
@@ -951,7 +969,8 @@ class CRP:
                 # context refuses to re-use its slot)
                 for left in in_flight:
                     try:
-                        ctx.ll_rows_wait(left['slot'],
+                        (ctx.ll_rows_wait_hint if 'prior' in left
+                            else ctx.ll_rows_wait)(left['slot'],
                             left['end'] - left['pos'], left['ld'])
                     except RuntimeError:
                         pass
@@ -1010,7 +1029,7 @@ class CRP:
         late = np.flatnonzero(live_col < 0)
         n_cols = cols.size + late.size
         if n_cols + 1 > ld:
-            if hint is not None:
+            if hint is not None and whole:
                 ctx.matrix_wait()
             ll = np.concatenate([ll, np.empty((n_rows, n_cols + 16 - ld))],
                 axis=1)
@@ -1033,12 +1052,15 @@ class CRP:
 
         st = _lib.GibbsState(N, ld, n_cols, K, pos, -1, pos_end,
             -1 if whole else pos, _lib.host_threads())
-        if hint is not None and whole and not late.size:
-            # columns 0..cols.size-1 of ll are the hint's columns
+        if hint is not None and (not whole or not late.size):
+            # columns 0..cols.size-1 of ll are the hint's columns (a tile's
+            # hint also covers columns of clusters that have died or whose id
+            # was re-used since: the loop never picks a dead column, and the
+            # hint's largest entry bounds every issued column from above)
             st.hint = _lib.ptr(hint[0])
             st.hint_prior = _lib.ptr(hint[1])
             st.hint_cols = cols.size
-            hook = getattr(ctx, 'matrix_wait_hook', None)
+            hook = getattr(ctx, 'matrix_wait_hook', None) if whole else None
             if hook is not None:
                 # the matrix is copied behind the loop, which waits for it
                 # itself before the first row it has to read
@@ -1081,7 +1103,7 @@ class CRP:
                 born.extend(int(i) for i in born_buf[:st.n_born])
             if st.new_cell < 0:
                 break
-            if hint is not None:
+            if hint is not None and whole:
                 # the matrix may still be on its way: it is about to be
                 # copied / written to from here
                 ctx.matrix_wait()

@@ -218,6 +218,22 @@ int bnpc_ll_rows_pinned(bnpc_ctx *ctx, int view, const int64_t *rows,
 int bnpc_ll_rows_issue(bnpc_ctx *ctx, int view, const int64_t *rows, int64_t K,
                        double FP, double FN, int64_t ldo, int slot);
 int bnpc_ll_rows_wait(bnpc_ctx *ctx, int slot, double **host);
+/* The same with the tile's HINTS (bnpc_gibbs_state.hint for a tile): per row
+ * the largest entry of out[s, k] + col_prior[k] over the K issued columns, its
+ * column and the largest entry among the other columns (col_prior[k] = the log
+ * prior of column k's cluster at issue time, CRP_prior[size]).  K may be tens
+ * of thousands: the record is a bnpc_top2 whose column is the 32-bit number
+ * (uint16) col | (uint16) col2 << 16, col3 = -1, row_here = 2, third = fourth
+ * = -inf.  From the moment the true clusters exist nearly every cell of a
+ * first sweep is dominated by one of them: the host's sequential loop then
+ * looks at one record per cell instead of walking 30 000 columns
+ * (libs/CRP.py:268-277).  *hint: rows of the view, valid until the next issue
+ * on the slot; NULL if the tile was issued without hints. */
+int bnpc_ll_rows_issue_hint(bnpc_ctx *ctx, int view, const int64_t *rows,
+                            int64_t K, double FP, double FN, int64_t ldo,
+                            int slot, const double *col_prior);
+int bnpc_ll_rows_wait_hint(bnpc_ctx *ctx, int slot, double **host,
+                           bnpc_top2 **hint);
 
 /* Same sums from caller-built element tables: L1[k,m] is the value an
  * observed 1 contributes, L0[k,m] an observed 0 (both K x M float64).  With
@@ -590,11 +606,13 @@ typedef struct bnpc_gibbs_state {
     int64_t threads;    /* host threads for the scan of a cell over thousands
                            of live clusters (first sweeps); <= 1: none.  The
                            result does not depend on it. */
-    /* optional (NULL: none; whole-matrix sweeps only): per CELL the two
-     * largest entries of ll[cell, k] + hint_prior[k] over the first hint_cols
-     * columns, from bnpc_ll_theta_pinned_top2.  Where those, widened by how
-     * far the priors have moved since, leave no doubt about the winner, the
-     * cell is not scanned.  The result does not depend on it. */
+    /* optional (NULL: none): per ROW of ll (row_base < 0: per cell, at most
+     * 64 columns, from bnpc_ll_theta_pinned_top2; row_base >= 0: per position
+     * of the tile, any number of columns, from bnpc_ll_rows_wait_hint) the
+     * largest entries of ll[row, k] + hint_prior[k] over the first hint_cols
+     * columns.  Where those, widened by how far the priors have moved since,
+     * leave no doubt about the winner, the cell is not scanned.  The result
+     * does not depend on it. */
     const struct bnpc_top2 *hint;
     const double *hint_prior;
     int64_t hint_cols;

@@ -7,6 +7,7 @@ tests/test_gpu_parity.py (-m gpu)."""
 import numpy as np
 
 from oracle import crp_numpy as O
+from bnpc_amd import _lib
 
 
 class FakeContext:
@@ -108,7 +109,22 @@ class FakeContext:
     def ll_rows_wait(self, slot, n_rows, ld):
         _, out = self.tiles.pop(slot)
         assert out.shape == (n_rows, ld)
+        self.__dict__.setdefault('tile_hints', {}).pop(slot, None)
         return out
+
+    def ll_rows_issue_hint(self, view, rows, FP, FN, ld, slot, col_prior):
+        """The tile with its hints, computed from the matrix AS ISSUED (a
+        column poisoned later, because its id was re-used, keeps the hint it
+        had - as on the device)."""
+        self.ll_rows_issue(view, rows, FP, FN, ld, slot)
+        self._count('ll_rows_issue_hint')
+        hints = self.__dict__.setdefault('tile_hints', {})
+        hints[slot] = _lib.wide_hints_from_matrix(self.tiles[slot][1],
+            col_prior)
+
+    def ll_rows_wait_hint(self, slot, n_rows, ld):
+        hint = self.__dict__.setdefault('tile_hints', {}).get(slot)
+        return self.ll_rows_wait(slot, n_rows, ld), hint
 
     def _poison_in_flight(self, row0, n):
         """A parameter row rewritten while a tile is in flight makes that

@@ -857,3 +857,40 @@ def test_screened_parameter_batch_equals_the_plain_batch():
     st, _ = _lib.rng_export()
     assert _lib.load().bnpc_mh_batch(C.addressof(table), C.byref(st),
         C.byref(a), C.byref(status)) != 0
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_tile_hints_change_nothing(seed, monkeypatch):
+    """A first sweep in tiles WITH the tiles' hints (per row the largest entry
+    under the priors at issue, its column, the runner-up: the loop decides a
+    cell from that record - or from a column born since the tile was issued -
+    wherever one cluster dominates) against the same sweep without hints
+    (BNPC_SWEEP_HINT=0: every cell walks every live column): the same labels,
+    cluster table, parameter rows and stream position, three sweeps in a row;
+    and the hints do decide most cells once the true clusters exist."""
+    data = synth(seed, 420, 300, 4, 0.1)
+    monkeypatch.setenv('BNPC_SWEEP_BYTES', '60000')     # 7 tiles at first
+    outs = []
+    for hints in ('1', '0'):
+        monkeypatch.setenv('BNPC_SWEEP_HINT', hints)
+        m = make(P, 'learn', data)
+        np.random.seed(10 + seed)
+        m.init()
+        states = []
+        for sweep in range(3):
+            m.update_assignments_Gibbs()
+            ids = list(m.cells_per_cluster)
+            states.append((m.assignment.copy(),
+                [(int(a), int(b)) for a, b in m.cells_per_cluster.items()],
+                m.parameters[ids].copy()))
+            if sweep == 0:
+                assert m._ctx.calls['view_set'] >= 5    # it was tiled
+        outs.append((states, np.random.random(), getattr(m, '_hint_used', 0),
+            m._ctx.calls.get('ll_rows_issue_hint', 0)))
+    a, b = outs
+    assert a[3] >= 5 and b[3] == 0
+    assert a[2] > 0.5 * 420 and b[2] == 0, (a[2], b[2])
+    for sa, sb in zip(a[0], b[0]):
+        assert np.array_equal(sa[0], sb[0]) and sa[1] == sb[1]
+        assert np.array_equal(sa[2], sb[2])
+    assert a[1] == b[1]
