@@ -31,8 +31,8 @@ def env(name, default=None):
     return default if val is None else os.fsdecode(val)
 
 
-MAX_VIEWS = 6
-TILE_SLOTS = 3      # include/bnpc_hip.h: BNPC_TILE_SLOTS
+MAX_VIEWS = 7
+TILE_SLOTS = 4      # include/bnpc_hip.h: BNPC_TILE_SLOTS
 MAX_TRIALS = 4
 
 _i64 = C.c_int64

@@ -164,12 +164,6 @@ struct bnpc_ctx {
     // issued tile occupies the main stream - they must not queue behind it
     hipStream_t side_stream = nullptr;
     DevBuf side_theta, side_tabs, side_out, side_part;
-    // the stream of the issued tiles: all compute units but a few, which are
-    // the side lane's own - a 10 ms tile kernel fills every CU it may use
-    // with workgroups that run for milliseconds, and a high priority alone
-    // leaves a small kernel waiting for one of them to end (measured at
-    // config 5: 50 births in the first tile, 0.5 ms each instead of 0.1)
-    hipStream_t tile_stream = nullptr;
     // pinned staging arena for small host <-> device payloads (parameter
     // rows, cell lists, counts): a copy from/to pinned memory is a plain DMA
     // enqueue, a copy from/to pageable memory is staged by the runtime at
@@ -499,55 +493,18 @@ struct SideLane {
     }
 };
 
-// The calls that issue a tile (its view, its tables and sums) run on the tile
-// stream: swap it in for the duration of the call.
-struct TileLane {
-    bnpc_ctx *c;
-    bool on;
-    explicit TileLane(bnpc_ctx *ctx) : c(ctx), on(ctx->tile_stream != nullptr)
-    {
-        if (on) std::swap(c->stream, c->tile_stream);
-    }
-    ~TileLane()
-    {
-        if (on) std::swap(c->stream, c->tile_stream);
-    }
-};
-
-#define SIDE_LANE_CUS 8
-
-// side lane + tile lane, created at the first tile of a context
+// the side lane, created at the first tile of a context: calls made while
+// tiles are in flight (a column for a cluster just opened, the columns of
+// clusters born since a tile was issued) run beside 10 ms kernels that fill
+// the chip; on a stream of the highest priority their few workgroups get the
+// next free slots instead of waiting for a whole tile.  (Compute units of
+// their own - the tile kernels on a CU-masked stream, the side lane on the
+// rest - were tried in round 4: the masked stream ran the whole sweep 12 %
+// slower, 0.53 against 0.475 s, for births that are bound by their host-side
+// Beta draws anyway.)
 static int ensure_lanes(bnpc_ctx *c)
 {
     if (c->side_stream) return 0;
-    // calls made while tiles are in flight (a column for a cluster just
-    // opened, the columns of clusters born since a tile was issued) run
-    // beside 10 ms kernels that fill the chip.  They get a stream of the
-    // highest priority AND compute units of their own: the tile stream is
-    // masked off the first SIDE_LANE_CUS units, the side stream owns them.
-    int cus = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess)
-        cus = prop.multiProcessorCount;
-    if (cus >= 64 && cus <= 1024) {
-        std::vector<uint32_t> tile_mask((cus + 31) / 32, 0u),
-            side_mask((cus + 31) / 32, 0u);
-        for (int cu = 0; cu < cus; cu++)
-            (cu < SIDE_LANE_CUS ? side_mask : tile_mask)[cu >> 5]
-                |= 1u << (cu & 31);
-        hipStream_t tile = nullptr, side = nullptr;
-        if (hipExtStreamCreateWithCUMask(&tile, (uint32_t)tile_mask.size(),
-                                         tile_mask.data()) == hipSuccess
-            && hipExtStreamCreateWithCUMask(&side, (uint32_t)side_mask.size(),
-                                            side_mask.data()) == hipSuccess) {
-            c->tile_stream = tile;
-            c->side_stream = side;
-            return 0;
-        }
-        (void)hipGetLastError();
-        if (tile) (void)hipStreamDestroy(tile);
-        if (side) (void)hipStreamDestroy(side);
-    }
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess
         || hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking,
@@ -1997,7 +1954,6 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
-    if (c->tile_stream) (void)hipStreamSynchronize(c->tile_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
                       &c->tile_out[0], &c->tile_out[1],
@@ -2037,7 +1993,6 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    if (c->tile_stream) (void)hipStreamDestroy(c->tile_stream);
     delete c;
     return 0;
 }
@@ -2132,9 +2087,12 @@ extern "C" int bnpc_view_set_slot(bnpc_ctx *c, int view, const int64_t *cells,
         ARGCHK(cells[i] >= 0 && cells[i] < c->N, "cell index out of range");
     HIPCHK(hipSetDevice(c->device));
     if (ensure_lanes(c)) return 1;
-    TileLane tile_lane(c);
+    // (for all N cells at once: tiles grow as the clusters die, and growing
+    // a pinned buffer means hipHostFree - a device-wide synchronisation of
+    // ~5 ms in the middle of the pipeline; measured: 33 of them, 0.17 s of a
+    // config-5 first sweep)
     if (ensure_host(&c->tile_cells[slot], &c->tile_cells_cap[slot],
-                    n * sizeof(long long)))
+                    std::max<int64_t>(n, c->N) * sizeof(long long)))
         return 1;
     memcpy(c->tile_cells[slot], cells, n * sizeof(long long));
     void *d = nullptr;
@@ -2784,11 +2742,9 @@ static int ll_rows_issue_impl(bnpc_ctx *c, int view, const int64_t *rows,
         HIPCHK(hipEventRecord(c->tile_out_free[par], c->stream));
     }
     if (ensure_lanes(c)) return 1;
-    TileLane tile_lane(c);
     if (!c->copy_stream)
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream,
                                         hipStreamNonBlocking));
-    if (ensure_host(&c->tile_pin[slot], &c->tile_cap[slot], bytes)) return 1;
     if (ensure_host(&c->tile_rows[slot], &c->tile_rows_cap[slot],
                     K * sizeof(long long)))
         return 1;
@@ -2816,7 +2772,8 @@ static int ll_rows_issue_impl(bnpc_ctx *c, int view, const int64_t *rows,
         // through a pinned staging copy)
         const size_t rows_n = (size_t)c->views[view].n;
         if (ensure_host(&c->tile_hint[slot], &c->tile_hint_cap[slot],
-                        rows_n * sizeof(bnpc_top2)))
+                        std::max<size_t>(rows_n, (size_t)c->N)
+                            * sizeof(bnpc_top2)))
             return 1;
         if (ensure_host(&c->tile_prior[slot], &c->tile_prior_cap[slot],
                         K * sizeof(double)))
@@ -2837,6 +2794,10 @@ static int ll_rows_issue_impl(bnpc_ctx *c, int view, const int64_t *rows,
         c->tile_hinted[slot] = true;
     }
     HIPCHK(hipEventRecord(c->tile_summed[par], c->stream));
+    // the slot's pinned result buffer is made (18 ms per 256 MiB the first
+    // time) while the device is busy with the tile just queued - not in front
+    // of it: three of them were 54 ms of a config-5 first sweep
+    if (ensure_host(&c->tile_pin[slot], &c->tile_cap[slot], bytes)) return 1;
     HIPCHK(hipStreamWaitEvent(c->copy_stream, c->tile_summed[par], 0));
     HIPCHK(hipMemcpyAsync(c->tile_pin[slot], c->tile_out[par].p, bytes,
                           hipMemcpyDeviceToHost, c->copy_stream));

@@ -878,6 +878,9 @@ class CRP:
             opened, tiles = len(born), 1
         else:
             perm, assignment = self._sweep_order(N)
+            if timing:
+                print(f'[bnpc]   new-cluster term + order: '
+                    f'{time.perf_counter() - t_start:.3f}s', flush=True)
             # Tiled sweep.  The parameter rows stay resident on the device
             # (row = cluster id) and tiles select clusters by index.  Tiles
             # t+1 and t+2 are in flight while the host walks tile t - the
@@ -886,6 +889,9 @@ class CRP:
             # will need, minus the clusters (re)born before it is picked up,
             # whose columns are evaluated then.
             ctx.theta_put(0, self.parameters[:int(ids.max()) + 1])
+            if timing:
+                print(f'[bnpc]   parameter rows on the device: '
+                    f'{time.perf_counter() - t_start:.3f}s', flush=True)
 
             tile_bytes = min(budget,
                 int(_lib.env('BNPC_TILE_BYTES', 256 << 20)))
@@ -906,7 +912,12 @@ class CRP:
                 tile = dict(pos=start, end=min(N, start + rows), slot=slot,
                     number=number, view=VIEW_SWEEP + slot, cols=ids.copy(),
                     ld=ids.size + _TILE_SPARE, born_mark=len(born_log))
+                if timing:
+                    t_v = time.perf_counter()
                 ctx.view_set_slot(tile['view'], perm[start:tile['end']], slot)
+                if timing:
+                    spent['view'] = spent.get('view', 0.0) \
+                        + time.perf_counter() - t_v
                 if tile_hints:
                     # with the priors of the clusters as they are now: the
                     # device also says, per cell, which column is largest and
@@ -931,6 +942,10 @@ class CRP:
                     if timing:
                         t_0 = time.perf_counter()
                     tile = issue(upcoming[0], upcoming[1])
+                    if timing and upcoming[1] < 3:
+                        print(f'[bnpc]   tile {upcoming[1]} issued: '
+                            f'{time.perf_counter() - t_start:.3f}s',
+                            flush=True)
                     in_flight.append(tile)
                     upcoming[0] = tile['end']
                     upcoming[1] += 1
@@ -977,7 +992,8 @@ class CRP:
         if timing:
             extra = ''
             if tiles > 1:
-                extra = (f"; issuing {spent['issue']:.3f}s, waiting for the "
+                extra = (f"; issuing {spent['issue']:.3f}s (views "
+                    f"{spent.get('view', 0.0):.3f}s), waiting for the "
                     f"device {spent['wait']:.3f}s")
             print(f'[bnpc] gibbs N={N} K={K_start}->{ids.size}: '
                 f'{time.perf_counter() - t_start:.3f}s in {tiles} tile(s), '

@@ -47,8 +47,8 @@ extern "C" {
 
 typedef struct bnpc_ctx bnpc_ctx;
 
-#define BNPC_MAX_VIEWS 6
-#define BNPC_TILE_SLOTS 3    /* tiles in flight (bnpc_ll_rows_issue) */
+#define BNPC_MAX_VIEWS 7
+#define BNPC_TILE_SLOTS 4    /* tiles in flight (bnpc_ll_rows_issue) */
 #define BNPC_MAX_TRIALS 4
 
 /* ---- library / device ---------------------------------------------------- */

@@ -102,7 +102,7 @@ class FakeContext:
     def ll_rows_issue(self, view, rows, FP, FN, ld, slot):
         self._count('ll_rows_issue')
         tiles = self.__dict__.setdefault('tiles', {})
-        assert slot in (0, 1, 2) and slot not in tiles
+        assert slot in (0, 1, 2, 3) and slot not in tiles
         tiles[slot] = (np.asarray(rows).copy(),
             self.ll_rows_pinned(view, rows, FP, FN, ld))
 
