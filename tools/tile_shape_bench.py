@@ -25,7 +25,7 @@ for rows in (264, 512, 1024, 1060, 2048, 4096):
     ctx.bench_ll(1)
     ms = min(ctx.bench_ll(3) for _ in range(2))
     print(f'rows {rows:5d} x K {K} x M {M}: {ms:8.3f} ms  '
-        f'{rows * K * M / ms / 1e9:7.2f} T elem-evals/s '
-        f'({rows * K * M / ms / 1e9 / 19650 * 100:5.1f}% of 2-add peak)',
+        f'{rows * K * M / (ms * 1e-3) / 1e12:7.2f} T elem-evals/s '
+        f'({rows * K * M / (ms * 1e-3) / 19.65e12 * 100:5.1f}% of 2-add peak)',
         flush=True)
 ctx.close()
