@@ -24,6 +24,7 @@
 // /root/reference).
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -130,6 +131,14 @@ static void read_tunables(Tunables &t)
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
 }
 
+#define DONE_SLOTS 3     // 0, 1: the launches of a call; 2: the deferred total
+// what a kernel needs to tell the host that it is done (signal_done below)
+struct DoneSignal {
+    unsigned *count;    // device word, zero between launches
+    unsigned *flag;     // pinned host word (device address)
+    unsigned seq;
+};
+
 struct bnpc_ctx {
     Tunables tun;
     int device = 0;
@@ -192,6 +201,16 @@ struct bnpc_ctx {
     // a settled one never does)
     bool matrix_eager = false, lazy_fetched = false, pin_copy_queued = false;
     hipEvent_t ev_hints = nullptr;
+    // completion words (DoneSignal): two slots, so that two launches of one
+    // call may be in flight (the two halves of a screened batch)
+    unsigned *done_count = nullptr;         // device, DONE_SLOTS words
+    unsigned *done_pin = nullptr;           // pinned host, DONE_SLOTS x 16 words
+    unsigned *done_dev = nullptr;           // ... as the device addresses it
+    unsigned done_seq = 0;
+    unsigned total_seq = 0;                 // of the pending bnpc_ll_total
+    int total_slot = -1;
+    DoneSignal sig_next = {nullptr, nullptr, 0};    // for the last kernel of
+    bool sig_attached = false;                      // the next issue_ll
     bool total_pending = false;     // a deferred bnpc_ll_total_issue
     int total_blocks = 0, total_E = 0;
     // where the kernels of the current call read their inputs from: device
@@ -378,6 +397,63 @@ static int arena_reset(bnpc_ctx *c)
     return 0;
 }
 
+// A DoneSignal for the next launch on slot 0 / 1 (the words are made on first
+// use; without them - or with BNPC_DONE_WORDS=0 - the signal is empty and the
+// caller synchronises as before).  *seq receives the number to wait for.
+static DoneSignal make_signal(bnpc_ctx *c, int slot, unsigned *seq)
+{
+    DoneSignal none = {nullptr, nullptr, 0};
+    *seq = 0;
+    static const bool off = [] {
+        const char *e = getenv("BNPC_DONE_WORDS");
+        return e && e[0] == '0';
+    }();
+    if (off) return none;
+    if (!c->done_count) {
+        void *pin = nullptr, *dev = nullptr, *cnt = nullptr;
+        if (hipHostMalloc(&pin, DONE_SLOTS * 64, hipHostMallocDefault) != hipSuccess
+            || hipHostGetDevicePointer(&dev, pin, 0) != hipSuccess
+            || hipMalloc(&cnt, DONE_SLOTS * sizeof(unsigned)) != hipSuccess
+            || hipMemset(cnt, 0, DONE_SLOTS * sizeof(unsigned))
+                != hipSuccess) {
+            (void)hipGetLastError();
+            if (pin) (void)hipHostFree(pin);
+            if (cnt) (void)hipFree(cnt);
+            return none;
+        }
+        memset(pin, 0, DONE_SLOTS * 64);
+        c->done_pin = (unsigned *)pin;
+        c->done_dev = (unsigned *)dev;
+        c->done_count = (unsigned *)cnt;
+    }
+    if (++c->done_seq == 0) c->done_seq = 1;    // 0 = "no signal"
+    *seq = c->done_seq;
+    DoneSignal d = {c->done_count + slot, c->done_dev + 16 * slot, *seq};
+    return d;
+}
+
+// Wait for the word of a signalled launch; seq == 0 (no signal was attached)
+// or a word that does not come within the spin: hipStreamSynchronize.
+static int wait_done(bnpc_ctx *c, int slot, unsigned seq)
+{
+    if (seq) {
+        const volatile unsigned *f = c->done_pin + 16 * slot;
+        for (int spins = 0; spins < 20000; spins++) {       // ~100-200 us
+            // (launches of a stream finish in order and the numbers only
+            // grow: a later number on the word says this one is done too)
+            if ((int)(*f - seq) >= 0) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return 0;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // Zero-copy input: the payload is copied into the pinned arena and the
 // kernels of this call read it there, over the host link, instead of from a
 // device buffer filled by a DMA copy - for payloads of a few hundred KiB a
@@ -515,6 +591,41 @@ static int ensure_lanes(bnpc_ctx *c)
                                         hipStreamNonBlocking));
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Completion words.  A converged step is a chain of small dependent launches
+// whose results the host waits for (~7 waits per step), and the runtime's
+// completion signal reaches the host 11-14 us after a launch began - 5-8 us
+// after a word the kernel writes itself (tools/ubench/sync_probe.hip: 5.3
+// us).  So the kernels whose results the host waits for take a DoneSignal:
+// every workgroup, its stores complete (the barrier), has one thread publish
+// them at system scope and count itself in; the workgroup that counts in
+// last resets the counter and writes the launch's sequence number to a word
+// in pinned host memory, which the host polls (wait_done) - falling back to
+// hipStreamSynchronize after a bounded spin, so a lost word costs time, not
+// correctness.  count == NULL: no signal (the caller synchronises).
+// ---------------------------------------------------------------------------
+// EVERY thread of the workgroup must get here (no early return before it)
+__device__ __forceinline__ void signal_done(const DoneSignal &d)
+{
+    if (!d.count) return;
+    __syncthreads();                // each wave's stores are issued and acked
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        __threadfence_system();     // ... and visible to the host
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned n = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned old = __hip_atomic_fetch_add(
+            d.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == n - 1) {
+            __hip_atomic_store(d.count, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -767,26 +878,30 @@ __global__ __launch_bounds__(256) void k_ll(
 
 __global__ __launch_bounds__(256) void k_ll_combine(
     const double *__restrict__ part, long long n, int K, int MS,
-    long long ldo, double *__restrict__ out)
+    long long ldo, double *__restrict__ out, DoneSignal done)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n * K) return;
-    const long long slot = i / K;
-    const int k = (int)(i - slot * K);
-    // partial sums are added in index order (deterministic); the loads are
-    // independent of the adds, 8 in flight
-    const size_t stride = (size_t)n * K;
-    double s = part[i];
-    int ms = 1;
-    for (; ms + 8 <= MS; ms += 8) {
-        double v[8];
+    if (i < n * K) {
+        const long long slot = i / K;
+        const int k = (int)(i - slot * K);
+        // partial sums are added in index order (deterministic); the loads
+        // are independent of the adds, 8 in flight
+        const size_t stride = (size_t)n * K;
+        double s = part[i];
+        int ms = 1;
+        for (; ms + 8 <= MS; ms += 8) {
+            double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = part[(size_t)(ms + u) * stride + i];
+            for (int u = 0; u < 8; u++)
+                v[u] = part[(size_t)(ms + u) * stride + i];
 #pragma unroll
-        for (int u = 0; u < 8; u++) s += v[u];
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; ms < MS; ms++) s += part[(size_t)ms * stride + i];
+        out[(size_t)slot * ldo + k] = s;
     }
-    for (; ms < MS; ms++) s += part[(size_t)ms * stride + i];
-    out[(size_t)slot * ldo + k] = s;
+    // (ONE call per wave, where its lanes have converged: the barrier inside)
+    signal_done(done);
 }
 
 // One mutation for 8 clusters: EXEC <- lane mask of the cells that observed a
@@ -1005,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
     double *__restrict__ out, int xcd_remap, int MS_arg, int m_chunk,
-    const ulonglong2 *masks_pf, const double *T_pf)
+    const ulonglong2 *masks_pf, const double *T_pf, DoneSignal done)
 {
     // masks_pf / T_pf: the same two arrays again, or NULL (no prefetch).  The
     // prefetch below hands addresses to inline assembly; were they derived
@@ -1031,7 +1146,10 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     if (SPLIT) bx /= MSq;
     const int ms = SPLIT ? q * 4 + wave : 0;    // mutation chunk of this wave
     const long long blk0 = SPLIT ? bx * CB : (bx * 4 + wave) * CB;
-    if (blk0 >= nblk) return;           // SPLIT: the whole workgroup leaves
+    if (blk0 >= nblk) {                 // SPLIT: the whole workgroup leaves
+        if constexpr (SPLIT) signal_done(done);
+        return;
+    }
     const int m_begin = SPLIT ? ms * m_chunk : 0;
     const int m_len = !SPLIT ? Mt
         : (ms >= MS ? 0
@@ -1155,6 +1273,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
                 o[j] = s;
             }
         }
+        signal_done(done);
     } else {
 #pragma unroll
         for (int c = 0; c < CB; c++) {
@@ -1278,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_ll_seqp(
     const ulonglong2 *__restrict__ masks, int Mpad, int M, long long n,
     long long nblk, const double *__restrict__ L1,
     const double *__restrict__ L0, int K, long long ldo,
-    double *__restrict__ out)
+    double *__restrict__ out, DoneSignal done)
 {
     extern __shared__ double seqp_x[];          // [2][64][SEQP_XS]
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1303,19 +1422,20 @@ __global__ __launch_bounds__(256) void k_ll_seqp(
         for (int ch = nch; ch < nch_up; ch++) seqp_barrier();
         const long long slot = blk * 64 + lane;
         if (slot < n) out[(size_t)slot * ldo + k] = acc;
-        return;
+    } else {
+        // wave-uniform bases (SGPR pairs); the lane enters as a 32-bit offset
+        const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
+        const double *__restrict__ t1 = L1 + (size_t)k * M;
+        const double *__restrict__ t0 = L0 + (size_t)k * M;
+        double *xs = seqp_x + lane;
+        if (wave == 1)
+            seqp_producer<0, 22>(mk, t1, t0, nch, nch_up, M, lane, xs);
+        else if (wave == 2)
+            seqp_producer<22, 43>(mk, t1, t0, nch, nch_up, M, lane, xs);
+        else
+            seqp_producer<43, 64>(mk, t1, t0, nch, nch_up, M, lane, xs);
     }
-    // wave-uniform bases (SGPR pairs); the lane enters as a 32-bit offset
-    const ulonglong2 *__restrict__ mk = masks + (size_t)blk * Mpad;
-    const double *__restrict__ t1 = L1 + (size_t)k * M;
-    const double *__restrict__ t0 = L0 + (size_t)k * M;
-    double *xs = seqp_x + lane;
-    if (wave == 1)
-        seqp_producer<0, 22>(mk, t1, t0, nch, nch_up, M, lane, xs);
-    else if (wave == 2)
-        seqp_producer<22, 43>(mk, t1, t0, nch, nch_up, M, lane, xs);
-    else
-        seqp_producer<43, 64>(mk, t1, t0, nch, nch_up, M, lane, xs);
+    signal_done(done);
 }
 
 // tables of a K2p launch, pinned arena -> device: ONE trip over the host link
@@ -1540,7 +1660,7 @@ __global__ __launch_bounds__(256) void k_counts_masks(
     const ulonglong2 *__restrict__ masks, int Mpad, int M, long long nblk,
     const unsigned long long *__restrict__ member, int G,
     int *__restrict__ n1, int *__restrict__ n0, int *__restrict__ h1,
-    int *__restrict__ h0)
+    int *__restrict__ h0, DoneSignal done)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1597,6 +1717,7 @@ __global__ __launch_bounds__(256) void k_counts_masks(
             }
         }
     }
+    signal_done(done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1612,7 +1733,7 @@ __global__ __launch_bounds__(256) void k_ll_total(
     const float *__restrict__ theta, const int *__restrict__ n1,
     const int *__restrict__ n0, long long KM, int E, double FP0, double FN0,
     double FP1, double FN1, double FP2, double FN2, double FP3, double FN3,
-    double *__restrict__ partial)
+    double *__restrict__ partial, DoneSignal done)
 {
     const double FPs[4] = {FP0, FP1, FP2, FP3};
     const double FNs[4] = {FN0, FN1, FN2, FN3};
@@ -1648,6 +1769,7 @@ __global__ __launch_bounds__(256) void k_ll_total(
     }
     if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
         red[threadIdx.x][0];
+    signal_done(done);
 }
 
 
@@ -1696,80 +1818,84 @@ __global__ __launch_bounds__(256) void k_mh_screen(
     const float *__restrict__ theta, const int *__restrict__ n1,
     const int *__restrict__ n0, const int *__restrict__ sd_idx,
     const double *__restrict__ U, const double *__restrict__ u, long long GM,
-    int M, int sum_row, MHScreenConst k, unsigned char *__restrict__ flags)
+    int M, int sum_row, MHScreenConst k, unsigned char *__restrict__ flags,
+    DoneSignal done)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= GM) return;
-    const int g = (int)(i / M);
-    const int m = (int)(i - (long long)g * M);
-    int c1, c0;
-    if (g == sum_row) {             // the merged cluster of a restricted scan
-        c1 = n1[m] + n1[M + m];
-        c0 = n0[m] + n0[M + m];
-    } else {
-        c1 = n1[(size_t)g * M + m];
-        c0 = n0[(size_t)g * M + m];
-    }
-    const float old = theta[i];
-    const double Ui = U[i], ui = u[i];
-    const int si = sd_idx[i];
-    unsigned char flag = 1;
-    if (si >= 0 && si < 8 && Ui > 0.0 && Ui < 1.0 && ui > 0.0 && ui < 1.0
-        && old >= k.tmin32 && old <= k.tmax32 && c1 >= 0 && c0 >= 0) {
-        const double sd = k.sd[si];
-        const double lo = (double)(k.tmin32 - old) / sd;
-        const double hi = (double)(k.tmax32 - old) / sd;
-        if (lo <= 0.0 && hi > 0.0) {
-            const double Pa = normcdf(lo), Qb = normcdf(-hi);
-            const double Z = 1.0 - Pa - Qb;
-            const double pl = Pa + Ui * Z;
-            double x;
-            if (pl <= 0.5)
-                x = normcdfinv(pl);
-            else
-                x = -normcdfinv(Qb + (1.0 - Ui) * Z);
-            const double xv = x * sd + (double)old;
-            const float nw = (float)xv;
-            // four float32 steps inside the bounds: the host's proposal may
-            // sit an ulp or two away and must still be inside
-            const float in_lo = k.tmin32 * (1.0f + 6e-7f);
-            const float in_hi = k.tmax32 * (1.0f - 6e-7f);
-            if (nw > in_lo && nw < in_hi) {
-                const double ar = (double)(k.tmin32 - nw) / sd;
-                const double br = (double)(k.tmax32 - nw) / sd;
-                const double Zr = 1.0 - normcdf(ar) - normcdf(-br);
-                const double pFN1 = 1.0 - k.FN, pFP0 = 1.0 - k.FP;
-                const double tn = (double)nw, on = (double)(1.0f - nw);
-                const double to = (double)old, oo = (double)(1.0f - old);
-                const double P1n = tn * pFN1 + on * k.FP;
-                const double P0n = tn * k.FN + on * pFP0;
-                const double P1o = to * pFN1 + oo * k.FP;
-                const double P0o = to * k.FN + oo * pFP0;
-                const double lln = (double)c1 * log(P1n) + (double)c0 * log(P0n);
-                const double llo = (double)c1 * log(P1o) + (double)c0 * log(P0o);
-                double prn = 0.0, pro = 0.0, prs = 0.0;
-                if (!k.uniform_prior) {
-                    prn = (k.q - 1.0) * log1p(-tn) + (k.p - 1.0) * log(tn);
-                    pro = (k.q - 1.0) * log1p(-to) + (k.p - 1.0) * log(to);
-                    prs = fabs(k.p - 1.0) / tn + fabs(k.q - 1.0) / (1.0 - tn);
-                }
-                const double A = (lln - llo) + (prn - pro) + (log(Z) - log(Zr));
-                const double cc = fabs(1.0 - k.FN - k.FP);
-                const double sens = (double)c1 * cc / P1n + (double)c0 * cc / P0n
-                    + prs + 1.0 / (sd * Zr);
-                const double dtheta = 4.0 * 1.2e-7 * tn + 1e-13;
-                const double margin = sens * dtheta + 1e-7
-                    + 1e-12 * (fabs(lln) + fabs(llo) + fabs(prn) + fabs(pro));
-                const double gap = log(ui) - A;
-                if (Z > 0.0 && Zr > 0.0 && gap == gap && gap < INFINITY
-                    && gap > -INFINITY) {
-                    if (gap > margin) flag = 0;         // declined for certain
-                    else if (-gap > margin) flag = 2;   // accepted for certain
+    // (no early return: every wave reaches signal_done once, converged)
+    if (i < GM) {
+        const int g = (int)(i / M);
+        const int m = (int)(i - (long long)g * M);
+        int c1, c0;
+        if (g == sum_row) {             // the merged cluster of a restricted scan
+            c1 = n1[m] + n1[M + m];
+            c0 = n0[m] + n0[M + m];
+        } else {
+            c1 = n1[(size_t)g * M + m];
+            c0 = n0[(size_t)g * M + m];
+        }
+        const float old = theta[i];
+        const double Ui = U[i], ui = u[i];
+        const int si = sd_idx[i];
+        unsigned char flag = 1;
+        if (si >= 0 && si < 8 && Ui > 0.0 && Ui < 1.0 && ui > 0.0 && ui < 1.0
+            && old >= k.tmin32 && old <= k.tmax32 && c1 >= 0 && c0 >= 0) {
+            const double sd = k.sd[si];
+            const double lo = (double)(k.tmin32 - old) / sd;
+            const double hi = (double)(k.tmax32 - old) / sd;
+            if (lo <= 0.0 && hi > 0.0) {
+                const double Pa = normcdf(lo), Qb = normcdf(-hi);
+                const double Z = 1.0 - Pa - Qb;
+                const double pl = Pa + Ui * Z;
+                double x;
+                if (pl <= 0.5)
+                    x = normcdfinv(pl);
+                else
+                    x = -normcdfinv(Qb + (1.0 - Ui) * Z);
+                const double xv = x * sd + (double)old;
+                const float nw = (float)xv;
+                // four float32 steps inside the bounds: the host's proposal may
+                // sit an ulp or two away and must still be inside
+                const float in_lo = k.tmin32 * (1.0f + 6e-7f);
+                const float in_hi = k.tmax32 * (1.0f - 6e-7f);
+                if (nw > in_lo && nw < in_hi) {
+                    const double ar = (double)(k.tmin32 - nw) / sd;
+                    const double br = (double)(k.tmax32 - nw) / sd;
+                    const double Zr = 1.0 - normcdf(ar) - normcdf(-br);
+                    const double pFN1 = 1.0 - k.FN, pFP0 = 1.0 - k.FP;
+                    const double tn = (double)nw, on = (double)(1.0f - nw);
+                    const double to = (double)old, oo = (double)(1.0f - old);
+                    const double P1n = tn * pFN1 + on * k.FP;
+                    const double P0n = tn * k.FN + on * pFP0;
+                    const double P1o = to * pFN1 + oo * k.FP;
+                    const double P0o = to * k.FN + oo * pFP0;
+                    const double lln = (double)c1 * log(P1n) + (double)c0 * log(P0n);
+                    const double llo = (double)c1 * log(P1o) + (double)c0 * log(P0o);
+                    double prn = 0.0, pro = 0.0, prs = 0.0;
+                    if (!k.uniform_prior) {
+                        prn = (k.q - 1.0) * log1p(-tn) + (k.p - 1.0) * log(tn);
+                        pro = (k.q - 1.0) * log1p(-to) + (k.p - 1.0) * log(to);
+                        prs = fabs(k.p - 1.0) / tn + fabs(k.q - 1.0) / (1.0 - tn);
+                    }
+                    const double A = (lln - llo) + (prn - pro) + (log(Z) - log(Zr));
+                    const double cc = fabs(1.0 - k.FN - k.FP);
+                    const double sens = (double)c1 * cc / P1n + (double)c0 * cc / P0n
+                        + prs + 1.0 / (sd * Zr);
+                    const double dtheta = 4.0 * 1.2e-7 * tn + 1e-13;
+                    const double margin = sens * dtheta + 1e-7
+                        + 1e-12 * (fabs(lln) + fabs(llo) + fabs(prn) + fabs(pro));
+                    const double gap = log(ui) - A;
+                    if (Z > 0.0 && Zr > 0.0 && gap == gap && gap < INFINITY
+                        && gap > -INFINITY) {
+                        if (gap > margin) flag = 0;         // declined for certain
+                        else if (-gap > margin) flag = 2;   // accepted for certain
+                    }
                 }
             }
         }
+        flags[i] = flag;
     }
-    flags[i] = flag;
+    signal_done(done);
 }
 
 // ---------------------------------------------------------------------------
@@ -1955,6 +2081,8 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->done_pin) (void)hipHostFree(c->done_pin);
+    if (c->done_count) (void)hipFree(c->done_count);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
                       &c->tile_out[0], &c->tile_out[1],
                       &c->tile_prior_dev[0], &c->tile_prior_dev[1],
@@ -2212,7 +2340,14 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        (const double *)c->tabs.p, (int)K, (long long)ldo,    \
                        dst, xcd, MS, m_chunk,                                \
                        pf ? (const ulonglong2 *)v.masks.p : nullptr,         \
-                       pf ? (const double *)c->tabs.p : nullptr)
+                       pf ? (const double *)c->tabs.p : nullptr,             \
+                       (SPLIT_) && need_planes == 1 ? sig : no_sig)
+    // the completion word rides on the LAST kernel of the evaluation: the
+    // combine pass, or the split sums kernel itself when a workgroup holds
+    // the whole sum (4 chunks); other forms leave it unattached
+    const DoneSignal sig = c->sig_next, no_sig = {nullptr, nullptr, 0};
+    c->sig_next = no_sig;
+    c->sig_attached = false;
     const char *combine = "";
     if (KW == 8 && wg2 >= ASM2_MIN_WGS) {
         if (MS > 1) {
@@ -2271,7 +2406,10 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         hipLaunchKernelGGL(k_ll_combine, dim3((unsigned)((total + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->part.p,
                            (long long)v.n, (int)K, planes, (long long)ldo,
-                           d_out);
+                           d_out, sig);
+        c->sig_attached = sig.count != nullptr;
+    } else if (KW == 8 && MS > 1 && need_planes == 1) {
+        c->sig_attached = sig.count != nullptr;
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2345,7 +2483,10 @@ static int issue_seqp(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     hipLaunchKernelGGL(k_ll_seqp, grid, dim3(256), SEQP_LDS, c->stream,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.n, (long long)v.nblk, tabs,
-                       tabs + (size_t)K * c->M, (int)K, (long long)ldo, d_out);
+                       tabs + (size_t)K * c->M, (int)K, (long long)ldo, d_out,
+                       c->sig_next);
+    c->sig_attached = c->sig_next.count != nullptr;
+    c->sig_next = DoneSignal{nullptr, nullptr, 0};
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2380,6 +2521,11 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
                 from_theta && c->tun.msplit, &MS, &m_chunk);
     double *d_out = zc_host ? (double *)zc_dev : (double *)c->out.p;
     if (c->dst_override) d_out = c->dst_override;
+    // a result written in place for the host is waited for through the
+    // completion word of the evaluation's last kernel
+    unsigned done_seq = 0;
+    c->sig_attached = false;
+    if (zc_host) c->sig_next = make_signal(c, 0, &done_seq);
     int rc;
     // caller-built tables: the one-chain-on-four-SIMDs pipeline; a forced
     // cluster tile (BNPC_KW, tests) takes them through k_ll<KW> instead
@@ -2405,8 +2551,10 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     c->last_K = K;
     c->last_ldo = ldo;
     c->last_out = d_out;
+    c->sig_next = DoneSignal{nullptr, nullptr, 0};
     if (zc_host) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (int rw = wait_done(c, 0, c->sig_attached ? done_seq : 0))
+            return rw;
         // columns K..ldo of the caller's rows are not ours to touch
         if (ldo == K) {
             memcpy(out, zc_host, out_bytes);
@@ -2995,14 +3143,17 @@ static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
         bnpc_set_error("view too large for the mask-count kernel");
         return 1;
     }
+    unsigned done_seq = 0;
+    const DoneSignal sig = (zc_host && !defer) ? make_signal(c, 0, &done_seq)
+                                               : DoneSignal{nullptr, nullptr, 0};
     hipLaunchKernelGGL(k_counts_masks, grid, dim3(256), lds, c->stream,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
-                       (long long)v.nblk, d_mem, (int)G, d1, d0, h1, h0);
+                       (long long)v.nblk, d_mem, (int)G, d1, d0, h1, h0, sig);
     HIPCHK(hipGetLastError());
     if (zc_host && defer) {
         *defer = zc_host;
     } else if (zc_host) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (int rc = wait_done(c, 0, done_seq)) return rc;
         memcpy(n1, zc_host, half);
         memcpy(n0, zc_host + (size_t)G * c->M, half);
     } else if (n1 && n0) {
@@ -3214,7 +3365,8 @@ static int mh_counts(bnpc_ctx *c, int src, int64_t G, const int **n1,
 
 // rows [g0, g0 + Gp) of the batch
 static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
-                            const MHPin &dev, int64_t g0 = 0, int64_t Gp = -1)
+                            const MHPin &dev, int64_t g0 = 0, int64_t Gp = -1,
+                            DoneSignal sig = {nullptr, nullptr, 0})
 {
     const int *n1, *n0;
     int sum_row;
@@ -3236,7 +3388,7 @@ static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
     hipLaunchKernelGGL(k_mh_screen, dim3((unsigned)((GM + 255) / 256)),
                        dim3(256), 0, c->stream, dev.theta + at, n1 + at,
                        n0 + at, dev.sd_idx + at, dev.U + at, dev.u + at, GM,
-                       (int)a->M, sum_row, k, dev.flags + at);
+                       (int)a->M, sum_row, k, dev.flags + at, sig);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -3312,6 +3464,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
             HIPCHK(hipEventCreateWithFlags(&c->mh_ev[p],
                                            hipEventDisableTiming));
     SideLane lane(c);
+    unsigned done_seq[2] = {0, 0};
     for (int p = 0; p < parts; p++) {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M, n = (size_t)Gp * M;
@@ -3325,8 +3478,10 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
             memcpy(h.sd_idx + at, a->sd_idx + at, n * 4);
         }
         memcpy(h.theta + at, a->old_theta + at, n * 4);
-        if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp)) return rc;
-        HIPCHK(hipEventRecord(c->mh_ev[p], c->stream));
+        const DoneSignal sig = make_signal(c, p, &done_seq[p]);
+        if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp, sig))
+            return rc;
+        if (!done_seq[p]) HIPCHK(hipEventRecord(c->mh_ev[p], c->stream));
     }
     if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
     int64_t kept = 0;
@@ -3334,7 +3489,11 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     for (int p = 0; p < parts; p++) {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M;
-        HIPCHK(hipEventSynchronize(c->mh_ev[p]));
+        if (done_seq[p]) {
+            if (int rc = wait_done(c, p, done_seq[p])) return rc;
+        } else {
+            HIPCHK(hipEventSynchronize(c->mh_ev[p]));
+        }
         if (pending) {          // the counts were written before the screen
             memcpy((void *)a->n1, pending, E * sizeof(int32_t));
             memcpy((void *)a->n0, pending + E, E * sizeof(int32_t));
@@ -3435,8 +3594,10 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
     if (int rc = bnpc_mt_mh_draws(rng, a->G, M, a->n_sd, h.sd_idx, h.U, h.u))
         return rc;
     memcpy(h.theta, a->old_theta, E * 4);
-    if (int rc = mh_screen_launch(c, 1, a, d)) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned done_seq = 0;
+    const DoneSignal sig = make_signal(c, 0, &done_seq);
+    if (int rc = mh_screen_launch(c, 1, a, d, 0, -1, sig)) return rc;
+    if (int rc = wait_done(c, 0, done_seq)) return rc;
     if (pending) {
         const size_t half = (size_t)2 * M * sizeof(int32_t);
         memcpy(n1, pending, half);
@@ -3548,7 +3709,10 @@ extern "C" int bnpc_ll_total_issue(bnpc_ctx *c, const float *theta, int64_t K,
     const int *n0 = n1 + (size_t)K * c->M;
     hipLaunchKernelGGL(k_ll_total, dim3(blocks), dim3(256), 0, c->stream,
                        d_theta, n1, n0, KM, E, fp[0], fn[0], fp[1], fn[1],
-                       fp[2], fn[2], fp[3], fn[3], (double *)d_part);
+                       fp[2], fn[2], fp[3], fn[3], (double *)d_part,
+                       in_place ? make_signal(c, 2, &c->total_seq)
+                                : DoneSignal{nullptr, nullptr, 0});
+    if (!in_place) c->total_seq = 0;
     HIPCHK(hipGetLastError());
     if (!in_place)
         HIPCHK(hipMemcpyAsync(c->pin_small, c->partial.p,
@@ -3566,7 +3730,7 @@ extern "C" int bnpc_ll_total_wait(bnpc_ctx *c, double *out)
     ARGCHK(c->total_pending, "no deferred total is pending");
     HIPCHK(hipSetDevice(c->device));
     c->total_pending = false;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int rc = wait_done(c, 2, c->total_seq)) return rc;
     const double *p = (const double *)c->pin_small;
     for (int e = 0; e < c->total_E; e++) {
         double sum = 0.0;
