@@ -242,30 +242,45 @@ def timed_steps(ranks, step_fn, first, last):
     return ranks.max_over_ranks(time.perf_counter() - t0)
 
 
+PMC_FILE = ('profiles', 'r04', 'pmc_final.json')
+
+
 def load_pmc_traffic(kernel_substr):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC
     passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or None.
-    The counters cannot be read from inside this process.  gfx950 correction
-    (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-byte requests of a
-    wide coalesced read at 64 bytes; this kernel's misses are taken by its
-    16-byte-per-lane L2 prefetch stream (the scalar loads behind it hit), so
-    the fetch counter is doubled - which also reproduces the 68 MiB the same
-    launch fetched through scalar loads alone before the prefetch existed
-    (profiles/r03/README.md).  WRITE_SIZE is taken as it reads."""
-    for rel in (('profiles', 'r03', 'pmc_final.json'),
-            ('profiles', 'r02', 'pmc_final.json')):
-        path = os.path.join(ROOT, *rel)
-        try:
-            with open(path) as f:
-                pmc = json.load(f)
-            for name, ctr in pmc.items():
-                if kernel_substr in name:
-                    kib = 2 * ctr['FETCH_SIZE']['mean'] \
-                        + ctr['WRITE_SIZE']['mean']
-                    return int(kib * 1024), os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+    The counters cannot be read from inside this process, so the file must be
+    of THIS build: it carries the digest of the library's sources it was
+    taken with (tools/pmc_collect.py; tools/r04_evidence.sh regenerates it
+    and the bench line in one lease), and a file of another build is refused
+    - `traffic` is then null and `traffic_source` says why.  gfx950
+    correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-byte
+    requests of a wide coalesced read at 64 bytes; the likelihood kernels'
+    misses are taken by their 16-byte-per-lane streams (the L2 prefetch of
+    k_ll8_asm, the table staging of k_ll8_lds), so the fetch counter is
+    doubled (calibrated in round 3 against the same launch with the prefetch
+    off: 68.3 MiB of scalar-stream fetches = 2.02 x 33.8;
+    profiles/r03/README.md).  WRITE_SIZE is taken as it reads."""
+    path = os.path.join(ROOT, *PMC_FILE)
+    rel = os.path.join(*PMC_FILE)
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None, f'no {rel}'
+    from bnpc_amd import build
+    have = (pmc.get('_meta') or {}).get('source_digest')
+    want = build.source_digest()
+    if have != want:
+        return None, (f'{rel} refused: taken with sources {have}, this '
+            f'build is {want} (re-run tools/r04_evidence.sh)')
+    for name, ctr in pmc.items():
+        if name != '_meta' and kernel_substr in name:
+            try:
+                kib = 2 * ctr['FETCH_SIZE']['mean'] + ctr['WRITE_SIZE']['mean']
+            except KeyError:
+                continue
+            return int(kib * 1024), rel
+    return None, f'{rel} has no kernel matching {kernel_substr!r}'
 
 
 def ll_roofline(ctx, rng, N, M, K, reps, traffic=None, traffic_src=None):
@@ -410,6 +425,9 @@ def main():
             if all(p[0] is not None for p in parts):
                 roofline_converged['traffic'] = sum(p[0] for p in parts)
                 roofline_converged['traffic_source'] = parts[0][1]
+            else:
+                roofline_converged['traffic_source'] = \
+                    [p[1] for p in parts if p[0] is None][0]
         for Kc in sorted({10, 64, K_end}):
             r, ev = ll_roofline(ctx, rng, N, M, Kc, max(20, args.kernel_reps))
             extra[f'll_evals_per_s_K{Kc}'] = ev

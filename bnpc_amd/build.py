@@ -37,6 +37,18 @@ def find_hipcc():
     raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over the library's sources and headers:
+    what a measurement file must carry to be taken for the code that is
+    running (bench.py refuses PMC passes of another build)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(SOURCES + HEADERS):
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(TARGET):
         return True

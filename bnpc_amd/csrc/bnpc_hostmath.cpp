@@ -696,8 +696,10 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // a thread per ~12 tasks: waking a parked team costs more than
         // several hundred elements
         // (4 gave 130 against 180 us per update_parameters under the
-        // profiler and nothing on the bench line)
-        const int64_t per = 12;
+        // profiler and nothing on the bench line at config 3, whose batches
+        // leave a dozen tasks; the parts of a config-5 batch leave 50 each
+        // and are bound by this arithmetic: a rank per 4 tasks there)
+        const int64_t per = n_tasks >= 32 ? 4 : 12;
         if (threads > (n_tasks + per - 1) / per)
             threads = (int)((n_tasks + per - 1) / per);
         if (threads < 1) threads = 1;

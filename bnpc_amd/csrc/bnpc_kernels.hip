@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <thread>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -110,6 +111,8 @@ struct Tunables {
 #define ZC_IN_MAX ((int64_t)256 << 10)      // zero-copy inputs / results up to
 #define ZC_OUT_MAX ((int64_t)512 << 10)
 #define MH_SCREEN_MIN 512           // batch entries from which the screen pays
+#define MH_THREADED_MIN 65536       // batch entries from which a helper thread
+                                    // draws and launches ahead of the waits
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
 
@@ -3454,18 +3457,35 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     const size_t E = (size_t)G * M;
     MHPin h, d;
     if (mh_pin_get(c, E, h, d)) return 1;
-    // Two halves in a pipeline (batches of 4 rows and more): the draws of the
-    // second half are taken while the device screens the first, and the host
-    // evaluates what the first screen left while the second one runs.
-    const int parts = (G >= 4 && counts_src == 0) ? 2 : 1;
-    const int64_t cut[3] = {0, parts == 2 ? (G + 1) / 2 : G, G};
+    // Parts in a pipeline (batches of 4 rows and more): the draws of part
+    // p + 1 are taken while the device screens part p, and the host evaluates
+    // what a screen left while the next one runs.  Two halves for the batches
+    // of a config-3 step; a LARGE batch (configs 4 and 5: 40 000 - 250 000
+    // entries, two thirds of a millisecond of draws) is cut into up to 8
+    // parts whose draws, staging and screen launches are made by a helper
+    // thread while this one waits for the completion words and evaluates the
+    // leftovers part by part - the stream is consumed in the same order by
+    // the one thread that touches it.
+    static const bool done_words_off = [] {
+        const char *e = getenv("BNPC_DONE_WORDS");
+        return e && e[0] == '0';
+    }();
+    const bool threaded = rng && !done_words_off && G >= 4 && counts_src == 0
+        && E >= MH_THREADED_MIN;
+    int parts = (G >= 4 && counts_src == 0) ? 2 : 1;
+    if (threaded)
+        parts = (int)std::max<int64_t>(2, std::min<int64_t>(
+            std::min<int64_t>(8, G), (int64_t)(E / (MH_THREADED_MIN / 2))));
+    int64_t cut[9];
+    for (int p = 0; p <= parts; p++) cut[p] = G * p / parts;
     for (int p = 0; p < 2; p++)
         if (!c->mh_ev[p])
             HIPCHK(hipEventCreateWithFlags(&c->mh_ev[p],
                                            hipEventDisableTiming));
     SideLane lane(c);
-    unsigned done_seq[2] = {0, 0};
-    for (int p = 0; p < parts; p++) {
+    unsigned done_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // draws + staging + launch of one part (either thread)
+    auto issue_part = [&](int p) -> int {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M, n = (size_t)Gp * M;
         if (rng) {
@@ -3478,10 +3498,46 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
             memcpy(h.sd_idx + at, a->sd_idx + at, n * 4);
         }
         memcpy(h.theta + at, a->old_theta + at, n * 4);
-        const DoneSignal sig = make_signal(c, p, &done_seq[p]);
+        // (one word for all parts: the launches of a stream finish in order)
+        const DoneSignal sig = make_signal(c, threaded ? 0 : p, &done_seq[p]);
         if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp, sig))
             return rc;
-        if (!done_seq[p]) HIPCHK(hipEventRecord(c->mh_ev[p], c->stream));
+        if (!done_seq[p]) HIPCHK(hipEventRecord(c->mh_ev[p & 1], c->stream));
+        return 0;
+    };
+    std::atomic<int> issued(0);     // parts issued so far; -1: the helper failed
+    char helper_err[512] = "";
+    std::thread helper;
+    struct Joiner {
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } joiner{helper};
+    if (threaded) {
+        helper = std::thread([&]() {
+            if (hipSetDevice(c->device) != hipSuccess) {
+                snprintf(helper_err, sizeof helper_err, "hipSetDevice failed "
+                         "in the batch's helper thread");
+                issued.store(-1, std::memory_order_release);
+                return;
+            }
+            for (int p = 0; p < parts; p++) {
+                if (issue_part(p)) {
+                    snprintf(helper_err, sizeof helper_err, "%s",
+                             bnpc_last_error());
+                    issued.store(-1, std::memory_order_release);
+                    return;
+                }
+                issued.store(p + 1, std::memory_order_release);
+            }
+        });
+    } else {
+        for (int p = 0; p < parts; p++) {
+            if (int rc = issue_part(p)) return rc;
+            issued.store(p + 1, std::memory_order_release);
+        }
     }
     if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
     int64_t kept = 0;
@@ -3489,10 +3545,21 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     for (int p = 0; p < parts; p++) {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M;
+        for (int spins = 0;; spins++) {
+            const int got = issued.load(std::memory_order_acquire);
+            if (got < 0) {
+                bnpc_set_error("%s", helper_err);
+                return 1;
+            }
+            if (got > p) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
         if (done_seq[p]) {
-            if (int rc = wait_done(c, p, done_seq[p])) return rc;
+            if (int rc = wait_done(c, threaded ? 0 : p, done_seq[p])) return rc;
         } else {
-            HIPCHK(hipEventSynchronize(c->mh_ev[p]));
+            HIPCHK(hipEventSynchronize(c->mh_ev[p & 1]));
         }
         if (pending) {          // the counts were written before the screen
             memcpy((void *)a->n1, pending, E * sizeof(int32_t));

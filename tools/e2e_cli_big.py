@@ -2,7 +2,8 @@
 """End-to-end CLI run at a large shape on one GPU box (dev tool): writes a
 synthetic matrix in the reference's text format, runs run_BnpC.py with several
 chains through the fork pool, all three estimators, and reports timings.
-usage: e2e_cli_big.py N M C chains steps [estimators...]"""
+usage: [E2E_FLAGS="-smp 0.5 -sms 5"] e2e_cli_big.py N M C chains steps
+       [estimators...]   (E2E_FLAGS: further CLI flags, e.g. config 5's moves)"""
 import os
 import subprocess
 import sys
@@ -37,7 +38,8 @@ for attempt in ('first run (text scanned, bit-plane file written)',
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'run_BnpC.py'),
         path, '-n', str(chains), '-s', str(steps), '--seed', '1', '-np', '-o',
-        out, '-e', *(sys.argv[6:] or ['posterior', 'ML', 'MAP'])],
+        out, *os.environ.get('E2E_FLAGS', '').split(), '-e',
+        *(sys.argv[6:] or ['posterior', 'ML', 'MAP'])],
         capture_output=True, text=True)
     print(f'== {attempt}')
     print(r.stdout[-1500:])

@@ -30,6 +30,12 @@ for f in files:
             acc.setdefault(name, {}).setdefault(ctr, []).append(val)
 summary = {k: {c: {'launches': len(v), 'mean': sum(v) / len(v), 'max': max(v)}
     for c, v in sorted(ctrs.items())} for k, ctrs in sorted(acc.items())}
+# which build the counters belong to (bench.py refuses another one's)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bnpc_amd import build as _build  # noqa: E402
+summary['_meta'] = {'source_digest': _build.source_digest(),
+    'command': 'rocprofv3 --pmc <counter> -- python3 bench.py --steps 20 '
+        '--warmup 5 --cpu-steps 0 (one pass per counter set)'}
 with open(out, 'w') as fh:
     json.dump(summary, fh, indent=1)
 print(f'{len(files)} file(s), {len(summary)} kernels -> {out}')
