@@ -153,7 +153,8 @@ PHASE_ASSIGN, PHASE_ALPHA, PHASE_PARAMS, PHASE_ERRORS, PHASE_RECORD = range(5)
 NEED_NONE, NEED_MOVE, NEED_GIBBS, NEED_PARAMS, NEED_ERRORS, NEED_RECORD = \
     range(6)
 STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
-    'merge_rejected', 'dp_alpha', 'parameters', 'error_rates', 'record')
+    'merge_rejected', 'dp_alpha', 'parameters', 'error_rates', 'record',
+    'gibbs_waits_for_device')
 
 
 # the version bnpc_abi_version() of a matching library reports (bumped with

@@ -214,6 +214,12 @@ struct bnpc_ctx {
     int total_slot = -1;
     DoneSignal sig_next = {nullptr, nullptr, 0};    // for the last kernel of
     bool sig_attached = false;                      // the next issue_ll
+    // bnpc_view_set's own pinned cell list (N entries) and the event that
+    // says the last gather has read it
+    void *view_cells_pin = nullptr;
+    const long long *view_cells_dev = nullptr;
+    hipEvent_t view_cells_read = nullptr;
+    bool view_cells_busy = false;
     bool total_pending = false;     // a deferred bnpc_ll_total_issue
     int total_blocks = 0, total_E = 0;
     // where the kernels of the current call read their inputs from: device
@@ -2084,6 +2090,8 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->view_cells_pin) (void)hipHostFree(c->view_cells_pin);
+    if (c->view_cells_read) (void)hipEventDestroy(c->view_cells_read);
     if (c->done_pin) (void)hipHostFree(c->done_pin);
     if (c->done_count) (void)hipFree(c->done_count);
     DevBuf *bufs[] = {&c->theta, &c->tabs, &c->tab_in, &c->out, &c->cells,
@@ -2174,6 +2182,37 @@ extern "C" int bnpc_view_set(bnpc_ctx *c, int view, const int64_t *cells,
     if (n == 0) {
         c->views[view].n = 0;
         c->views[view].nblk = 0;
+        return 0;
+    }
+    // The cell list travels through a pinned buffer of its own (N entries,
+    // read in place by the gather kernel), so the call returns without
+    // waiting for the device: what uses the view is queued behind the gather
+    // on the same stream, and the buffer is only written again once the
+    // gather that read it last has finished (an event; it has, long since,
+    // in a split / merge move: a 12 us wait per move otherwise).
+    if (!c->view_cells_pin) {
+        void *pin = nullptr, *dev = nullptr;
+        if (hipHostMalloc(&pin, (size_t)c->N * sizeof(long long),
+                          hipHostMallocDefault) == hipSuccess
+            && hipHostGetDevicePointer(&dev, pin, 0) == hipSuccess
+            && hipEventCreateWithFlags(&c->view_cells_read,
+                                       hipEventDisableTiming) == hipSuccess) {
+            c->view_cells_pin = pin;
+            c->view_cells_dev = (const long long *)dev;
+        } else {
+            (void)hipGetLastError();
+            if (pin) (void)hipHostFree(pin);
+        }
+    }
+    if (c->view_cells_pin && n <= c->N && !c->any_tile_pending()) {
+        if (c->view_cells_busy) {
+            HIPCHK(hipEventSynchronize(c->view_cells_read));
+            c->view_cells_busy = false;
+        }
+        memcpy(c->view_cells_pin, cells, n * sizeof(long long));
+        if (build_view(c, view, c->view_cells_dev, n)) return 1;
+        HIPCHK(hipEventRecord(c->view_cells_read, c->stream));
+        c->view_cells_busy = true;
         return 0;
     }
     if (arena_reset(c)) return 1;

@@ -294,7 +294,16 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
     w.scratch.resize((size_t)2 * (ld + 1));
     w.born.resize((size_t)N);
-    rc = bnpc_hints_wait(ctx);
+    {
+        // how long the sweep waits for its evaluation (tables, sums, combine,
+        // hint: four launches) once the visiting order and its state are
+        // ready - the part of the device's work that is NOT hidden
+        const Clock::time_point t0 = Clock::now();
+        rc = bnpc_hints_wait(ctx);
+        ch->clock_ns[9] += std::chrono::duration_cast<
+            std::chrono::nanoseconds>(Clock::now() - t0).count();
+        ch->clock_calls[9]++;
+    }
     if (rc) return rc;
 
     bnpc_gibbs_state st;

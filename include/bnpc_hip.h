@@ -815,7 +815,8 @@ typedef struct bnpc_chain {
     int64_t swept, hint_used, pair_used, triple_used, native_moves, steps;
     /* wall time by part of the step, ns / calls: 0 Gibbs, 1 split accepted,
      * 2 split rejected, 3 merge accepted, 4 merge rejected, 5 DP alpha,
-     * 6 parameters, 7 error rates, 8 record, 9 unused */
+     * 6 parameters, 7 error rates, 8 record, 9 of 0: the sweep waiting for
+     * the device's evaluation after its own preparations */
     int64_t clock_ns[BNPC_STEP_CLOCKS], clock_calls[BNPC_STEP_CLOCKS];
     void *work;                 /* bnpc_chain_open / bnpc_chain_close */
 } bnpc_chain;
