@@ -593,137 +593,139 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             bnpc_set_error("bad argument: a screened batch brings its draws");
             return 2;
         }
-        static thread_local std::vector<int32_t> todo, sure, miss;
-        static thread_local std::vector<int64_t> todo_at, sure_at, miss_at;
-        todo.clear();
-        sure.clear();
-        miss.clear();
-        todo_at.assign(G + 1, 0);
-        sure_at.assign(G + 1, 0);
-        miss_at.assign(G + 1, 0);
         const bool want_prior = a->prior_out && !a->uniform_prior;
         // One pass per row used to touch every element (copy, cache compare,
-        // branch on its flag: 4 ns each, half a millisecond per 125 000 - the
-        // largest single piece of a config-5 batch and a quarter of a
-        // config-3 one).  Now: the declined majority by block copies, the
-        // flagged minority found eight flags at a time, the cache misses by a
-        // compare that all but never fires.
-        for (int64_t g = 0; g < G; g++) {
-            const size_t row = (size_t)g * M;
-            const uint8_t *sc = a->screen + row;
-            const float *old = a->old_theta + row;
-            float *out = a->new_theta + row;
-            memcpy(out, old, (size_t)M * sizeof(float));
-            int64_t flagged = 0;
-            int64_t m = 0;
-            for (; m + 8 <= M; m += 8) {
+        // branch on its flag: 4 ns each); then the declined majority went by
+        // block copies, the flagged minority was found eight flags at a time
+        // and the cache misses by a compare that all but never fires - 2.4 ns
+        // each, but still ONE thread's pass in front of the team's arithmetic:
+        // 83 of the 135 us of a 7 x 5000 part of a config-5 batch.  Now the
+        // team does both: a task is a SEGMENT of a row - its copies, its
+        // compare, its flags, and the exact arithmetic of what it finds
+        // flagged (lists on the stack, no shared list, no second phase).
+        constexpr int64_t SEG = 256;
+        // how many elements are flagged (what the thread count goes by): eight
+        // flags at a time
+        int64_t flagged_all = 0;
+        {
+            const uint8_t *sc = a->screen;
+            const int64_t E = G * M;
+            int64_t e = 0;
+            for (; e + 8 <= E; e += 8) {
                 uint64_t w;
-                memcpy(&w, sc + m, 8);
+                memcpy(&w, sc + e, 8);
                 if (!w) continue;
-                for (int b = 0; b < 8; b++) {
-                    const uint8_t f = sc[m + b];
-                    if (f) {
-                        (f == 2 ? sure : todo).push_back((int32_t)(m + b));
-                        flagged++;
-                    }
-                }
+                // (the high bit of every non-zero byte)
+                w = (((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w)
+                    & 0x8080808080808080ull;
+                flagged_all += __builtin_popcountll(w);
             }
-            for (; m < M; m++) {
-                if (sc[m]) {
-                    (sc[m] == 2 ? sure : todo).push_back((int32_t)m);
-                    flagged++;
-                }
-            }
-            if (want_prior) {
-                if (a->known_theta) {
-                    // entries whose cached parameter has the bits of the old
-                    // one take the cached density; the others (declined ones
-                    // only: the flagged get theirs from the evaluation) are
-                    // evaluated
-                    memcpy(a->prior_out + row, a->known_prior + row,
-                           (size_t)M * sizeof(double));
-                    // (64 bytes at a time: nearly every entry of a running
-                    // chain is a hit - a compare per element was 1 ns each,
-                    // a quarter of a millisecond per config-5 batch)
-                    const float *kt = a->known_theta + row;
-                    int64_t i = 0;
-                    for (; i + 16 <= M; i += 16) {
-                        if (!memcmp(kt + i, old + i, 64)) continue;
-                        for (int64_t j = i; j < i + 16; j++)
-                            if (memcmp(kt + j, old + j, 4) && !sc[j])
-                                miss.push_back((int32_t)j);
-                    }
-                    for (; i < M; i++)
-                        if (memcmp(kt + i, old + i, 4) && !sc[i])
-                            miss.push_back((int32_t)i);
-                } else {
-                    for (int64_t i = 0; i < M; i++)
-                        if (!sc[i]) miss.push_back((int32_t)i);
-                }
-            } else if (a->prior_out) {
-                // uniform prior: the density is 0 everywhere
-                memset(a->prior_out + row, 0, (size_t)M * sizeof(double));
-            }
-            a->declined[g] = M - flagged;
-            todo_at[g + 1] = (int64_t)todo.size();
-            sure_at[g + 1] = (int64_t)sure.size();
-            miss_at[g + 1] = (int64_t)miss.size();
+            for (; e < E; e++) flagged_all += sc[e] != 0;
         }
-        // tasks: runs of <= 64 flagged elements of one row, then runs of
-        // <= 256 prior-cache misses of one row
-        struct Task {
-            int64_t g, lo, hi;
-            int kind;           // 0 in doubt, 1 accepted for certain, 2 prior
-        };
-        static thread_local std::vector<Task> tasks;
-        tasks.clear();
-        for (int64_t g = 0; g < G; g++)
-            for (int64_t lo = todo_at[g]; lo < todo_at[g + 1]; lo += BLK / 2)
-                tasks.push_back({g, lo, std::min(lo + BLK / 2,
-                                                 todo_at[g + 1]), 0});
-        for (int64_t g = 0; g < G; g++)
-            for (int64_t lo = sure_at[g]; lo < sure_at[g + 1]; lo += BLK / 2)
-                tasks.push_back({g, lo, std::min(lo + BLK / 2,
-                                                 sure_at[g + 1]), 1});
-        for (int64_t g = 0; g < G; g++)
-            for (int64_t lo = miss_at[g]; lo < miss_at[g + 1]; lo += 2 * BLK)
-                tasks.push_back({g, lo, std::min(lo + 2 * BLK,
-                                                 miss_at[g + 1]), 2});
-        const int64_t n_tasks = (int64_t)tasks.size();
-        const Task *tk = tasks.data();
-        const int32_t *todo_p = todo.data(), *miss_p = miss.data();
-        const int32_t *sure_p = sure.data();
-        // a thread per ~12 tasks: waking a parked team costs more than
-        // several hundred elements
+        const int64_t segs = (M + SEG - 1) / SEG;
+        const int64_t n_tasks = G * segs;
+        // a thread per ~12 blocks of 64 flagged elements: waking a parked
+        // team costs more than several hundred elements
         // (4 gave 130 against 180 us per update_parameters under the
         // profiler and nothing on the bench line at config 3, whose batches
-        // leave a dozen tasks; the parts of a config-5 batch leave 50 each
-        // and are bound by this arithmetic: a rank per 4 tasks there)
-        const int64_t per = n_tasks >= 32 ? 4 : 12;
-        if (threads > (n_tasks + per - 1) / per)
-            threads = (int)((n_tasks + per - 1) / per);
+        // leave a dozen blocks; the parts of a config-5 batch leave 50 each
+        // and are bound by this arithmetic: a rank per 4 blocks there)
+        const int64_t blocks = (flagged_all + BLK / 2 - 1) / (BLK / 2);
+        const int64_t per = blocks >= 32 ? 4 : 12;
+        if (threads > (blocks + per - 1) / per)
+            threads = (int)((blocks + per - 1) / per);
+        if (threads > n_tasks) threads = (int)n_tasks;
         if (threads < 1) threads = 1;
-        std::atomic<int64_t> next(0);
+        std::atomic<int64_t> next(0), n_todo(0), n_sure(0), n_miss(0);
         auto work = [&](int) {
+            int32_t todo[SEG], sure[SEG];
             for (;;) {
                 const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
                 if (t >= n_tasks) break;
                 if (bail.load(std::memory_order_relaxed)) continue;
-                const Task &q = tk[t];
-                if (q.kind == 2) {
-                    const size_t row = (size_t)q.g * M;
-                    for (int64_t j = q.lo; j < q.hi; j++) {
-                        const int32_t m = miss_p[j];
-                        a->prior_out[row + m] = beta_logpdf1(k,
-                            a->old_theta[row + m], a->p, a->q, c.betaln_pq);
+                const int64_t g = t / segs, m0 = (t - g * segs) * SEG;
+                const int64_t m1 = std::min(M, m0 + SEG);
+                const size_t row = (size_t)g * M;
+                const uint8_t *sc = a->screen + row;
+                const float *old = a->old_theta + row;
+                float *out = a->new_theta + row;
+                memcpy(out + m0, old + m0, (size_t)(m1 - m0) * sizeof(float));
+                int nt = 0, ns = 0;
+                int64_t m = m0;
+                for (; m + 8 <= m1; m += 8) {
+                    uint64_t w;
+                    memcpy(&w, sc + m, 8);
+                    if (!w) continue;
+                    for (int b = 0; b < 8; b++) {
+                        const uint8_t f = sc[m + b];
+                        if (f == 2) sure[ns++] = (int32_t)(m + b);
+                        else if (f) todo[nt++] = (int32_t)(m + b);
                     }
-                } else if (!mh_block(k, a, c, q.g,
-                                     (q.kind ? sure_p : todo_p) + q.lo, 0,
-                                     (int)(q.hi - q.lo), q.kind == 1)) {
-                    bail.store(1, std::memory_order_relaxed);
+                }
+                for (; m < m1; m++) {
+                    if (sc[m] == 2) sure[ns++] = (int32_t)m;
+                    else if (sc[m]) todo[nt++] = (int32_t)m;
+                }
+                int64_t missed = 0;
+                if (want_prior) {
+                    double *po = a->prior_out + row;
+                    if (a->known_theta) {
+                        // entries whose cached parameter has the bits of the
+                        // old one take the cached density; the others
+                        // (declined ones only: the flagged get theirs from
+                        // the evaluation) are evaluated.  64 bytes at a time:
+                        // nearly every entry of a running chain is a hit.
+                        memcpy(po + m0, a->known_prior + row + m0,
+                               (size_t)(m1 - m0) * sizeof(double));
+                        const float *kt = a->known_theta + row;
+                        int64_t i = m0;
+                        for (; i + 16 <= m1; i += 16) {
+                            if (!memcmp(kt + i, old + i, 64)) continue;
+                            for (int64_t j = i; j < i + 16; j++)
+                                if (memcmp(kt + j, old + j, 4) && !sc[j]) {
+                                    po[j] = beta_logpdf1(k, old[j], a->p,
+                                                         a->q, c.betaln_pq);
+                                    missed++;
+                                }
+                        }
+                        for (; i < m1; i++)
+                            if (memcmp(kt + i, old + i, 4) && !sc[i]) {
+                                po[i] = beta_logpdf1(k, old[i], a->p, a->q,
+                                                     c.betaln_pq);
+                                missed++;
+                            }
+                    } else {
+                        for (int64_t i = m0; i < m1; i++)
+                            if (!sc[i]) {
+                                po[i] = beta_logpdf1(k, old[i], a->p, a->q,
+                                                     c.betaln_pq);
+                                missed++;
+                            }
+                    }
+                } else if (a->prior_out) {
+                    // uniform prior: the density is 0 everywhere
+                    memset(a->prior_out + row + m0, 0,
+                           (size_t)(m1 - m0) * sizeof(double));
+                }
+                __atomic_fetch_add(&a->declined[g],
+                                   (int64_t)(m1 - m0 - nt - ns),
+                                   __ATOMIC_RELAXED);
+                bool ok = true;
+                for (int lo = 0; lo < nt && ok; lo += BLK / 2)
+                    ok = mh_block(k, a, c, g, todo + lo, 0,
+                                  std::min(BLK / 2, nt - lo), false);
+                for (int lo = 0; lo < ns && ok; lo += BLK / 2)
+                    ok = mh_block(k, a, c, g, sure + lo, 0,
+                                  std::min(BLK / 2, ns - lo), true);
+                if (!ok) bail.store(1, std::memory_order_relaxed);
+                if (trace) {
+                    n_todo.fetch_add(nt, std::memory_order_relaxed);
+                    n_sure.fetch_add(ns, std::memory_order_relaxed);
+                    n_miss.fetch_add(missed, std::memory_order_relaxed);
                 }
             }
         };
+        const long t_prep = trace ? since() : 0;
         if (threads > 1)
             team_for(threads)->run(threads, work);
         else
@@ -731,11 +733,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         if (trace)
             fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld in doubt, "
                     "%lld accepted of %lld elements, %lld prior misses, "
-                    "threads=%d, %.1f us\n",
-                    (long long)G, (long long)M, (long long)todo.size(),
-                    (long long)sure.size(),
-                    (long long)(G * M), (long long)miss.size(), threads,
-                    since() / 1e3);
+                    "threads=%d, %.1f us (counting the flags %.1f)\n",
+                    (long long)G, (long long)M, (long long)n_todo.load(),
+                    (long long)n_sure.load(),
+                    (long long)(G * M), (long long)n_miss.load(), threads,
+                    since() / 1e3, t_prep / 1e3);
         if (bail.load()) {
             *status = 1;
             return 0;

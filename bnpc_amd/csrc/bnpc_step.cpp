@@ -265,13 +265,20 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         }
         w.col_prior[g] = ch->crp_prior[ch->sizes[g]];
     }
+    static const bool trace_g = [] {
+        const char *e = getenv("BNPC_TIMING");
+        return e && strstr(e, "gibbs");
+    }();
+    const Clock::time_point tg0 = Clock::now();
     gather_rows(ch, w);
+    const Clock::time_point tg1 = Clock::now();
     double *ll = nullptr;
     bnpc_top2 *top2 = nullptr;
     int rc = bnpc_ll_theta_pinned_top2_issue(ctx, 0, w.rows.data(), K, FP, FN,
                                              ld, w.col_prior.data(), &ll,
                                              &top2);
     if (rc) return rc;
+    const Clock::time_point tg2 = Clock::now();
     // under the launch: the visiting order and the sweep's private state
     w.perm.resize((size_t)N);
     mt_fill_permutation(rng, N, w.perm.data());
@@ -294,6 +301,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
     w.scratch.resize((size_t)2 * (ld + 1));
     w.born.resize((size_t)N);
+    const Clock::time_point tg3 = Clock::now();
     {
         // how long the sweep waits for its evaluation (tables, sums, combine,
         // hint: four launches) once the visiting order and its state are
@@ -305,6 +313,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         ch->clock_calls[9]++;
     }
     if (rc) return rc;
+    const Clock::time_point tg4 = Clock::now();
 
     bnpc_gibbs_state st;
     memset(&st, 0, sizeof st);
@@ -378,6 +387,17 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         if (rc) return rc;
         w.rows_current = false;
         st.new_cell = -1;
+    }
+    if (trace_g) {
+        auto us = [](Clock::time_point a, Clock::time_point b) {
+            return std::chrono::duration_cast<std::chrono::nanoseconds>(
+                b - a).count() / 1e3;
+        };
+        fprintf(stderr, "[gibbs] N=%lld K=%lld: rows "
+                "%.1f, issue %.1f, order + state %.1f, wait %.1f, loop %.1f "
+                "us\n", (long long)N, (long long)K,
+                us(tg0, tg1), us(tg1, tg2), us(tg2, tg3), us(tg3, tg4),
+                us(tg4, Clock::now()));
     }
     // commit: the live clusters in dict order, the new labels
     for (int64_t a = 0; a < st.n_active; a++) {
@@ -513,8 +533,15 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const int64_t K = ch->K, M = ch->M;
     if (K < 1 || K > 64) return 0;
     const size_t E = (size_t)K * M;
+    static const bool trace_p = [] {
+        const char *e = getenv("BNPC_TIMING");
+        return e && strstr(e, "params");
+    }();
+    const Clock::time_point tp0 = Clock::now();
     gather_rows(ch, w);
+    const Clock::time_point tp1 = Clock::now();
     const bool stale = !counts_current(ctx, ch, w);
+    const Clock::time_point tp2 = Clock::now();
     w.n1.resize(E);
     w.n0.resize(E);
     w.fresh.resize(E);
@@ -558,6 +585,7 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     a.declined = w.declined.data();
     a.threads = team_for(ch, (int64_t)E);
     const Snapshot before(rng, (bnpc_legacy_gauss *)ch->gauss);
+    const Clock::time_point tp3 = Clock::now();
     int sub = 0, rc;
     if (stale) {
         w.lab_set = false;
@@ -573,6 +601,7 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         before.put_back(rng, (bnpc_legacy_gauss *)ch->gauss);
         return 0;
     }
+    const Clock::time_point tp4 = Clock::now();
     int64_t declined = 0;
     for (int64_t g = 0; g < K; g++) {
         memcpy(ch->parameters + (size_t)ch->ids[g] * ch->param_stride,
@@ -591,6 +620,16 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
     ch->par_declined = declined;
     ch->par_accepted = (int64_t)E - declined;
+    if (trace_p) {
+        auto us = [](Clock::time_point a, Clock::time_point b) {
+            return std::chrono::duration_cast<std::chrono::nanoseconds>(
+                b - a).count() / 1e3;
+        };
+        fprintf(stderr, "[params] K=%lld stale=%d: rows %.1f, counts current? "
+                "%.1f, buffers + cached prior %.1f, batch %.1f, results %.1f "
+                "us\n", (long long)K, (int)stale, us(tp0, tp1), us(tp1, tp2),
+                us(tp2, tp3), us(tp3, tp4), us(tp4, Clock::now()));
+    }
     *done = true;
     return 0;
 }
