@@ -102,9 +102,6 @@ struct Tunables {
                                     // mask-popcount counts (tests lower it)
     int mh_screen = 1;              // BNPC_MH_SCREEN: device screen of the
                                     // parameter batches
-    int fold = 1;                   // BNPC_LL_FOLD: small evaluations in one
-                                    // launch (k_ll8_fold); 0: the split sums
-                                    // + combine (+ hint) launches
 };
 
 #define MSPLIT_MAX 64               // chunks of a split launch at most
@@ -118,9 +115,6 @@ struct Tunables {
                                     // draws and launches ahead of the waits
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
-#define FOLD_MAX_BLOCKS 512         // k_ll8_fold: slot blocks (a workgroup of 16
-                                    // waves each, one per CU) up to which the
-                                    // one-launch evaluation is used
 
 static int env_int(const char *name, int dflt)
 {
@@ -138,7 +132,6 @@ static void read_tunables(Tunables &t)
     t.zero_copy = env_int("BNPC_ZERO_COPY", 1);
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
-    t.fold = env_int("BNPC_LL_FOLD", 1);
 }
 
 #define DONE_SLOTS 3     // 0, 1: the launches of a call; 2: the deferred total
@@ -221,14 +214,6 @@ struct bnpc_ctx {
     int total_slot = -1;
     DoneSignal sig_next = {nullptr, nullptr, 0};    // for the last kernel of
     bool sig_attached = false;                      // the next issue_ll
-    // the hint the next evaluation may write itself (k_ll8_fold<true>):
-    // priors, the records' and the rows' pinned addresses as the device sees
-    // them; fold_hint_done: it did
-    const double *fold_prior = nullptr;
-    void *fold_hint = nullptr, *fold_rows = nullptr;
-    bool fold_hint_done = false;
-    bool fold_now = false;          // ll_common -> issue_ll: the one-launch form
-    int fold_chunk = 0;
     // bnpc_view_set's own pinned cell list (N entries) and the event that
     // says the last gather has read it
     void *view_cells_pin = nullptr;
@@ -1313,201 +1298,6 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
 }
 
 // ---------------------------------------------------------------------------
-// K2f: the SMALL evaluation in one launch (a converged sweep: K ~ 10-60 over
-// all cells; a restricted-Gibbs scan: 2-3 clusters over the cells of two).
-// The split form above leaves ceil(MS / 4) partial planes to k_ll_combine and
-// the sweep's hint to k_row_top2: three dependent launches, 23.5 MB of counter
-// traffic for 1.7 MB of algorithmic bytes at 5000 x 1000 x 14 (11 planes
-// written, re-read, the matrix re-read for the hint).  Here ONE workgroup of
-// 16 waves owns a slot block for ALL mutation chunks and ALL cluster groups:
-//   wave w sums chunk w (m_chunk mutations, the hand-placed step of
-//   k_ll8_asm) for one cluster group at a time; the 16 chunk sums of a group
-//   meet in LDS and are added IN WAVE ORDER (a fixed tree: the bits do not
-//   depend on timing), 8 waves a column each; the group's final sums stay in
-//   LDS until every group is done; then the workgroup writes its 64 rows of
-//   the matrix and - HINT - wave 0 derives the rows' hint records from the
-//   LDS copy (the arithmetic of k_row_top2, priors as kernel arguments),
-//   written in place into pinned host memory with the rows the sweep will
-//   have to scan.
-// No partial planes, no combine pass, no hint pass; the masks are read once
-// per cluster group from the scalar cache.  Global stores come after the last
-// load (the scalar loads of the mutation loop stay scalar).
-// ---------------------------------------------------------------------------
-struct Top2Prior {                  // the priors of a hint pass, by value
-    double v[64];
-};
-
-#define FOLD_WAVES 16
-#define FOLD_FIN_LD 65              // doubles per column of the final sums
-#define FOLD_LDS ((FOLD_WAVES * 8 * 64 + 64 * FOLD_FIN_LD) * sizeof(double))
-
-template <bool HINT>
-__global__ __launch_bounds__(1024) void k_ll8_fold(
-    const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
-    long long nblk, const double *__restrict__ T, int K, long long ldo,
-    double *__restrict__ out, int m_chunk, const ulonglong2 *masks_pf,
-    const double *T_pf, Top2Prior prior, bnpc_top2 *__restrict__ hint,
-    double *__restrict__ host_ll, DoneSignal done)
-{
-    constexpr int KW = 8;
-    extern __shared__ double fold_lds[];
-    double (*red)[KW][64] = (double (*)[KW][64])fold_lds;
-    double (*fin)[FOLD_FIN_LD] =
-        (double (*)[FOLD_FIN_LD])(fold_lds + FOLD_WAVES * KW * 64);
-    const bool PF = T_pf != nullptr;
-    const bool PFM = masks_pf != nullptr;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const long long blk = blockIdx.x;           // grid = slot blocks
-    const int G = (K + KW - 1) / KW;
-    const int m_begin = wave * m_chunk;
-    const int m_len = m_begin >= Mt ? 0
-        : ((m_begin + m_chunk < Mt) ? m_chunk : Mt - m_begin);
-    const size_t mo = (size_t)blk * Mpad + (m_len > 0 ? m_begin : 0);
-
-    typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));
-    pf_u32x4 pf_sink = {0u, 0u, 0u, 0u};
-    // (the masks' lines by an ordinary load whose value is folded into a word
-    // that is looked at once, after the sums: nothing waits for it earlier)
-    unsigned long long pf_masks = 0ull;
-    const unsigned pf_lo = (unsigned)lane * 16u, pf_hi = pf_lo + 4096u;
-    // (see k_ll8_asm: vector loads into a register nobody reads pull the next
-    // 64 mutations' masks and table stages into the L2 ahead of the scalar
-    // loads)
-#define PF_TAB(MP, I, OFF, IMM)                                               \
-    if ((MP) + 8 * (I) < m_len)                                               \
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM            \
-                     : "+v"(pf_sink) : "v"(OFF), "s"(t64_));
-#define PF_BLOCK(MP, MASKS_TOO)                                               \
-    {                                                                         \
-        if (PFM && (MASKS_TOO) && m_begin + (MP) + lane < Mpad)              \
-            pf_masks ^= masks_pf[mo + (MP) + lane].x;                         \
-        const double *t64_ = T_pf + t_off + (size_t)(MP) * 16;                \
-        PF_TAB(MP, 0, pf_lo, 0) PF_TAB(MP, 1, pf_lo, 1024)                    \
-        PF_TAB(MP, 2, pf_lo, 2048) PF_TAB(MP, 3, pf_lo, 3072)                 \
-        PF_TAB(MP, 4, pf_hi, 0) PF_TAB(MP, 5, pf_hi, 1024)                    \
-        PF_TAB(MP, 6, pf_hi, 2048) PF_TAB(MP, 7, pf_hi, 3072)                 \
-    }
-
-    for (int g = 0; g < G; g++) {
-        const size_t t_off = ((size_t)g * Mt + (m_len > 0 ? m_begin : 0))
-            * (2 * KW);
-        const double *__restrict__ tp = T + t_off;
-        double acc[KW];
-#pragma unroll
-        for (int j = 0; j < KW; j++) acc[j] = 0.0;
-        if (PF && m_len > 0) PF_BLOCK(0, g == 0)
-
-        ulonglong2 ma, mb;
-        double ta[16], tb[16];
-        ma = masks[mo];
-#pragma unroll
-        for (int j = 0; j < 16; j++) ta[j] = tp[j];
-        for (int m = 0; m < m_len; m += 2) {    // chunks are multiples of 8
-            if (PF && (m & 63) == 0 && m + 64 < m_len)
-                PF_BLOCK(m + 64, g == 0)
-            __builtin_amdgcn_s_waitcnt(0xC07F);     // stage A landed
-            mb = masks[mo + m + 1];
-#pragma unroll
-            for (int j = 0; j < 16; j++) tb[j] = tp[16 + j];
-            ll_step8(acc, ma, ta);
-            __builtin_amdgcn_s_waitcnt(0xC07F);     // stage B landed
-            ma = masks[mo + m + 2];
-#pragma unroll
-            for (int j = 0; j < 16; j++) ta[j] = tp[32 + j];
-            ll_step8(acc, mb, tb);
-            tp += 32;
-        }
-        // the 16 chunk sums of this group, added in wave order
-#pragma unroll
-        for (int j = 0; j < KW; j++) red[wave][j][lane] = acc[j];
-        __syncthreads();
-        if (wave < KW) {
-            double s = red[0][wave][lane];
-#pragma unroll
-            for (int w = 1; w < FOLD_WAVES; w++) s += red[w][wave][lane];
-            fin[g * KW + wave][lane] = s;
-        }
-        __syncthreads();
-    }
-#undef PF_BLOCK
-#undef PF_TAB
-    if (PF)     // the sink stays allocated to the end; nothing in flight
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink));
-    // (never true: what keeps the prefetching loads of the masks alive)
-    if (pf_masks == 0x9e3779b97f4a7c15ull && m_chunk < 0) fin[0][lane] = 0.0;
-
-    // the workgroup's 64 rows of the matrix (consecutive threads = consecutive
-    // columns of a row)
-    for (int idx = threadIdx.x; idx < 64 * K; idx += FOLD_WAVES * 64) {
-        const int cell = idx / K, k = idx - cell * K;
-        const long long slot = blk * 64 + cell;
-        if (slot < n) out[(size_t)slot * ldo + k] = fin[k][cell];
-    }
-    if (HINT && wave == 0) {
-        const long long slot = blk * 64 + lane;
-        if (slot < n) {
-            // (k_row_top2, the row read from LDS)
-            double best = -INFINITY, second = -INFINITY, third = -INFINITY;
-            double fourth = -INFINITY;
-            double lb = 0.0, ls = 0.0, lt = 0.0;
-            int col = 0, col2 = -1, col3 = -1;
-            for (int k = 0; k < K; k++) {
-                const double l = fin[k][lane];
-                const double v = l + prior.v[k];
-                if (v > best) {
-                    fourth = third;
-                    third = second;
-                    lt = ls;
-                    col3 = col2;
-                    second = best;
-                    ls = lb;
-                    col2 = best > -INFINITY ? col : -1;
-                    best = v;
-                    lb = l;
-                    col = k;
-                } else if (v > second) {
-                    fourth = third;
-                    third = second;
-                    lt = ls;
-                    col3 = col2;
-                    second = v;
-                    ls = l;
-                    col2 = k;
-                } else if (v > third) {
-                    fourth = third;
-                    third = v;
-                    lt = l;
-                    col3 = k;
-                } else if (v > fourth) {
-                    fourth = v;
-                }
-            }
-            bnpc_top2 t;
-            t.best = best;
-            t.second = second;
-            t.third = third;
-            t.fourth = fourth;
-            t.ll_best = lb;
-            t.ll_second = ls;
-            t.ll_third = lt;
-            t.col = (int16_t)col;
-            t.col2 = (int16_t)col2;
-            t.col3 = (int16_t)col3;
-            int through = 0;
-            if (host_ll && fourth > second - 72.0 && second > best - 48.0) {
-                double *__restrict__ h = host_ll + (size_t)slot * ldo;
-                for (int k = 0; k < K; k++) h[k] = fin[k][lane];
-                through = 1;
-            }
-            t.row_here = (int16_t)through;
-            hint[slot] = t;
-        }
-    }
-    signal_done(done);
-}
-
-// ---------------------------------------------------------------------------
 // K2p: the same sums over CALLER-BUILT tables in strict mutation order - the
 // bit-exact path of CRP._rg_init_split (libs/CRP.py:547-561, whose
 // `ll_j > ll_i` is the one discrete decision on the path) and of the
@@ -1673,6 +1463,10 @@ __global__ __launch_bounds__(256) void k_stage_copy(
 // priors travel as kernel arguments (no memory to fetch them from); the matrix
 // was just written and is read from L2.
 // ---------------------------------------------------------------------------
+struct Top2Prior {
+    double v[64];
+};
+
 __global__ __launch_bounds__(256) void k_row_top2(
     const double *__restrict__ ll, long long n, long long ldo, int K,
     Top2Prior prior, bnpc_top2 *__restrict__ out,
@@ -2564,52 +2358,6 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     const size_t stream_bytes = (size_t)v.nblk * c->Mpad * 16
         + (size_t)G * c->Mt * 2 * KW * sizeof(double) / 8;
     const int pf = stream_bytes > (3u << 20) || MS > 1;
-    if (KW == 8 && c->fold_now) {
-        // the whole small evaluation in one launch (K2f)
-        static bool lds_raised = false;
-        if (!lds_raised) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_ll8_fold<false>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FOLD_LDS));
-            HIPCHK(hipFuncSetAttribute((const void *)k_ll8_fold<true>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)FOLD_LDS));
-            lds_raised = true;
-        }
-        DoneSignal sig = c->sig_next;
-        c->sig_next = DoneSignal{nullptr, nullptr, 0};
-        const int dbg = env_int("BNPC_FOLD_DEBUG", 0);
-        if (dbg & 2) sig = DoneSignal{nullptr, nullptr, 0};
-        const ulonglong2 *pfm = (dbg & 5) ? nullptr : (const ulonglong2 *)v.masks.p;
-        const double *pft = (dbg & 1) ? nullptr : (const double *)c->tabs.p;
-        Top2Prior pr;
-        const bool hinted = c->fold_hint != nullptr && c->fold_prior != nullptr;
-        for (int k = 0; k < 64; k++)
-            pr.v[k] = hinted && k < K ? c->fold_prior[k] : 0.0;
-        if (hinted)
-            hipLaunchKernelGGL(k_ll8_fold<true>, dim3((unsigned)v.nblk),
-                               dim3(FOLD_WAVES * 64), FOLD_LDS, c->stream,
-                               (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,
-                               (long long)v.n, (long long)v.nblk,
-                               (const double *)c->tabs.p, (int)K,
-                               (long long)ldo, d_out, c->fold_chunk,
-                               pfm, pft, pr,
-                               (bnpc_top2 *)c->fold_hint,
-                               (double *)c->fold_rows, sig);
-        else
-            hipLaunchKernelGGL(k_ll8_fold<false>, dim3((unsigned)v.nblk),
-                               dim3(FOLD_WAVES * 64), FOLD_LDS, c->stream,
-                               (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,
-                               (long long)v.n, (long long)v.nblk,
-                               (const double *)c->tabs.p, (int)K,
-                               (long long)ldo, d_out, c->fold_chunk,
-                               pfm, pft, pr,
-                               (bnpc_top2 *)nullptr, (double *)nullptr, sig);
-        HIPCHK(hipGetLastError());
-        c->fold_hint_done = hinted;
-        c->sig_attached = sig.count != nullptr;
-        snprintf(c->last_name, sizeof(c->last_name), "k_ll8_fold<%s>",
-                 hinted ? "true" : "false");
-        return 0;
-    }
     double *dst = d_out;
     // partial planes: the hand-placed kernel sums 4 chunks inside a
     // workgroup (ceil(MS / 4) planes, none for exactly 4), k_ll writes MS
@@ -2813,19 +2561,6 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     int MS, m_chunk;
     pick_msplit(c->tun, v.nblk * ((K + kw - 1) / kw), c->Mt,
                 from_theta && c->tun.msplit, &MS, &m_chunk);
-    // ... or fold them inside one workgroup per slot block (K2f): the launches
-    // that would be split, up to 64 clusters and FOLD_MAX_BLOCKS slot blocks
-    c->fold_now = kw == 8 && from_theta && c->tun.msplit && c->tun.fold
-        && K <= 64 && v.nblk <= FOLD_MAX_BLOCKS
-        && v.nblk * ((K + 7) / 8) < msplit_limit(c->tun);
-    c->fold_hint_done = false;
-    if (c->fold_now) {
-        int chunk = ((c->Mt + FOLD_WAVES - 1) / FOLD_WAVES + 7) / 8 * 8;
-        if (chunk < 8) chunk = 8;
-        c->fold_chunk = chunk;
-        MS = (c->Mt + chunk - 1) / chunk;
-        m_chunk = chunk;
-    }
     double *d_out = zc_host ? (double *)zc_dev : (double *)c->out.p;
     if (c->dst_override) d_out = c->dst_override;
     // a result written in place for the host is waited for through the
@@ -2847,7 +2582,6 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     case 2: rc = launch_ll<2>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
     default: rc = launch_ll<1>(c, v, K, ldo, from_theta, FP, FN, d_out, MS, m_chunk); break;
     }
-    c->fold_now = false;
     if (rc) return rc;
     c->last_ms = MS;
     c->last_mchunk = m_chunk;
@@ -2992,31 +2726,23 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     // did the previous hinted sweep read its matrix?
     c->matrix_eager = c->lazy_fetched;
     c->lazy_fetched = false;
-    // the host's copy of the matrix as the device sees it (rows the sweep is
-    // going to scan are written through with the hints)
-    double *rows_dev = nullptr;
-    if (hint && bytes) {
-        void *pin_dev = nullptr;
-        if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
-            rows_dev = (double *)pin_dev;
-        else
-            (void)hipGetLastError();        // not mapped: no write-through
-        // a small evaluation writes the hints itself (k_ll8_fold<true>)
-        c->fold_prior = col_prior;
-        c->fold_hint = zc_dev;
-        c->fold_rows = rows_dev;
-    }
     int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
-    c->fold_prior = nullptr;
-    c->fold_hint = c->fold_rows = nullptr;
     if (rc) return rc;
     if (bytes == 0) {
         HIPCHK(hipStreamSynchronize(c->stream));
         return 0;
     }
-    if (hint && !c->fold_hint_done) {
+    if (hint) {
         Top2Prior pr;
         for (int k = 0; k < 64; k++) pr.v[k] = k < K ? col_prior[k] : 0.0;
+        // the host's copy of the matrix as the device sees it (rows the
+        // sweep is going to scan are written through by the hint kernel)
+        void *pin_dev = nullptr;
+        double *rows_dev = nullptr;
+        if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
+            rows_dev = (double *)pin_dev;
+        else
+            (void)hipGetLastError();        // not mapped: no write-through
         hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->out.p,
                            (long long)n, (long long)ldo, (int)K, pr,

@@ -1025,57 +1025,6 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
     ctx.close()
 
 
-@pytest.mark.parametrize('N,M', [(1, 1), (63, 7), (65, 64), (700, 130),
-    (5000, 1000), (130, 4097), (2100, 333)])
-def test_small_evaluations_in_one_launch(N, M, monkeypatch):
-    """k_ll8_fold (one workgroup of 16 waves per slot block: all mutation
-    chunks, all cluster groups, the hint) against the split sums + combine +
-    hint launches it replaces (BNPC_LL_FOLD=0) and against the strict-order
-    sums: same values to the last ulp or two of a sum (another fixed
-    summation tree), the same bits on every call, hints that are the top
-    entries of the very matrix returned with them."""
-    rng = np.random.RandomState(N + 7 * M)
-    data = (rng.random_sample((N, M)) < 0.3).astype(float)
-    data[rng.random_sample(data.shape) < 0.2] = np.nan
-    ctx = _lib.Context(data=data)
-    cells = rng.permutation(N)[:max(1, N // 3)]
-    ctx.view_set(1, cells)
-    for K in (2, 8, 9, 14, 33, 64):
-        theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
-            .astype(np.float32)
-        prior = -rng.uniform(0, 9, size=K)
-        L1, L0 = host_tables(theta, .01, .2)
-        strict = table_sums(data, L1, L0)
-        monkeypatch.setenv('BNPC_LL_FOLD', '0')
-        ctx.reload_options()
-        split = ctx.ll_theta(0, theta, .01, .2)
-        split_name = ctx.last_launch()[0]
-        monkeypatch.setenv('BNPC_LL_FOLD', '1')
-        ctx.reload_options()
-        fold = ctx.ll_theta(0, theta, .01, .2)
-        assert ctx.last_launch()[0].startswith('k_ll8_fold'), (K, split_name)
-        assert 'fold' not in split_name
-        np.testing.assert_allclose(fold, strict, rtol=1e-13, atol=1e-12)
-        np.testing.assert_allclose(fold, split, rtol=1e-13, atol=1e-12)
-        assert np.array_equal(fold, ctx.ll_theta(0, theta, .01, .2))
-        # a gathered view: the rows of its cells, bit for bit
-        assert np.array_equal(ctx.ll_theta(1, theta, .01, .2), fold[cells])
-        # the hint written by the same launch
-        ll, hint = ctx.ll_theta_pinned_top2(0, theta, .01, .2, K + 5, prior)
-        assert ctx.last_launch()[0] == 'k_ll8_fold<true>'
-        hint = hint.copy()
-        ctx.matrix_wait()
-        assert np.array_equal(ll[:, :K], fold)
-        want = _lib.hints_from_matrix(ll[:, :K], prior)
-        for name in ('best', 'second', 'third', 'fourth', 'col', 'col2',
-                'col3'):
-            assert np.array_equal(hint[name], want[name]), (K, name)
-        assert np.array_equal(hint['row_here'] == 1,
-            (hint['fourth'] > hint['second'] - 72.0)
-            & (hint['second'] > hint['best'] - 48.0))
-    ctx.close()
-
-
 def test_fused_restricted_scan_changes_nothing(monkeypatch):
     """bnpc_rg_scan_step (device sums + assignment scan + counts + parameter
     batch in one native call) against the same scan made call by call: a
