@@ -47,6 +47,19 @@ double bnpc_legacy_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
 
 // bnpc_kernels.hip: counts of the two launch clusters of a restricted scan +
 // the (screened) parameter batch on one stream synchronisation
+// bnpc_ll_theta in two halves (bnpc_kernels.hip): the caller works between
+// them - bnpc_sm_move draws the third Beta row under the first scan's sums
+int bnpc_ll_theta_begin(bnpc_ctx *c, int view, const float *theta, int64_t K,
+                        double FP, double FN, double *out, int64_t ldo);
+int bnpc_ll_theta_end(bnpc_ctx *c);
+// bnpc_rg_scan_step whose n x 2 log-likelihoods are already there (ll_ready,
+// from bnpc_ll_theta_begin / _end); NULL: evaluated inside
+int bnpc_rg_scan_step_with(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                           bnpc_mt19937 *rng, int view, int64_t n,
+                           int64_t *rg_assignment, double DP_a,
+                           const bnpc_mh_args *mh, int32_t *n1, int32_t *n0,
+                           double *scan_log_prob, int *status,
+                           const double *ll_ready);
 int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
                              bnpc_mt19937 *rng, int view,
                              const int64_t *labels, const bnpc_mh_args *a,

@@ -214,6 +214,16 @@ struct bnpc_ctx {
     int total_slot = -1;
     DoneSignal sig_next = {nullptr, nullptr, 0};    // for the last kernel of
     bool sig_attached = false;                      // the next issue_ll
+    // bnpc_ll_theta_begin / _end: an evaluation whose result is written in
+    // place for the host and picked up later (the caller works in between)
+    bool defer_next = false, defer_set = false;
+    struct {
+        void *zc_host;
+        unsigned seq;
+        double *out;
+        size_t bytes;
+        int64_t n, K, ldo;
+    } defer = {nullptr, 0, nullptr, 0, 0, 0, 0};
     // bnpc_view_set's own pinned cell list (N entries) and the event that
     // says the last gather has read it
     void *view_cells_pin = nullptr;
@@ -2594,6 +2604,17 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     c->last_ldo = ldo;
     c->last_out = d_out;
     c->sig_next = DoneSignal{nullptr, nullptr, 0};
+    if (zc_host && c->defer_next) {
+        c->defer.zc_host = zc_host;
+        c->defer.seq = c->sig_attached ? done_seq : 0;
+        c->defer.out = out;
+        c->defer.bytes = out_bytes;
+        c->defer.n = v.n;
+        c->defer.K = K;
+        c->defer.ldo = ldo;
+        c->defer_set = true;
+        return 0;
+    }
     if (zc_host) {
         if (int rw = wait_done(c, 0, c->sig_attached ? done_seq : 0))
             return rw;
@@ -2654,6 +2675,42 @@ extern "C" int bnpc_ll_theta(bnpc_ctx *c, int view, const float *theta,
                              int64_t ldo)
 {
     return ll_theta_impl(c, view, theta, K, FP, FN, out, ldo, true);
+}
+
+// bnpc_ll_theta in two halves (bnpc_internal.h): _begin queues the evaluation
+// and returns where its result is small enough to be written in place for the
+// host (otherwise it is complete on return, as bnpc_ll_theta); _end waits for
+// the completion word and fills `out`.  No other call on the context in
+// between (the parameters stay staged in the arena).
+int bnpc_ll_theta_begin(bnpc_ctx *c, int view, const float *theta, int64_t K,
+                        double FP, double FN, double *out, int64_t ldo)
+{
+    ARGCHK(c && out, "NULL argument");
+    c->defer_set = false;
+    c->defer_next = !c->any_tile_pending();
+    const int rc = ll_theta_impl(c, view, theta, K, FP, FN, out, ldo, true);
+    c->defer_next = false;
+    if (rc) c->defer_set = false;
+    return rc;
+}
+
+int bnpc_ll_theta_end(bnpc_ctx *c)
+{
+    ARGCHK(c, "ctx is NULL");
+    if (!c->defer_set) return 0;
+    c->defer_set = false;
+    HIPCHK(hipSetDevice(c->device));
+    if (int rw = wait_done(c, 0, c->defer.seq)) return rw;
+    const int64_t K = c->defer.K, ldo = c->defer.ldo;
+    if (ldo == K) {
+        memcpy(c->defer.out, c->defer.zc_host, c->defer.bytes);
+    } else {
+        for (int64_t r = 0; r < c->defer.n; r++)
+            memcpy(c->defer.out + r * ldo,
+                   (const double *)c->defer.zc_host + r * ldo,
+                   (size_t)K * sizeof(double));
+    }
+    return 0;
 }
 
 // Same as bnpc_ll_theta, but the result lands in a context-owned PINNED host

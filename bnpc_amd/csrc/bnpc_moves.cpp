@@ -26,7 +26,7 @@ namespace {
 
 struct Scratch {
     std::vector<int64_t> cells, others, rg, labels, perm, target;
-    std::vector<double> probs, cdf, work, L, ll, tmp, U, u, A, std2;
+    std::vector<double> probs, cdf, work, L, ll, ll_first, tmp, U, u, A, std2;
     std::vector<int32_t> n1, n0, sd_idx;
     std::vector<float> rows, fresh, gather;
 };
@@ -324,12 +324,33 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     s.rows.resize((size_t)3 * M);
     s.fresh.resize((size_t)3 * M);
     float *rows = s.rows.data(), *fresh = s.fresh.data();
+    // The next call is a restricted scan over the two launch rows (an
+    // intermediate one, or the scored scan of a split): its sums are queued
+    // as soon as those two rows exist and run under the draws of the third
+    // (the merged cluster's: ~M gamma pairs on the host).
+    const bool ahead = st->scan_no > 0 || split;
+    bool begun = false;
     for (int g = 0; g < 3; g++) {
+        if (g == 2 && ahead) {
+            s.ll_first.resize((size_t)n * 2);
+            rc = bnpc_ll_theta_begin(ctx, st->view, rows, 2, FP, FN,
+                                     s.ll_first.data(), 0);
+            if (rc) return rc;
+            begun = true;
+        }
         rc = bnpc_mt_beta_theta(rng, gauss, M, st->p, st->q, n1 + g * M,
                                 n0 + g * M, 1.0, st->tmin, st->tmax,
                                 rows + g * M);
+        if (rc) {
+            if (begun) (void)bnpc_ll_theta_end(ctx);
+            return rc;
+        }
+    }
+    if (begun) {
+        rc = bnpc_ll_theta_end(ctx);
         if (rc) return rc;
     }
+    const double *ll_first = begun ? s.ll_first.data() : nullptr;
 
     // ---- the intermediate scans (libs/CRP.py:535-537) ----------------------
     s.sd_idx.resize((size_t)3 * M);
@@ -366,8 +387,10 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         mh.trans_prob = 0;
         mh.old_theta = rows;
         mh.new_theta = fresh;
-        rc = bnpc_rg_scan_step(ctx, k, rng, st->view, n, s.rg.data(),
-                               st->DP_a, &mh, n1, n0, &scan_prob, &sub);
+        rc = bnpc_rg_scan_step_with(ctx, k, rng, st->view, n, s.rg.data(),
+                                    st->DP_a, &mh, n1, n0, &scan_prob, &sub,
+                                    ll_first);
+        ll_first = nullptr;
         if (rc) return rc;
         if (sub) return 0;
         std::swap(rows, fresh);
@@ -389,8 +412,10 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         mh.new_theta = fresh;
         // (the merged cluster's row is not part of the scored scan)
         memcpy(fresh + 2 * M, rows + 2 * M, (size_t)M * sizeof(float));
-        rc = bnpc_rg_scan_step(ctx, k, rng, st->view, n, s.rg.data(),
-                               st->DP_a, &mh, n1, n0, &scan_prob, &sub);
+        rc = bnpc_rg_scan_step_with(ctx, k, rng, st->view, n, s.rg.data(),
+                                    st->DP_a, &mh, n1, n0, &scan_prob, &sub,
+                                    ll_first);
+        ll_first = nullptr;
         if (rc) return rc;
         if (sub) return 0;
         std::swap(rows, fresh);

@@ -1299,6 +1299,17 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
                                  int32_t *n0, double *scan_log_prob,
                                  int *status)
 {
+    return bnpc_rg_scan_step_with(ctx, k, rng, view, n, rg_assignment, DP_a,
+                                  mh, n1, n0, scan_log_prob, status, nullptr);
+}
+
+int bnpc_rg_scan_step_with(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                           bnpc_mt19937 *rng, int view, int64_t n,
+                           int64_t *rg_assignment, double DP_a,
+                           const bnpc_mh_args *mh, int32_t *n1, int32_t *n0,
+                           double *scan_log_prob, int *status,
+                           const double *ll_ready)
+{
     if (!ctx || !k || !rng || !rg_assignment || !mh || !n1 || !n0 || !status
         || n < 3 || (mh->G != 3 && mh->G != 2) || mh->n1 != n1
         || mh->n0 != n0) {
@@ -1307,19 +1318,24 @@ extern "C" int bnpc_rg_scan_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     }
     *status = 0;
     const int64_t S = n - 2, M = mh->M;
-    static thread_local std::vector<double> ll;
+    static thread_local std::vector<double> ll_own;
     static thread_local std::vector<int64_t> labels;
-    ll.resize((size_t)n * 2);
     labels.resize((size_t)n);
 
     // rows 0 and 1 of the parameter block are the launch clusters
-    int rc = bnpc_ll_theta(ctx, view, mh->old_theta, 2, mh->FP, mh->FN,
-                           ll.data(), 0);
-    if (rc) return rc;
+    int rc = 0;
+    const double *ll_at = ll_ready;
+    if (!ll_at) {
+        ll_own.resize((size_t)n * 2);
+        rc = bnpc_ll_theta(ctx, view, mh->old_theta, 2, mh->FP, mh->FN,
+                           ll_own.data(), 0);
+        if (rc) return rc;
+        ll_at = ll_own.data();
+    }
     // (an unscored scan: no log-probabilities, the loop may take its picks
     // from one exp() per cell)
     double log_prob = 0.0;
-    rc = bnpc_rg_scan(rng, 0, S, ll.data() + 2, DP_a, rg_assignment, nullptr,
+    rc = bnpc_rg_scan(rng, 0, S, ll_at + 2, DP_a, rg_assignment, nullptr,
                       mh->trans_prob ? &log_prob : nullptr);
     if (rc) return rc;
 
