@@ -39,6 +39,8 @@ python3 tools/python_overhead.py c3 300 > $out/python_overhead.log 2>&1
 BNPC_NATIVE_STEP=0 python3 tools/python_overhead.py c3 300 > $out/python_overhead_by_method.log 2>&1
 python3 tools/mh_dev_trace.py c3 30 > /dev/null 2> $out/mh_screen_trace_c3.log
 python3 tools/mh_dev_trace.py c5 20 > /dev/null 2> $out/mh_screen_trace_c5.log
+BNPC_TIMING=gibbs,params python3 bench.py --config c5 --steps 20 --warmup 10 --cpu-steps 0 > /dev/null 2> $out/host_phase_trace_c5.log
+BNPC_TIMING=gibbs,params python3 bench.py --steps 40 --warmup 10 --cpu-steps 0 > /dev/null 2> $out/host_phase_trace_c3.log
 python3 tools/ll_microbench.py > $out/ll_microbench.md 2>&1
 python3 tools/tile_shape_bench.py 50000 5000 31608 > $out/tile_shape_c5.log 2>&1
 python3 tools/first_sweep_profile.py c5 > $out/first_sweep_c5.log 2>&1
