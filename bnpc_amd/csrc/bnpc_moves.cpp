@@ -248,6 +248,35 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     const int64_t M = st->M, N = st->N;
     const double FP = st->FP, FN = st->FN;
     const bool split = st->move == 0;
+    // BNPC_TIMING=move: where a move's time goes, on stderr
+    static const bool trace = [] {
+        const char *e = getenv("BNPC_TIMING");
+        return e && strstr(e, "move");
+    }();
+    timespec tr0;
+    double tr_at[12];
+    int tr_n = 0;
+    if (trace) clock_gettime(CLOCK_MONOTONIC, &tr0);
+    auto mark = [&]() {
+        if (!trace || tr_n >= 12) return;
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        tr_at[tr_n++] = (t.tv_sec - tr0.tv_sec) * 1e6
+            + (t.tv_nsec - tr0.tv_nsec) / 1e3;
+    };
+    auto report = [&](const char *what) {
+        if (!trace) return;
+        mark();
+        fprintf(stderr, "[move] %s of %lld cells, M=%lld:", what,
+                (long long)st->n_cells, (long long)st->M);
+        static const char *names[] = {"proposal", "view + launch sums",
+            "counts", "3 Beta rows", "scans", "scored scan / batch",
+            "reverse proposal", "priors", "likelihood ratio", "end"};
+        for (int i = 0; i < tr_n; i++)
+            fprintf(stderr, " %s %.1f", i < 10 ? names[i] : "?",
+                    tr_at[i] - (i ? tr_at[i - 1] : 0.0));
+        fprintf(stderr, " us\n");
+    };
 
     // ---- the proposal ----------------------------------------------------
     int64_t pos_i = -1, pos_j = -1, n_first = 0;
@@ -263,6 +292,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     if (n <= 4) return 0;               // the binding's small-move path
     const int64_t *cells = s.cells.data();
     st->n_cells = n;
+    mark();
 
     // ---- run_rg_nc: the launch state (libs/CRP.py:527-567) -----------------
     int rc = bnpc_view_set(ctx, st->view, cells, n);
@@ -309,6 +339,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         s.labels[n - 1] = 1;
     };
     set_labels();
+    mark();
     s.n1.resize((size_t)3 * M);
     s.n0.resize((size_t)3 * M);
     int32_t *n1 = s.n1.data(), *n0 = s.n0.data();
@@ -321,6 +352,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         }
     };
     sum_rows();
+    mark();
     s.rows.resize((size_t)3 * M);
     s.fresh.resize((size_t)3 * M);
     float *rows = s.rows.data(), *fresh = s.fresh.data();
@@ -351,6 +383,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         if (rc) return rc;
     }
     const double *ll_first = begun ? s.ll_first.data() : nullptr;
+    mark();
 
     // ---- the intermediate scans (libs/CRP.py:535-537) ----------------------
     s.sd_idx.resize((size_t)3 * M);
@@ -396,6 +429,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         std::swap(rows, fresh);
     }
 
+    mark();
     const double log_a = np_log1(k, st->DP_a);
     double A;
     auto rg_ones = [&]() {
@@ -420,6 +454,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         if (sub) return 0;
         std::swap(rows, fresh);
         sum_rows();
+        mark();
         const double gs_split = scan_prob + (0.0 + log_prob[0] + log_prob[1]);
         // np.random.choice(sd, size=M); the reverse move's parameter
         // proposal: the merged launch row -> the cluster's own row
@@ -455,6 +490,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         if (rc) return rc;
         if (sub) return 0;
         const double trans = gs_merge - gs_split;
+        mark();
 
         // _get_lprior_ratio_split (libs/CRP.py:695-713)
         const int64_t n_j = rg_ones() + 1, n_i = n - n_j;
@@ -465,14 +501,17 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
             double sum_split = 0.0, sum_own = 0.0;
             s.work.resize((size_t)2 * M);
             rc = bnpc_beta_logpdf_f32(k, rows, 2 * M, st->p, st->q, nullptr,
-                                      nullptr, s.work.data(), &sum_split, 1);
+                                      nullptr, s.work.data(), &sum_split,
+                                      st->threads_wide);
             if (rc) return rc;
             rc = bnpc_beta_logpdf_f32(k, own, M, st->p, st->q, nullptr,
-                                      nullptr, s.work.data(), &sum_own, 1);
+                                      nullptr, s.work.data(), &sum_own,
+                                      st->threads_wide);
             if (rc) return rc;
             lprior += sum_split - sum_own;
         }
         // _get_ll_ratio (libs/CRP.py:716-733)
+        mark();
         const double ll_i = subset_ll_sum(k, rows, n1, n0, nullptr, nullptr,
                                           M, FP, FN, s);
         const double ll_j = subset_ll_sum(k, rows + M, n1 + M, n0 + M,
@@ -480,6 +519,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         const double ll_all = subset_ll_sum(k, rows + 2 * M, n1, n0, n1 + M,
                                             n0 + M, M, FP, FN, s);
         const double llr = ll_i + ll_j - ll_all;
+        mark();
         // _get_ltrans_prob_size_ratio_split (libs/CRP.py:757-764)
         double norm = 0.0;
         {
@@ -546,6 +586,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
             if (sub) return 0;
         }
         const float *merged = fresh + 2 * M;
+        mark();
         // _rg_get_split_prob (libs/CRP.py:777-820)
         mt_fill_interval32(rng, (uint32_t)(st->n_sd - 1), s.sd_idx.data(),
                            2 * M);
@@ -593,6 +634,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         if (rc) return rc;
         const double gs_split = prob2[0] + prob2[1] + prob_assign;
         const double trans = gs_split - gs_merge;
+        mark();
 
         // _get_lprior_ratio_merge (libs/CRP.py:736-754); the launch
         // assignment is now the clusters' own
@@ -604,15 +646,17 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
             double sum_merged = 0.0, sum_own = 0.0;
             s.work.resize((size_t)2 * M);
             rc = bnpc_beta_logpdf_f32(k, merged, M, st->p, st->q, nullptr,
-                                      nullptr, s.work.data(), &sum_merged, 1);
+                                      nullptr, s.work.data(), &sum_merged,
+                                      st->threads_wide);
             if (rc) return rc;
             rc = bnpc_beta_logpdf_f32(k, s.gather.data(), 2 * M, st->p, st->q,
                                       nullptr, nullptr, s.work.data(),
-                                      &sum_own, 1);
+                                      &sum_own, st->threads_wide);
             if (rc) return rc;
             lprior += sum_merged - sum_own;
         }
         // _get_ll_ratio: the counts of the clusters' own halves
+        mark();
         set_labels();
         rc = bnpc_view_counts(ctx, st->view, s.labels.data(), 2, n1, n0);
         if (rc) return rc;
@@ -623,6 +667,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         const double ll_all = subset_ll_sum(k, merged, n1, n0, n1 + M, n0 + M,
                                             M, FP, FN, s);
         const double llr = ll_all - ll_i - ll_j;
+        mark();
         // _get_ltrans_prob_size_ratio_merge (libs/CRP.py:767-774)
         if (S - 1 <= 0) return 0;
         const double rev = -np_log1(k, (double)N) - np_log1(k, (double)(S - 1));
@@ -642,5 +687,6 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     st->log_A = A;
     restore.armed = false;
     *status = 0;
+    report(split ? "split" : "merge");
     return 0;
 }
