@@ -628,10 +628,12 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // team costs more than several hundred elements
         // (4 gave 130 against 180 us per update_parameters under the
         // profiler and nothing on the bench line at config 3, whose batches
-        // leave a dozen blocks; the parts of a config-5 batch leave 50 each
-        // and are bound by this arithmetic: a rank per 4 blocks there)
+        // leave a dozen blocks; the parts of a config-5 batch leave 100 each,
+        // the scans of its moves 20, and are bound by this arithmetic: a rank
+        // per 4 blocks from 16 blocks on - config 5 267 -> 282 steps/s, config
+        // 4 1177 -> 1262; from 8 on, or a rank per 3: no further gain)
         const int64_t blocks = (flagged_all + BLK / 2 - 1) / (BLK / 2);
-        const int64_t per = blocks >= 32 ? 4 : 12;
+        const int64_t per = blocks >= 16 ? 4 : 12;
         if (threads > (blocks + per - 1) / per)
             threads = (int)((blocks + per - 1) / per);
         if (threads > n_tasks) threads = (int)n_tasks;
