@@ -523,6 +523,15 @@ bool mh_block(const bnpc_host_kernels *k, const bnpc_mh_args *a,
 
 }  // namespace
 
+// What rank 0 of the NEXT screened bnpc_mh_batch of this thread does before it
+// joins the evaluation (bnpc_internal.h); consumed by that call.
+static thread_local const std::function<void()> *g_rank0_hook = nullptr;
+
+void bnpc_mh_rank0_hook(const std::function<void()> *hook)
+{
+    g_rank0_hook = hook;
+}
+
 static int check_kernels(const bnpc_host_kernels *k)
 {
     if (!k || !k->ndtr || !k->log_ndtr || !k->ndtri_exp || !k->sc_log1p
@@ -728,10 +737,22 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             }
         };
         const long t_prep = trace ? since() : 0;
-        if (threads > 1)
-            team_for(threads)->run(threads, work);
-        else
+        const std::function<void()> *first = g_rank0_hook;
+        g_rank0_hook = nullptr;
+        if (threads > 1) {
+            if (first) {
+                const std::function<void(int)> both = [&](int rank) {
+                    if (rank == 0) (*first)();
+                    work(rank);
+                };
+                team_for(threads)->run(threads, both);
+            } else {
+                team_for(threads)->run(threads, work);
+            }
+        } else {
+            if (first) (*first)();
             work(0);
+        }
         if (trace)
             fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld in doubt, "
                     "%lld accepted of %lld elements, %lld prior misses, "

@@ -47,6 +47,11 @@ double bnpc_legacy_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
 
 // bnpc_kernels.hip: counts of the two launch clusters of a restricted scan +
 // the (screened) parameter batch on one stream synchronisation
+// The next screened bnpc_mh_batch of this thread has its rank 0 call *hook
+// before it joins the evaluation of the batch (bnpc_mh_batch_dev: the draws
+// and the screen launch of a later part of a large batch under the team's
+// work on this one); NULL: nothing.  Consumed by that call.
+void bnpc_mh_rank0_hook(const std::function<void()> *hook);
 // bnpc_ll_theta in two halves (bnpc_kernels.hip): the caller works between
 // them - bnpc_sm_move draws the third Beta row under the first scan's sums
 int bnpc_ll_theta_begin(bnpc_ctx *c, int view, const float *theta, int64_t K,
@@ -123,7 +128,12 @@ static inline uint64_t mt_interval(bnpc_mt19937 *s, uint64_t max)
 // ---- bulk draws (bnpc_mt.cpp): the same stream as mt_double / mt_interval
 // one by one, tempered straight out of the state block in vectorised loops
 // (AVX-512 / AVX2 / baseline clones, picked at load time) -------------------
-void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n);
+void mt_fill_double(bnpc_mt19937 *s, double *out, int64_t n,
+                    bool stream = false);
+// bnpc_mt_mh_draws; stream: the uniforms go out with non-temporal stores (a
+// large pinned destination the device reads next), fenced before return
+int bnpc_mt_mh_draws_to(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
+                        int32_t *sd_idx, double *U, double *u, bool stream);
 void mt_fill_interval32(bnpc_mt19937 *s, uint32_t max, int32_t *out,
                         int64_t n);
 void mt_fill_permutation(bnpc_mt19937 *s, int64_t n, int64_t *out);

@@ -111,7 +111,7 @@ struct Tunables {
 #define ZC_IN_MAX ((int64_t)256 << 10)      // zero-copy inputs / results up to
 #define ZC_OUT_MAX ((int64_t)512 << 10)
 #define MH_SCREEN_MIN 512           // batch entries from which the screen pays
-#define MH_THREADED_MIN 65536       // batch entries from which a helper thread
+#define MH_THREADED_MIN 65536       // batch entries from which rank 0 issues
                                     // draws and launches ahead of the waits
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
@@ -3556,18 +3556,21 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     // Parts in a pipeline (batches of 4 rows and more): the draws of part
     // p + 1 are taken while the device screens part p, and the host evaluates
     // what a screen left while the next one runs.  Two halves for the batches
-    // of a config-3 step; a LARGE batch (configs 4 and 5: 40 000 - 250 000
-    // entries, two thirds of a millisecond of draws) is cut into up to 8
-    // parts whose draws, staging and screen launches are made by a helper
-    // thread while this one waits for the completion words and evaluates the
-    // leftovers part by part - the stream is consumed in the same order by
-    // the one thread that touches it.
+    // of a config-3 step; a LARGE batch (configs 4 and 5: 65 000 - 250 000
+    // entries, 0.2 ms of draws) is cut into up to 8 parts, two of them
+    // issued up front; while the team evaluates what the screen left of part
+    // p, its rank 0 - this thread, the only one that touches the stream -
+    // first takes the draws of part p + 2, stages them and launches their
+    // screen (bnpc_mh_rank0_hook), then joins the evaluation.  (A helper
+    // std::thread did the issuing earlier in round 4: a thread started per
+    // batch on whatever core is free took 80-120 us for the draws of a part
+    // that this thread, warm, takes in 27 - tools/draws_bench.py.)
     static const bool done_words_off = [] {
         const char *e = getenv("BNPC_DONE_WORDS");
         return e && e[0] == '0';
     }();
     const bool threaded = rng && !done_words_off && G >= 4 && counts_src == 0
-        && E >= MH_THREADED_MIN;
+        && E >= MH_THREADED_MIN;     // "pipelined on rank 0"
     int parts = (G >= 4 && counts_src == 0) ? 2 : 1;
     if (threaded)
         parts = (int)std::max<int64_t>(2, std::min<int64_t>(
@@ -3580,14 +3583,23 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
                                            hipEventDisableTiming));
     SideLane lane(c);
     unsigned done_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double t_draws_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // draws + staging + launch of one part (either thread)
     auto issue_part = [&](int p) -> int {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M, n = (size_t)Gp * M;
+        timespec tq0, tq1;
+        if (trace) clock_gettime(CLOCK_MONOTONIC, &tq0);
         if (rng) {
-            if (int rc = bnpc_mt_mh_draws(rng, Gp, M, a->n_sd, h.sd_idx + at,
-                                          h.U + at, h.u + at))
+            if (int rc = bnpc_mt_mh_draws_to(rng, Gp, M, a->n_sd,
+                                             h.sd_idx + at, h.U + at,
+                                             h.u + at, threaded))
                 return rc;
+            if (trace) {
+                clock_gettime(CLOCK_MONOTONIC, &tq1);
+                t_draws_us[p] = (tq1.tv_sec - tq0.tv_sec) * 1e6
+                    + (tq1.tv_nsec - tq0.tv_nsec) / 1e3;
+            }
         } else {
             memcpy(h.U + at, a->U + at, n * 8);
             memcpy(h.u + at, a->u + at, n * 8);
@@ -3601,41 +3613,18 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         if (!done_seq[p]) HIPCHK(hipEventRecord(c->mh_ev[p & 1], c->stream));
         return 0;
     };
-    std::atomic<int> issued(0);     // parts issued so far; -1: the helper failed
     timespec t_issued[8], t_got[8], t_waited[8], t_hosted[8];
-    char helper_err[512] = "";
-    std::thread helper;
-    struct Joiner {
-        std::thread &t;
-        ~Joiner()
-        {
-            if (t.joinable()) t.join();
-        }
-    } joiner{helper};
-    if (threaded) {
-        helper = std::thread([&]() {
-            if (hipSetDevice(c->device) != hipSuccess) {
-                snprintf(helper_err, sizeof helper_err, "hipSetDevice failed "
-                         "in the batch's helper thread");
-                issued.store(-1, std::memory_order_release);
-                return;
-            }
-            for (int p = 0; p < parts; p++) {
-                if (issue_part(p)) {
-                    snprintf(helper_err, sizeof helper_err, "%s",
-                             bnpc_last_error());
-                    issued.store(-1, std::memory_order_release);
-                    return;
-                }
-                if (trace) clock_gettime(CLOCK_MONOTONIC, &t_issued[p]);
-                issued.store(p + 1, std::memory_order_release);
-            }
-        });
-    } else {
-        for (int p = 0; p < parts; p++) {
-            if (int rc = issue_part(p)) return rc;
-            issued.store(p + 1, std::memory_order_release);
-        }
+    // issue one part, keep its time for the trace
+    auto issue_timed = [&](int p) -> int {
+        const int rc = issue_part(p);
+        if (trace) clock_gettime(CLOCK_MONOTONIC, &t_issued[p]);
+        return rc;
+    };
+    int next_issue = 0;
+    {
+        const int up_front = threaded ? std::min(2, parts) : parts;
+        for (; next_issue < up_front; next_issue++)
+            if (int rc = issue_timed(next_issue)) return rc;
     }
     if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
     int64_t kept = 0;
@@ -3643,17 +3632,6 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     for (int p = 0; p < parts; p++) {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M;
-        for (int spins = 0;; spins++) {
-            const int got = issued.load(std::memory_order_acquire);
-            if (got < 0) {
-                bnpc_set_error("%s", helper_err);
-                return 1;
-            }
-            if (got > p) break;
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
         if (trace) clock_gettime(CLOCK_MONOTONIC, &t_got[p]);
         if (done_seq[p]) {
             if (int rc = wait_done(c, threaded ? 0 : p, done_seq[p])) return rc;
@@ -3685,7 +3663,15 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         b.declined += g0;
         b.screen = h.flags + at;
         int st = 0;
+        // rank 0 of this part's evaluation issues the next part but one first
+        int hook_rc = 0;
+        const std::function<void()> hook = [&]() {
+            hook_rc = issue_timed(next_issue++);
+        };
+        if (next_issue < parts) bnpc_mh_rank0_hook(&hook);
         int rc = bnpc_mh_batch(k, nullptr, &b, &st);
+        bnpc_mh_rank0_hook(nullptr);
+        if (rc == 0) rc = hook_rc;
         if (rc) {
             (void)hipStreamSynchronize(c->stream);
             return rc;
@@ -3709,9 +3695,10 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
                 (long long)kept);
         if (threaded)
             for (int p = 0; p < parts; p++)
-                fprintf(stderr, "[mh_batch_dev]   part %d: issued at %.1f, "
-                        "picked up at %.1f, screened at %.1f, evaluated at "
-                        "%.1f us\n", p, us(ts0, t_issued[p]), us(ts0, t_got[p]),
+                fprintf(stderr, "[mh_batch_dev]   part %d: issued at %.1f "
+                        "(its draws %.1f), picked up at %.1f, screened at "
+                        "%.1f, evaluated at %.1f us\n", p,
+                        us(ts0, t_issued[p]), t_draws_us[p], us(ts0, t_got[p]),
                         us(ts0, t_waited[p]), us(ts0, t_hosted[p]));
     }
     if (*status != 0) {

@@ -69,6 +69,12 @@ extern "C" int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M,
                                 int64_t n_sd, int32_t *sd_idx, double *U,
                                 double *u)
 {
+    return bnpc_mt_mh_draws_to(rng, G, M, n_sd, sd_idx, U, u, false);
+}
+
+int bnpc_mt_mh_draws_to(bnpc_mt19937 *rng, int64_t G, int64_t M, int64_t n_sd,
+                        int32_t *sd_idx, double *U, double *u, bool stream)
+{
     if (!rng || !sd_idx || !U || !u || n_sd < 1) {
         bnpc_set_error("bad argument: NULL");
         return 2;
@@ -77,9 +83,13 @@ extern "C" int bnpc_mt_mh_draws(bnpc_mt19937 *rng, int64_t G, int64_t M,
         int32_t *si = sd_idx + g * M;
         double *Ug = U + g * M, *ug = u + g * M;
         mt_fill_interval32(rng, (uint32_t)(n_sd - 1), si, M);
-        mt_fill_double(rng, Ug, M);     // uniform(0, 1): 0.0 + 1.0 * u == u
-        mt_fill_double(rng, ug, M);
+        // uniform(0, 1): 0.0 + 1.0 * u == u
+        mt_fill_double(rng, Ug, M, stream);
+        mt_fill_double(rng, ug, M, stream);
     }
+#if defined(__x86_64__)
+    if (stream) __builtin_ia32_sfence();
+#endif
     return 0;
 }
 
