@@ -102,6 +102,8 @@ struct Tunables {
                                     // mask-popcount counts (tests lower it)
     int mh_screen = 1;              // BNPC_MH_SCREEN: device screen of the
                                     // parameter batches
+    int done_words = 1;             // BNPC_DONE_WORDS: completion words written
+                                    // by the kernels (0: stream synchronisation)
 };
 
 #define MSPLIT_MAX 64               // chunks of a split launch at most
@@ -132,6 +134,7 @@ static void read_tunables(Tunables &t)
     t.zero_copy = env_int("BNPC_ZERO_COPY", 1);
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
+    t.done_words = env_int("BNPC_DONE_WORDS", 1);
 }
 
 #define DONE_SLOTS 3     // 0, 1: the launches of a call; 2: the deferred total
@@ -423,11 +426,7 @@ static DoneSignal make_signal(bnpc_ctx *c, int slot, unsigned *seq)
 {
     DoneSignal none = {nullptr, nullptr, 0};
     *seq = 0;
-    static const bool off = [] {
-        const char *e = getenv("BNPC_DONE_WORDS");
-        return e && e[0] == '0';
-    }();
-    if (off) return none;
+    if (!c->tun.done_words) return none;
     if (!c->done_count) {
         void *pin = nullptr, *dev = nullptr, *cnt = nullptr;
         if (hipHostMalloc(&pin, DONE_SLOTS * 64, hipHostMallocDefault) != hipSuccess
@@ -3565,11 +3564,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     // std::thread did the issuing earlier in round 4: a thread started per
     // batch on whatever core is free took 80-120 us for the draws of a part
     // that this thread, warm, takes in 27 - tools/draws_bench.py.)
-    static const bool done_words_off = [] {
-        const char *e = getenv("BNPC_DONE_WORDS");
-        return e && e[0] == '0';
-    }();
-    const bool threaded = rng && !done_words_off && G >= 4 && counts_src == 0
+    const bool threaded = rng && c->tun.done_words && G >= 4 && counts_src == 0
         && E >= MH_THREADED_MIN;     // "pipelined on rank 0"
     int parts = (G >= 4 && counts_src == 0) ? 2 : 1;
     if (threaded)

@@ -1364,13 +1364,15 @@ def test_native_step_hands_phases_back_and_resumes(monkeypatch):
 
 @pytest.mark.parametrize('switch,value', [('BNPC_MH_SCREEN', '0'),
     ('BNPC_NATIVE_BETA', '0'), ('BNPC_STREAM_LIVE', '0'),
-    ('BNPC_STREAM_LIVE', 'rng'), ('BNPC_ZERO_COPY', '0')])
+    ('BNPC_STREAM_LIVE', 'rng'), ('BNPC_ZERO_COPY', '0'),
+    ('BNPC_DONE_WORDS', '0')])
 def test_fallback_switches_walk_the_same_chain(switch, value, monkeypatch):
     """The documented fallbacks (README, environment switches) that no other
     test flips: the parameter batches without the device screen, Beta draws
     through NumPy, the stream exchanged through get_state / set_state instead
     of addressed in place (whole or the cached Gaussian only), small payloads
-    through the copy engine - the same chain, bit for bit."""
+    through the copy engine, waits through the stream instead of the kernels'
+    completion words - the same chain, bit for bit."""
     data = H.synth(8, 700, 180, 6, 0.15)
 
     def fresh():

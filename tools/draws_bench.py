@@ -35,3 +35,27 @@ for _ in range(100):
 print(f'numpy random_sample of the same doubles: '
       f'{(time.perf_counter() - t) / 100 * 1e6:.1f} us')
 print(open('/proc/cpuinfo').read().split('model name')[1].split('\n')[0])
+
+# the same draws into a destination that is not in the cache (64 MB walked part
+# by part), ordinary and non-temporal stores
+f = getattr(lib, '_Z19bnpc_mt_mh_draws_toP12bnpc_mt19937lllPiPdS2_b', None)
+if f is not None:
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.c_bool]
+    E = G * M
+    parts = max(2, (8 << 20) // E)
+    sd_big = np.zeros(E * parts, np.int32)
+    U_big = np.zeros(E * parts)
+    u_big = np.zeros(E * parts)
+    with _lib.NumpyStream() as rng:
+        for stream in (False, True):
+            t = time.perf_counter()
+            for rep in range(3):
+                for p in range(parts):
+                    f(C.cast(rng, C.c_void_p), G, M, 3,
+                      sd_big[p * E:].ctypes.data, U_big[p * E:].ctypes.data,
+                      u_big[p * E:].ctypes.data, stream)
+            per = (time.perf_counter() - t) / (3 * parts) * 1e6
+            print(f'cold destination, non-temporal stores {stream}: '
+                  f'{per:.1f} us per batch')
