@@ -8,6 +8,7 @@
 # itself after "--" (python3, no wrappers).
 out=gpurun_out/${1:-r04ev}
 mkdir -p $out
+uptime > $out/box_load.log; nproc >> $out/box_load.log
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 
 # 1. PMC passes first (separate runs: FETCH_SIZE and WRITE_SIZE do not fit
@@ -66,5 +67,6 @@ python3 bench.py --config c2 --steps 200 > $out/bench_config2.json 2> /dev/null
 python3 bench.py --config c4 --steps 100 --cpu-steps 0 > $out/bench_config4.json 2> /dev/null
 python3 bench.py --config c5 --steps 60 --warmup 10 --cpu-steps 0 > $out/bench_config5.json 2> /dev/null
 E2E_FLAGS="-smp 0.5 -sms 5" python3 tools/e2e_cli_big.py 50000 5000 50 8 200 posterior ML MAP > $out/e2e_cli_config5_posterior.log 2>&1
+uptime >> $out/box_load.log
 find $out -name "*_trace.csv" -size +4M -delete
 ls $out
