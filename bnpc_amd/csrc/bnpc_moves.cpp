@@ -16,6 +16,9 @@
 // the stream and the cached Gaussian are put back where they were when the
 // call started, nothing else has been modified, *status = 1, and the binding
 // runs the move through its own step-by-step path.
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
 #include <algorithm>
 #include <cstring>
 #include <vector>

@@ -14,6 +14,8 @@
 // A phase this file does not model ends the call BEFORE that phase with the
 // stream where the reference has it there (ch->need); the binding runs the
 // phase through its methods and calls again (ch->phase).
+#include <stdio.h>
+#include <stdlib.h>
 #include <chrono>
 #include <cstring>
 #include <vector>

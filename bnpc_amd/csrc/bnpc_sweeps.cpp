@@ -1327,7 +1327,7 @@ int bnpc_rg_scan_step_with(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         return 2;
     }
     *status = 0;
-    const int64_t S = n - 2, M = mh->M;
+    const int64_t S = n - 2;
     static thread_local std::vector<double> ll_own;
     static thread_local std::vector<int64_t> labels;
     labels.resize((size_t)n);
