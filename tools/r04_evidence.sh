@@ -42,6 +42,10 @@ python3 tools/mh_dev_trace.py c3 30 > /dev/null 2> $out/mh_screen_trace_c3.log
 python3 tools/mh_dev_trace.py c5 20 > /dev/null 2> $out/mh_screen_trace_c5.log
 BNPC_TIMING=gibbs,params python3 bench.py --config c5 --steps 20 --warmup 10 --cpu-steps 0 > /dev/null 2> $out/host_phase_trace_c5.log
 BNPC_TIMING=gibbs,params python3 bench.py --steps 40 --warmup 10 --cpu-steps 0 > /dev/null 2> $out/host_phase_trace_c3.log
+BNPC_TIMING=move python3 bench.py --steps 60 --warmup 10 --cpu-steps 0 2>&1 >/dev/null | grep '^\[move\]' > $out/move_trace_c3.log
+BNPC_TIMING=move python3 bench.py --config c5 --steps 30 --warmup 10 --cpu-steps 0 2>&1 >/dev/null | grep '^\[move\]' > $out/move_trace_c5.log
+rocprofv3 --kernel-trace --stats -d $out/prof_c5 -o c5 -f csv -- \
+    python3 bench.py --config c5 --steps 30 --warmup 10 --cpu-steps 0 > /dev/null 2>&1
 python3 tools/ll_microbench.py > $out/ll_microbench.md 2>&1
 python3 tools/tile_shape_bench.py 50000 5000 31608 > $out/tile_shape_c5.log 2>&1
 python3 tools/first_sweep_profile.py c5 > $out/first_sweep_c5.log 2>&1
