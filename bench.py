@@ -47,6 +47,12 @@ CONFIGS = {
     'c3': (5000, 1000, 10, 0.20, True),
     'c4': (10000, 2000, 20, 0.20, True),
     'c5': (50000, 5000, 50, 0.20, True),   # -smp 0.5 -sms 5 (MOVE_OVERRIDES)
+    # many clones: a running chain with 64 < K < the tiling threshold (the
+    # configs above collapse to K = 10-54).  c3k = config 3's shape with 200
+    # true clusters; k150 = the same regime at a size the CPU oracle walks in
+    # seconds (parity soaks, tests)
+    'c3k': (5000, 1000, 200, 0.20, True),
+    'k150': (2000, 500, 150, 0.20, True),
 }
 # move settings that differ from the CLI defaults (BASELINE.json configs)
 MOVE_OVERRIDES = {'c5': dict(sm_prob=.5, sm_steps=5)}
