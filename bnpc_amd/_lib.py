@@ -34,6 +34,7 @@ def env(name, default=None):
 MAX_VIEWS = 7
 TILE_SLOTS = 4      # include/bnpc_hip.h: BNPC_TILE_SLOTS
 MAX_TRIALS = 4
+HINT_COLS_MAX = 32767   # columns of a hinted sweep (bnpc_top2 holds them as int16)
 
 _i64 = C.c_int64
 # array arguments travel as plain addresses (building a typed ctypes pointer
@@ -100,7 +101,8 @@ class MHArgs(C.Structure):
         ('U', C.c_void_p), ('u', C.c_void_p), ('new_theta', C.c_void_p),
         ('prior_out', C.c_void_p), ('A', C.c_void_p),
         ('log_prob', C.c_void_p), ('declined', C.c_void_p),
-        ('threads', C.c_int), ('screen', C.c_void_p)]
+        ('threads', C.c_int), ('screen', C.c_void_p),
+        ('screen_theta', C.c_void_p)]
 
 
 class LogAArgs(C.Structure):
@@ -159,7 +161,7 @@ STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
 
 # the version bnpc_abi_version() of a matching library reports (bumped with
 # every change of a structure or signature of include/bnpc_hip.h)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
@@ -237,7 +239,7 @@ SIGNATURES = {
         C.POINTER(MHArgs),
         C.POINTER(C.c_int)]),
     'bnpc_mh_screen': (C.c_int, [_ctx, C.c_int, C.POINTER(MHArgs),
-        C.c_void_p]),
+        C.c_void_p, C.c_void_p]),
     'bnpc_mh_batch_dev': (C.c_int, [_ctx, C.c_void_p, C.POINTER(MT19937),
         C.POINTER(MHArgs), C.c_int, C.POINTER(C.c_int)]),
     'bnpc_label_counts_and_batch': (C.c_int, [_ctx, C.c_void_p,
@@ -1403,11 +1405,12 @@ class Context:
                 wait=True):
         """ll_theta_pinned plus the sweep's hint: (matrix view, hint) where
         hint is a structured NumPy VIEW (TOP2 records, one per slot) of
-        pinned memory, or None (more than 64 columns).  wait=False returns
-        once the work is queued: call sync() before reading the hints."""
+        pinned memory, or None (more than HINT_COLS_MAX columns).  wait=False
+        returns once the work is queued: call hints_wait() before reading the
+        hints."""
         theta = np.ascontiguousarray(theta, dtype=np.float32)
         K = theta.shape[0]
-        if K > 64:
+        if K > HINT_COLS_MAX:
             return self.ll_theta_pinned(view, theta, FP, FN, ld), None
         col_prior = np.ascontiguousarray(col_prior, dtype=np.float64)
         assert col_prior.size == K
@@ -1543,9 +1546,11 @@ class Context:
         return n1, n0
 
     def mh_screen(self, counts_src, old, sd, draws, tmin, tmax, FP, FN, p, q,
-                uniform):
+                uniform, with_theta=False):
         """bnpc_mh_screen: uint8 (G, M), 0 where the proposal is declined for
-        certain under the resident counts (tests)."""
+        certain under the resident counts, 2 / 3 where it is accepted for
+        certain (tests); with_theta: (flags, float32 (G, M) holding the
+        proposals of the entries flagged 3)."""
         old = np.ascontiguousarray(old, dtype=np.float32)
         G, M = old.shape
         sd = np.ascontiguousarray(sd, dtype=np.float64)
@@ -1559,9 +1564,10 @@ class Context:
         a.uniform_prior, a.trans_prob = int(bool(uniform)), 0
         a.sd_idx, a.U, a.u = ptr(sd_idx), ptr(U), ptr(u)
         flags = np.empty((G, M), dtype=np.uint8)
+        new32 = np.full((G, M), np.nan, dtype=np.float32)
         check(self._lib.bnpc_mh_screen(self._h, counts_src, C.byref(a),
-            ptr(flags)), 'mh_screen')
-        return flags
+            ptr(flags), ptr(new32)), 'mh_screen')
+        return (flags, new32) if with_theta else flags
 
     def mh_screen_stats(self):
         """(elements screened so far, of those left to the host)"""

@@ -945,6 +945,15 @@ extern "C" int bnpc_post_ward(bnpc_post *p, double *Z_raw)
     if (d_pd) (void)hipFree(d_pd);
     if (d_pi) (void)hipFree(d_pi);
     if (d_ws) (void)hipFree(d_ws);
+    if (e == hipErrorOutOfMemory) {
+        // an allocation that failed although the pre-check saw room
+        // (fragmentation, other chains on the same GPU): the announced
+        // out-of-memory code, so that the caller's host fallback applies
+        (void)hipGetLastError();
+        bnpc_set_error("ward linkage: out of device memory (%s)",
+                       hipGetErrorString(e));
+        return 5;
+    }
     if (e != hipSuccess) {
         bnpc_set_error("ward linkage: %s", hipGetErrorString(e));
         return 1;

@@ -619,17 +619,24 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         {
             const uint8_t *sc = a->screen;
             const int64_t E = G * M;
-            int64_t e = 0;
+            int64_t e = 0, light = 0;   // light: flag 3 with the device's bits
+            const uint64_t lo7 = 0x7f7f7f7f7f7f7f7full;
             for (; e + 8 <= E; e += 8) {
                 uint64_t w;
                 memcpy(&w, sc + e, 8);
                 if (!w) continue;
-                // (the high bit of every non-zero byte)
-                w = (((w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | w)
-                    & 0x8080808080808080ull;
-                flagged_all += __builtin_popcountll(w);
+                // (the high bit of every non-zero byte; of every byte == 3)
+                const uint64_t x = w ^ 0x0303030303030303ull;
+                flagged_all += __builtin_popcountll(
+                    (((w & lo7) + lo7) | w) & ~lo7);
+                light += __builtin_popcountll(~(((x & lo7) + lo7) | x | lo7));
             }
-            for (; e < E; e++) flagged_all += sc[e] != 0;
+            for (; e < E; e++) {
+                flagged_all += sc[e] != 0;
+                light += sc[e] == 3;
+            }
+            // (a value taken and one density: a quarter of the full proposal)
+            if (a->screen_theta) flagged_all -= light - light / 4;
         }
         const int64_t segs = (M + SEG - 1) / SEG;
         const int64_t n_tasks = G * segs;
@@ -647,9 +654,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             threads = (int)((blocks + per - 1) / per);
         if (threads > n_tasks) threads = (int)n_tasks;
         if (threads < 1) threads = 1;
-        std::atomic<int64_t> next(0), n_todo(0), n_sure(0), n_miss(0);
+        std::atomic<int64_t> next(0), n_todo(0), n_sure(0), n_miss(0),
+            n_given(0);
         auto work = [&](int) {
-            int32_t todo[SEG], sure[SEG];
+            int32_t todo[SEG], sure[SEG], given[SEG];
+            const bool take_given = a->screen_theta != nullptr;
             for (;;) {
                 const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
                 if (t >= n_tasks) break;
@@ -661,22 +670,21 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 const float *old = a->old_theta + row;
                 float *out = a->new_theta + row;
                 memcpy(out + m0, old + m0, (size_t)(m1 - m0) * sizeof(float));
-                int nt = 0, ns = 0;
+                int nt = 0, ns = 0, ng = 0;
+                auto sort_out = [&](int64_t at) {
+                    const uint8_t f = sc[at];
+                    if (f == 3 && take_given) given[ng++] = (int32_t)at;
+                    else if (f == 2 || f == 3) sure[ns++] = (int32_t)at;
+                    else if (f) todo[nt++] = (int32_t)at;
+                };
                 int64_t m = m0;
                 for (; m + 8 <= m1; m += 8) {
                     uint64_t w;
                     memcpy(&w, sc + m, 8);
                     if (!w) continue;
-                    for (int b = 0; b < 8; b++) {
-                        const uint8_t f = sc[m + b];
-                        if (f == 2) sure[ns++] = (int32_t)(m + b);
-                        else if (f) todo[nt++] = (int32_t)(m + b);
-                    }
+                    for (int b = 0; b < 8; b++) sort_out(m + b);
                 }
-                for (; m < m1; m++) {
-                    if (sc[m] == 2) sure[ns++] = (int32_t)m;
-                    else if (sc[m]) todo[nt++] = (int32_t)m;
-                }
+                for (; m < m1; m++) sort_out(m);
                 int64_t missed = 0;
                 if (want_prior) {
                     double *po = a->prior_out + row;
@@ -719,8 +727,22 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                            (size_t)(m1 - m0) * sizeof(double));
                 }
                 __atomic_fetch_add(&a->declined[g],
-                                   (int64_t)(m1 - m0 - nt - ns),
+                                   (int64_t)(m1 - m0 - nt - ns - ng),
                                    __ATOMIC_RELAXED);
+                // accepted, and the device vouches for the proposal's bits:
+                // the value is taken, its prior density evaluated
+                {
+                    const float *dev_new = take_given ? a->screen_theta + row
+                                                      : nullptr;
+                    double *po = want_prior ? a->prior_out + row : nullptr;
+                    for (int i = 0; i < ng; i++) {
+                        const float v = dev_new[given[i]];
+                        out[given[i]] = v;
+                        if (po)
+                            po[given[i]] = beta_logpdf1(k, v, a->p, a->q,
+                                                        c.betaln_pq);
+                    }
+                }
                 bool ok = true;
                 for (int lo = 0; lo < nt && ok; lo += BLK / 2)
                     ok = mh_block(k, a, c, g, todo + lo, 0,
@@ -732,6 +754,7 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 if (trace) {
                     n_todo.fetch_add(nt, std::memory_order_relaxed);
                     n_sure.fetch_add(ns, std::memory_order_relaxed);
+                    n_given.fetch_add(ng, std::memory_order_relaxed);
                     n_miss.fetch_add(missed, std::memory_order_relaxed);
                 }
             }
@@ -755,10 +778,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         }
         if (trace)
             fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld in doubt, "
-                    "%lld accepted of %lld elements, %lld prior misses, "
+                    "%lld accepted (+ %lld with the device's bits) of %lld "
+                    "elements, %lld prior misses, "
                     "threads=%d, %.1f us (counting the flags %.1f)\n",
                     (long long)G, (long long)M, (long long)n_todo.load(),
-                    (long long)n_sure.load(),
+                    (long long)n_sure.load(), (long long)n_given.load(),
                     (long long)(G * M), (long long)n_miss.load(), threads,
                     since() / 1e3, t_prep / 1e3);
         if (bail.load()) {

@@ -54,7 +54,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 8; }
+extern "C" int bnpc_abi_version(void) { return 9; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -104,6 +104,9 @@ struct Tunables {
                                     // parameter batches
     int done_words = 1;             // BNPC_DONE_WORDS: completion words written
                                     // by the kernels (0: stream synchronisation)
+    int screen_theta = 1;           // BNPC_SCREEN_THETA: the screen also hands
+                                    // over the float32 bits of the proposals it
+                                    // accepts, where they are beyond doubt
 };
 
 #define MSPLIT_MAX 64               // chunks of a split launch at most
@@ -115,6 +118,10 @@ struct Tunables {
 #define MH_SCREEN_MIN 512           // batch entries from which the screen pays
 #define MH_THREADED_MIN 65536       // batch entries from which rank 0 issues
                                     // draws and launches ahead of the waits
+#define HINT_COLS_MAX 32767         // columns of a hinted sweep (int16 in the
+                                    // record)
+#define HINT_THROUGH_MAX 1024       // ... up to which rows that will be scanned
+                                    // are written through to the host
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
 
@@ -135,6 +142,7 @@ static void read_tunables(Tunables &t)
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
     t.done_words = env_int("BNPC_DONE_WORDS", 1);
+    t.screen_theta = env_int("BNPC_SCREEN_THETA", 1);
 }
 
 #define DONE_SLOTS 3     // 0, 1: the launches of a call; 2: the deferred total
@@ -192,6 +200,7 @@ struct bnpc_ctx {
     char *zc_out_dev = nullptr;
     void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
     size_t hint_cap = 0;
+    DevBuf hint_prior;              // priors of a hinted sweep with > 64 columns
     // pinned block of a screened parameter batch (bnpc_mh_batch_dev): the
     // draws, the old parameter rows and the screen's verdicts, read / written
     // in place by k_mh_screen
@@ -1546,6 +1555,103 @@ __global__ __launch_bounds__(256) void k_row_top2(
     out[slot] = t;
 }
 
+// The same record for rows of MORE than 64 columns (a running chain with
+// hundreds of clusters, the first sweep of a data set whose whole matrix fits
+// the host budget: up to 32767 columns): one wave per row, lane l takes
+// columns l, l + 64, ... and keeps its own four largest; the 64 lists are
+// merged by an xor butterfly under the total order (value descending, column
+// ascending), so every lane ends with the row's record - the first column on
+// ties, as the one-thread kernel.  Priors from device memory.  Rows the sweep
+// will scan are written through to the host matrix when that is a few KiB per
+// row (through_max columns), coalesced.
+struct Top4 {
+    double b, s, t, f;      // the four largest entries of ll + prior
+    double lb, ls, lt;      // the log-likelihoods behind the first three
+    int cb, cs, ct;         // their columns (INT_MAX: none)
+};
+
+__device__ __forceinline__ bool top4_before(double v, int k, double x, int cx)
+{
+    return v > x || (v == x && k < cx);
+}
+
+__device__ __forceinline__ void top4_insert(Top4 &q, double v, double l, int k)
+{
+    if (top4_before(v, k, q.b, q.cb)) {
+        q.f = q.t;
+        q.t = q.s; q.lt = q.ls; q.ct = q.cs;
+        q.s = q.b; q.ls = q.lb; q.cs = q.cb;
+        q.b = v; q.lb = l; q.cb = k;
+    } else if (top4_before(v, k, q.s, q.cs)) {
+        q.f = q.t;
+        q.t = q.s; q.lt = q.ls; q.ct = q.cs;
+        q.s = v; q.ls = l; q.cs = k;
+    } else if (top4_before(v, k, q.t, q.ct)) {
+        q.f = q.t;
+        q.t = v; q.lt = l; q.ct = k;
+    } else if (v > q.f) {
+        q.f = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_row_top4_wave(
+    const double *__restrict__ ll, long long n, long long ldo, int K,
+    const double *__restrict__ prior, bnpc_top2 *__restrict__ out,
+    double *__restrict__ host_ll, int through_max)
+{
+    const int lane = threadIdx.x & 63;
+    const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= n) return;
+    const double *__restrict__ r = ll + (size_t)slot * ldo;
+    const int none = 0x7fffffff;
+    Top4 q = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0, 0.0, 0.0,
+              none, none, none};
+    for (int k = lane; k < K; k += 64) {
+        const double l = r[k];
+        top4_insert(q, l + prior[k], l, k);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Top4 o;
+        o.b = __shfl_xor(q.b, off);
+        o.s = __shfl_xor(q.s, off);
+        o.t = __shfl_xor(q.t, off);
+        o.f = __shfl_xor(q.f, off);
+        o.lb = __shfl_xor(q.lb, off);
+        o.ls = __shfl_xor(q.ls, off);
+        o.lt = __shfl_xor(q.lt, off);
+        o.cb = __shfl_xor(q.cb, off);
+        o.cs = __shfl_xor(q.cs, off);
+        o.ct = __shfl_xor(q.ct, off);
+        // (an entry that is not there compares below everything: -inf, none)
+        top4_insert(q, o.b, o.lb, o.cb);
+        top4_insert(q, o.s, o.ls, o.cs);
+        top4_insert(q, o.t, o.lt, o.ct);
+        if (o.f > q.f) q.f = o.f;
+    }
+    int through = 0;
+    if (host_ll && K <= through_max && q.f > q.s - 72.0 && q.s > q.b - 48.0) {
+        double *__restrict__ h = host_ll + (size_t)slot * ldo;
+        for (int k = lane; k < K; k += 64) h[k] = r[k];
+        through = 1;
+    }
+    if (lane == 0) {
+        bnpc_top2 t;
+        t.best = q.b;
+        t.second = q.s;
+        t.third = q.t;
+        t.fourth = q.f;
+        t.ll_best = q.lb;
+        t.ll_second = q.ls;
+        t.ll_third = q.lt;
+        t.col = (int16_t)(q.cb == none ? 0 : q.cb);
+        t.col2 = (int16_t)(q.cs == none || !(q.s > -INFINITY) ? -1 : q.cs);
+        t.col3 = (int16_t)(q.ct == none || !(q.t > -INFINITY) ? -1 : q.ct);
+        t.row_here = (int16_t)through;
+        out[slot] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K3: column counts of 1s and 0s over chunks of cell segments
 //   n1[g][m] = #{c in segment g : x_cm = 1},  n0 likewise
@@ -1837,7 +1943,7 @@ __global__ __launch_bounds__(256) void k_mh_screen(
     const int *__restrict__ n0, const int *__restrict__ sd_idx,
     const double *__restrict__ U, const double *__restrict__ u, long long GM,
     int M, int sum_row, MHScreenConst k, unsigned char *__restrict__ flags,
-    DoneSignal done)
+    float *__restrict__ new_out, DoneSignal done)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     // (no early return: every wave reaches signal_done once, converged)
@@ -1907,6 +2013,30 @@ __global__ __launch_bounds__(256) void k_mh_screen(
                         && gap > -INFINITY) {
                         if (gap > margin) flag = 0;         // declined for certain
                         else if (-gap > margin) flag = 2;   // accepted for certain
+                    }
+                    // An accepted proposal's float32 bits are certain too when
+                    // the float64 value lies clear of the two rounding
+                    // boundaries around nw by more than this value and the
+                    // host's can be apart: both are the same function of the
+                    // same inputs evaluated with errors of a few 1e-15 (here:
+                    // erfc and its inverse to a few ulp on |x| <= 10; there:
+                    // SciPy's log-space chain, whose largest term - log_ndtr
+                    // of a bound ten deviations out, 53 in magnitude - carries
+                    // 1e-14), times sd <= 1/2.  4e-13 + 0.4 % of the spacing:
+                    // an entry nearer to a boundary (0.8 % of them; all of
+                    // those below theta ~ 1e-4, where the spacing itself is
+                    // 1e-12) stays with the host's arithmetic.  Flag 3: the
+                    // host takes nw and evaluates its prior density only.
+                    if (flag == 2 && new_out) {
+                        const double up = (double)nextafterf(nw, INFINITY);
+                        const double dn = (double)nextafterf(nw, -INFINITY);
+                        const double sp = fmax(up - (double)nw, (double)nw - dn);
+                        const double guard = 4e-13 + 4e-3 * sp;
+                        if (xv < 0.5 * ((double)nw + up) - guard
+                            && xv > 0.5 * ((double)nw + dn) + guard) {
+                            flag = 3;
+                            new_out[i] = nw;
+                        }
                     }
                 }
             }
@@ -2109,7 +2239,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
                       &c->chunks, &c->cnt, &c->partial, &c->part,
                       &c->lab_cnt, &c->theta_store, &c->row_idx,
                       &c->side_theta, &c->side_tabs, &c->side_out,
-                      &c->side_part};
+                      &c->side_part, &c->hint_prior};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (View &v : c->views)
@@ -2748,7 +2878,7 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
                         bnpc_top2 **top2, bool wait)
 {
     ARGCHK(c && host && top2 && col_prior, "NULL argument");
-    ARGCHK(K > 0 && K <= 64, "K out of range for the top-2 hint");
+    ARGCHK(K > 0 && K <= HINT_COLS_MAX, "K out of range for the hint");
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
     *top2 = nullptr;
     if (ldo == 0) ldo = K;
@@ -2789,8 +2919,6 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
         return 0;
     }
     if (hint) {
-        Top2Prior pr;
-        for (int k = 0; k < 64; k++) pr.v[k] = k < K ? col_prior[k] : 0.0;
         // the host's copy of the matrix as the device sees it (rows the
         // sweep is going to scan are written through by the hint kernel)
         void *pin_dev = nullptr;
@@ -2799,10 +2927,49 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
             rows_dev = (double *)pin_dev;
         else
             (void)hipGetLastError();        // not mapped: no write-through
-        hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
-                           dim3(256), 0, c->stream, (const double *)c->out.p,
-                           (long long)n, (long long)ldo, (int)K, pr,
-                           (bnpc_top2 *)zc_dev, rows_dev);
+        if (K <= 64) {
+            Top2Prior pr;
+            for (int k = 0; k < 64; k++) pr.v[k] = k < K ? col_prior[k] : 0.0;
+            hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
+                               dim3(256), 0, c->stream,
+                               (const double *)c->out.p, (long long)n,
+                               (long long)ldo, (int)K, pr, (bnpc_top2 *)zc_dev,
+                               rows_dev);
+        } else {
+            // more columns than fit the kernel's arguments: the priors in
+            // device memory (staged in the arena behind the parameters and
+            // moved by a copy kernel - every wave reads all of them, which
+            // the host link should see once; a DMA copy when the arena is
+            // full), one wave per row
+            const size_t pb = (size_t)K * sizeof(double);
+            const size_t pb2 = (pb + 15) & ~(size_t)15;
+            if (ensure(c->hint_prior, pb2)) return 1;
+            const double *staged = (const double *)stage_in_place(c, col_prior,
+                                                                  pb);
+            if (staged) {
+                const long long n2 = (long long)(pb2 / 16);
+                hipLaunchKernelGGL(k_stage_copy,
+                                   dim3((unsigned)((n2 + 255) / 256)),
+                                   dim3(256), 0, c->stream,
+                                   (const double2 *)staged,
+                                   (double2 *)c->hint_prior.p, n2);
+            } else {
+                HIPCHK(hipMemcpyAsync(c->hint_prior.p, col_prior, pb,
+                                      hipMemcpyHostToDevice, c->stream));
+            }
+            hipLaunchKernelGGL(k_row_top4_wave, dim3((unsigned)((n + 3) / 4)),
+                               dim3(256), 0, c->stream,
+                               (const double *)c->out.p, (long long)n,
+                               (long long)ldo, (int)K,
+                               (const double *)c->hint_prior.p,
+                               (bnpc_top2 *)zc_dev, rows_dev,
+                               (int)HINT_THROUGH_MAX);
+            // a row of thousands of columns is not written through: the
+            // sweep that meets such a matrix (a first sweep: nothing is
+            // decided before its first births) reads it from its first cell
+            // on - the copy is queued at once
+            if (K > HINT_THROUGH_MAX) c->matrix_eager = true;
+        }
         HIPCHK(hipGetLastError());
     }
     if (hint) {
@@ -3392,15 +3559,18 @@ extern "C" int bnpc_colcounts_by_label(bnpc_ctx *c, const int64_t *assignment,
 
 // ---- device screen of a parameter batch -----------------------------------
 // layout of the pinned block for G x M = E elements (all 16-byte aligned):
-//   U[E] f64 | u[E] f64 | sd_idx[E] i32 | theta[E] f32 | flags[E] u8
+//   U[E] f64 | u[E] f64 | sd_idx[E] i32 | theta[E] f32 | new32[E] f32 |
+//   flags[E] u8
+// (new32: the proposals whose float32 bits the screen vouches for, flag 3)
 struct MHPin {
     double *U, *u;
     int32_t *sd_idx;
     float *theta;
+    float *new32;
     uint8_t *flags;
 };
 
-static size_t mh_pin_offsets(size_t E, size_t off[5])
+static size_t mh_pin_offsets(size_t E, size_t off[6])
 {
     const size_t Ea = (E + 15) & ~(size_t)15;
     off[0] = 0;
@@ -3408,12 +3578,13 @@ static size_t mh_pin_offsets(size_t E, size_t off[5])
     off[2] = off[1] + Ea * 8;
     off[3] = off[2] + Ea * 4;
     off[4] = off[3] + Ea * 4;
-    return off[4] + Ea;
+    off[5] = off[4] + Ea * 4;
+    return off[5] + Ea;
 }
 
 static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
 {
-    size_t off[5];
+    size_t off[6];
     const size_t need = mh_pin_offsets(E, off);
     if (need > c->mh_cap) {
         // the screen of a batch in flight reads this block: nothing is in
@@ -3432,10 +3603,10 @@ static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
     char *h = (char *)c->mh_pin, *d = c->mh_dev;
     host = {(double *)(h + off[0]), (double *)(h + off[1]),
             (int32_t *)(h + off[2]), (float *)(h + off[3]),
-            (uint8_t *)(h + off[4])};
+            (float *)(h + off[4]), (uint8_t *)(h + off[5])};
     dev = {(double *)(d + off[0]), (double *)(d + off[1]),
            (int32_t *)(d + off[2]), (float *)(d + off[3]),
-           (uint8_t *)(d + off[4])};
+           (float *)(d + off[4]), (uint8_t *)(d + off[5])};
     return 0;
 }
 
@@ -3486,7 +3657,8 @@ static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
     hipLaunchKernelGGL(k_mh_screen, dim3((unsigned)((GM + 255) / 256)),
                        dim3(256), 0, c->stream, dev.theta + at, n1 + at,
                        n0 + at, dev.sd_idx + at, dev.U + at, dev.u + at, GM,
-                       (int)a->M, sum_row, k, dev.flags + at, sig);
+                       (int)a->M, sum_row, k, dev.flags + at,
+                       c->tun.screen_theta ? dev.new32 + at : nullptr, sig);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -3503,7 +3675,8 @@ static int mh_screen_argchk(const bnpc_ctx *c, const bnpc_mh_args *a)
 }
 
 extern "C" int bnpc_mh_screen(bnpc_ctx *c, int counts_src,
-                              const bnpc_mh_args *a, uint8_t *flags)
+                              const bnpc_mh_args *a, uint8_t *flags,
+                              float *new32)
 {
     if (int rc = mh_screen_argchk(c, a)) return rc;
     ARGCHK(flags, "flags is NULL");
@@ -3518,6 +3691,8 @@ extern "C" int bnpc_mh_screen(bnpc_ctx *c, int counts_src,
     if (int rc = mh_screen_launch(c, counts_src, a, d)) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(flags, h.flags, E);
+    // (defined where the flag is 3)
+    if (new32) memcpy(new32, h.new32, E * sizeof(float));
     return 0;
 }
 
@@ -3657,6 +3832,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         b.log_prob += g0;
         b.declined += g0;
         b.screen = h.flags + at;
+        b.screen_theta = h.new32 + at;
         int st = 0;
         // rank 0 of this part's evaluation issues the next part but one first
         int hook_rc = 0;
@@ -3765,6 +3941,7 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
     b.U = h.U;
     b.u = h.u;
     b.screen = h.flags;
+    b.screen_theta = h.new32;
     if (int rc = bnpc_mh_batch(k, nullptr, &b, status)) return rc;
     int64_t kept = 0;
     for (size_t i = 0; i < E; i++) kept += h.flags[i] != 0;

@@ -231,7 +231,9 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     *done = false;
     const int64_t N = ch->N, M = ch->M, K = ch->K;
     // (births write their rows into `parameters` M floats apart)
-    if (K < 1 || K > 64 || !ch->sweep_hint || ch->param_stride != M
+    // (any number of clusters whose whole matrix fits the host budget: the
+    // hint record holds its columns as 16-bit numbers)
+    if (K < 1 || K + 512 > 32767 || !ch->sweep_hint || ch->param_stride != M
         || ch->sweep_bytes / (8 * (K + 16)) < N)
         return 0;
     const double FP = ch->FP, FN = ch->FN;
@@ -257,7 +259,13 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const double prior_new = ch->crp_prior[N + 1];
     for (int64_t i = 0; i < N; i++) w.post_new[i] = w.newcl[i] + prior_new;
 
-    const int64_t spare = std::max<int64_t>(4, std::min<int64_t>(16, K / 4));
+    // spare columns for the clusters opened during the sweep (running out
+    // means a copy of the whole matrix into a wider one): a few for a
+    // converged chain, an eighth of the columns when there are hundreds or
+    // thousands (a first sweep opens about as many clusters as the data hold)
+    const int64_t spare = K <= 64
+        ? std::max<int64_t>(4, std::min<int64_t>(16, K / 4))
+        : std::min<int64_t>(512, std::max<int64_t>(16, K / 8));
     int64_t ld = K + spare;
     w.col_prior.resize((size_t)K);
     for (int64_t g = 0; g < K; g++) {
@@ -533,7 +541,7 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
 {
     *done = false;
     const int64_t K = ch->K, M = ch->M;
-    if (K < 1 || K > 64) return 0;
+    if (K < 1) return 0;
     const size_t E = (size_t)K * M;
     static const bool trace_p = [] {
         const char *e = getenv("BNPC_TIMING");
@@ -925,7 +933,11 @@ extern "C" int bnpc_chain_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
             lap.stop();
         }
     }
-    {
+    // do_step alone (no recording target at all: the caller records through
+    // update_results, which evaluates likelihood and prior itself)
+    bool record = ch->rec_assignment || ch->rec_params;
+    for (int i = 0; i < 5; i++) record = record || ch->rec_scalars[i];
+    if (record) {
         Lap lap(ch, 8);
         rc = record_phase(ctx, k, ch, w, &done);
         if (rc) return rc;

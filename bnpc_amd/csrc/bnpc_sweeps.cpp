@@ -579,6 +579,13 @@ extern "C" int bnpc_two_way_pick(int quick, double p0, double p1, double u,
     return 0;
 }
 
+// live clusters up to which a cell is decided between its two / among its three
+// candidate columns from the hint alone: the interval ends the quick picks
+// compare the uniform with carry one rounding (~1e-16) per floor entry summed,
+// 4096 of them stay a factor 20 inside the 1e-11 band the picks keep clear of
+// (the checker hooks bnpc_pair_pick / bnpc_triple_pick take the same range)
+static const int64_t QUICK_PICK_MAX = 4096;
+
 static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                         const int64_t *perm, const double *ll,
                         const double *post_new, const double *crp_prior,
@@ -615,16 +622,18 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     // prior has moved since; with it the hint decides a cell without scanning
     // it when best - drift beats everything else + drift (and the new-cluster
     // entry, and the columns born since, which are looked at) by more than
-    // the dominance margin.  Two kinds: NARROW hints (<= 64 columns, a
-    // whole-matrix sweep of a converged chain: rows indexed by cell, the pair
-    // / triple tests apply) and WIDE hints (any number of columns, the tiles
+    // the dominance margin.  Two kinds: NARROW hints (a whole-matrix sweep,
+    // up to 32767 columns - a converged chain with a dozen clusters or with
+    // hundreds, the first sweep of a data set whose matrix fits the host
+    // budget: rows indexed by cell, the pair / triple tests apply) and WIDE
+    // hints (any number of columns, the tiles
     // of a first sweep: rows indexed by tile position, the column of the
     // largest entry as a 32-bit number, the dominance test only - from the
     // moment the true clusters have been born nearly every cell is dominated
     // by one of them and the 30 000 random ones need not be walked).
     const bool tile_rows = st->row_base >= 0;
     const bnpc_top2 *hint = (st->hint && st->hint_prior && st->hint_cols > 0
-                             && (tile_rows || st->hint_cols <= 64)
+                             && (tile_rows || st->hint_cols <= 32767)
                              && st->hint_cols <= st->n_cols && FLOOR_STEP > 0)
         ? st->hint : nullptr;
     const int64_t hint_cols = hint ? st->hint_cols : 0;
@@ -660,17 +669,19 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     const double *cpr0 = st->hint_prior;
     double drift = 0.0;
     int64_t pos_of_col[64];
+    // (a table re-made at every death of a cluster: for a few columns only)
+    const bool pos_table = narrow && hint_cols <= 64;
     auto index_live = [&]() {
-        if (!narrow) return;
+        if (!pos_table) return;
         for (int64_t c = 0; c < hint_cols; c++) pos_of_col[c] = -1;
         for (int64_t a = 0; a < st->n_active; a++)
             if (order[a] < hint_cols) pos_of_col[order[a]] = a;
     };
-    // position of a live column in the live list, or -1: a table for narrow
-    // hints, a bisection for wide ones (the list is ascending in column
+    // position of a live column in the live list, or -1: a table for hints of
+    // up to 64 columns, a bisection for more (the list is ascending in column
     // index; verified by the comparison at the end)
     auto pos_of = [&](int64_t c) -> int64_t {
-        if (narrow) return pos_of_col[c];
+        if (pos_table) return pos_of_col[c];
         int64_t a = 0, b = st->n_active;
         while (a < b) {
             const int64_t mid = (a + b) >> 1;
@@ -781,7 +792,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         double second = -INFINITY;          // largest entry that is not `top`
         bool hinted = false;
         const int64_t hrow = tile_rows ? st->pos - st->row_base : cell;
-        if (hint && (narrow ? A <= 64 : true)) {
+        if (hint) {
             const bnpc_top2 &h = hint[hrow];
             // (a wide record carries its column as 32 bits in col | col2)
             const int64_t hc = narrow ? (int64_t)h.col
@@ -838,12 +849,13 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // decides it, without reading its row.
         bool pair = false;
         int64_t pair_second = 0;
-        if (narrow && !hinted && A <= 64 && shortcuts) {
+        if (narrow && !hinted && A <= QUICK_PICK_MAX && shortcuts) {
             const bnpc_top2 &h = hint[cell];
             const int64_t c1 = h.col, c2 = h.col2;
+            int64_t a1 = -1, a2 = -1;
             if (c1 >= 0 && c1 < hint_cols && c2 >= 0 && c2 < hint_cols
                 && c1 != c2 && col_size[c1] > 0 && col_size[c2] > 0
-                && pos_of_col[c1] >= 0 && pos_of_col[c2] >= 0) {
+                && (a1 = pos_of(c1)) >= 0 && (a2 = pos_of(c2)) >= 0) {
                 const double q1 = h.ll_best + cpr[c1];
                 const double q2 = h.ll_second + cpr[c2];
                 double other = h.third + drift;
@@ -857,7 +869,6 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 const double low = q1 < q2 ? q1 : q2;
                 if (q1 > -INFINITY && q1 < INFINITY && q2 > -INFINITY
                     && q2 < INFINITY && other < low - 61.0) {
-                    const int64_t a1 = pos_of_col[c1], a2 = pos_of_col[c2];
                     // first maximum in list order wins a tie, as in the scan
                     const bool first = q1 > q2 || (q1 == q2 && a1 < a2);
                     top = first ? a1 : a2;
@@ -880,13 +891,15 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         bool triple = false, have_u = false;
         int64_t triple_pick = 0;
         double u_saved = 0.0;
-        if (narrow && !hinted && !pair && A <= 64 && A >= 2 && shortcuts) {
+        if (narrow && !hinted && !pair && A <= QUICK_PICK_MAX && A >= 2
+            && shortcuts) {
             const bnpc_top2 &h = hint[cell];
             const int64_t c[3] = {h.col, h.col2, h.col3};
+            int64_t a3[3] = {-1, -1, -1};
             bool ok = c[0] != c[1] && c[0] != c[2] && c[1] != c[2];
             for (int i = 0; i < 3 && ok; i++)
                 ok = c[i] >= 0 && c[i] < hint_cols && col_size[c[i]] > 0
-                    && pos_of_col[c[i]] >= 0;
+                    && (a3[i] = pos_of(c[i])) >= 0;
             if (ok) {
                 const double q[3] = {h.ll_best + cpr[c[0]],
                                      h.ll_second + cpr[c[1]],
@@ -909,8 +922,6 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 // below is 61 against the scan's 60)
                 if (lo3 > -INFINITY && hi3 < INFINITY
                     && other < mid3 - 61.0) {
-                    const int64_t a3[3] = {pos_of_col[c[0]], pos_of_col[c[1]],
-                                           pos_of_col[c[2]]};
                     u_saved = mt_double(rng);
                     have_u = true;
                     triple_pick = triple_pick_quick(q, a3, A, u_saved);

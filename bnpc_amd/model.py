@@ -850,12 +850,14 @@ class CRP:
             # the whole matrix in one launch, rows = cell ids
             # a few spare columns for clusters opened during the sweep (the
             # matrix is re-allocated with more if they run out)
-            spare = max(4, min(16, ids.size // 4))
-            # with few clusters the device also reports, per cell, the two
-            # best columns under the priors at launch: the native loop then
-            # decides most cells without scanning them
+            spare = max(4, min(16, ids.size // 4)) if ids.size <= 64 \
+                else min(512, max(16, ids.size // 8))
+            # the device also reports, per cell, the four largest entries
+            # under the priors at launch with the columns of three: the
+            # native loop then decides most cells without scanning them
             hint = None
-            if ids.size <= 64 and _lib.env('BNPC_SWEEP_HINT', '1') != '0':
+            if ids.size + spare <= _lib.HINT_COLS_MAX \
+                    and _lib.env('BNPC_SWEEP_HINT', '1') != '0':
                 # queued, not waited for: the permutation is drawn and the
                 # sweep's private state copied under the launch (no draw of
                 # the stream sits between them in the reference either: the
@@ -1205,6 +1207,12 @@ class CRP:
                 or _lib.env('BNPC_NATIVE_MOVES', '1') == '0' \
                 or _overrides_a_step_method(self):
             return None
+        ratios = knobs['sm_ratios']
+        if len(ratios) != 2 or not abs(float(ratios[0]) + float(ratios[1])
+                - 1.) <= np.sqrt(np.finfo(np.float64).eps):
+            # np.random.choice(p=) raises for these (libs/CRP.py:427): the
+            # step-by-step path lets NumPy do so
+            return None
         ctx = self._dev()
         theta = self.parameters
         if not getattr(ctx, '_h', None) or theta is None \
@@ -1251,6 +1259,7 @@ class CRP:
         out = {'move': None, 'sm': None, 'parameters': None, 'errors': None,
             'recorded': False}
         addr = C.addressof(table)
+        caller_records = False
         while True:
             with _lib.NumpyGaussStream() as (rng, gauss):
                 st.gauss = gauss
@@ -1280,9 +1289,13 @@ class CRP:
             elif need == _lib.NEED_ERRORS:
                 out['errors'] = self.update_error_rates()
                 st.phase = _lib.PHASE_RECORD
-            else:                   # NEED_RECORD: the caller records
-                self._native_steps = getattr(self, '_native_steps', 0) + 1
-                return out
+            else:
+                # NEED_RECORD (a scalar density left to SciPy - e.g. alpha at
+                # or below the Gamma prior's location, where the reference
+                # records -inf): the step itself is complete, the caller
+                # records through put_state
+                caller_records = True
+                break
             self._state_to_chain(nat)
         self._chain_to_state(nat)
         if out['parameters'] is None:
@@ -1294,9 +1307,10 @@ class CRP:
         if st.move in (0, 1) and st.sm_cells:
             self._note_move('merge' if st.move else 'split', st.sm_cells,
                 st.sm_accepted)
-        out['recorded'] = record is not None
-        out['params_recorded'] = bool(st.rec_params_done)
-        out['ML'], out['lprior'] = st.ML, st.lprior
+        out['recorded'] = record is not None and not caller_records
+        out['params_recorded'] = out['recorded'] and bool(st.rec_params_done)
+        if not caller_records and record is not None:
+            out['ML'], out['lprior'] = st.ML, st.lprior
         self._native_steps = getattr(self, '_native_steps', 0) + 1
         return out
 
@@ -1348,6 +1362,9 @@ class CRP:
     def _chain_to_state(self, nat):
         """bnpc_chain -> model (the arrays were updated in place)."""
         st = nat.st
+        # the library counts per cluster on its own (bnpc_chain_step): the
+        # device's resident counts are no longer the ones this cache is for
+        self._lab = None
         K = st.K
         self.cells_per_cluster = dict(zip(nat.ids[:K].tolist(),
             nat.sizes[:K].tolist()))
@@ -1385,8 +1402,7 @@ class CRP:
             or not np.array_equal(lab['assignment'], self.assignment)
         ctx = self._dev()
         table = _native_kernels()
-        if stale and table is not None and getattr(ctx, '_h', None) \
-                and ids.size <= 64:
+        if stale and table is not None and getattr(ctx, '_h', None):
             # counts and batch in ONE call: the device counts, screens the
             # proposals against those counts, and hands both back together
             old = self.parameters[ids]

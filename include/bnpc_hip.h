@@ -439,9 +439,16 @@ typedef struct bnpc_mh_args {
     /* optional verdicts of the device screen (bnpc_mh_screen), G x M bytes:
      * 0 = declined for certain (the element keeps old_theta and is not
      * evaluated), 2 = accepted for certain (only the proposal's bits and
-     * its prior density are evaluated), anything else = evaluate in full.  Needs rng == NULL (the screen
-     * saw the draws) and trans_prob == 0 (scored batches need every A). */
+     * its prior density are evaluated), 3 = accepted for certain AND the
+     * proposal's float32 bits are screen_theta[g, m] (only its prior density
+     * is evaluated; without screen_theta: as 2), anything else = evaluate in
+     * full.  Needs rng == NULL (the screen saw the draws) and trans_prob == 0
+     * (scored batches need every A). */
     const uint8_t *screen;
+    /* optional, G x M: the proposals of the entries flagged 3 (the device
+     * evaluated them in float64 and found them further from both float32
+     * rounding boundaries than its value and SciPy's can be apart) */
+    const float *screen_theta;
 } bnpc_mh_args;
 
 /* *status = 0: done.  *status = 1: the draws were taken (sd_idx, U, u are
@@ -464,8 +471,11 @@ int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
  * K), 1 = the two segments of the last bnpc_view_counts (G = 2, or 3 with
  * row 2 = their sum: the merged cluster of a restricted scan).  a->sd_idx /
  * U / u hold the draws; a->trans_prob must be 0. */
+/* ... 3 where, in addition to 2, the float32 bits of the proposal are
+ * beyond doubt: new32[g, m] (optional output, defined where the flag is 3;
+ * BNPC_SCREEN_THETA=0: no 3s). */
 int bnpc_mh_screen(bnpc_ctx *ctx, int counts_src, const bnpc_mh_args *a,
-                   uint8_t *flags);
+                   uint8_t *flags, float *new32);
 /* bnpc_mh_batch with that screen in front: the draws are taken (rng != NULL)
  * straight into pinned memory, the device screens them against the resident
  * counts, the host evaluates what is left (a few per cent) exactly as

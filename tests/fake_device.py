@@ -72,9 +72,9 @@ class FakeContext:
                 wait=True):
         mat = self.ll_theta_pinned(view, theta, FP, FN, ld)
         K = np.asarray(theta).shape[0]
-        if K > 64:
+        from bnpc_amd._lib import hints_from_matrix, HINT_COLS_MAX
+        if K > HINT_COLS_MAX:
             return mat, None
-        from bnpc_amd._lib import hints_from_matrix
         hint = hints_from_matrix(mat[:, :K], col_prior)
         return mat, hint
 

@@ -974,9 +974,15 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
     data = (rng.random_sample((N, M)) < 0.3).astype(float)
     data[rng.random_sample(data.shape) < 0.2] = np.nan
     ctx = _lib.Context(data=data)
-    for K in (1, 2, 13, 64):
+    # (up to 64 columns: one thread per row, priors as kernel arguments; more:
+    # one wave per row, priors in device memory; rows of more than 1024
+    # columns are not written through)
+    for K in (1, 2, 13, 64, 65, 130, 257, 1100, 2500):
         theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
             .astype(np.float32)
+        if K > 100:             # near-duplicates: rows torn between columns
+            theta[70:90] = theta[5]
+            theta[70:90, :3] = np.clip(theta[70:90, :3] + .01, 1e-5, 1 - 1e-5)
         if K > 2:
             theta[2] = theta[0]             # an exact tie between columns
         prior = -rng.uniform(0, 9, size=K)
@@ -987,7 +993,8 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         # sweep scans) are in the host matrix already, with the hints
         here = hint['row_here'] == 1
         assert np.array_equal(here, (hint['fourth'] > hint['second'] - 72.0)
-            & (hint['second'] > hint['best'] - 48.0))
+            & (hint['second'] > hint['best'] - 48.0) & (K <= 1024))
+        assert here.any() or K <= 3 or K > 1024
         early = ll[here, :K].copy()
         ctx.matrix_wait()       # the matrix is copied behind the hints
         assert np.array_equal(early, ll[here, :K])
@@ -1018,11 +1025,42 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
                 ('ll_third', 'col3')):
             there = want[col] >= 0
             assert np.array_equal(hint[lik][there], want[lik][there]), (K, lik)
-    theta = np.clip(rng.uniform(size=(65, M)), 1e-5, 1 - 1e-5) \
-        .astype(np.float32)
-    assert ctx.ll_theta_pinned_top2(0, theta, .01, .2, 70, np.zeros(65))[1] \
-        is None
     ctx.close()
+
+
+def test_chain_with_hundreds_of_clusters_matches_oracle(monkeypatch):
+    """A running chain with 64 < K: every sweep and every parameter update
+    inside the one-call step (no phase handed back), most cells decided from
+    the device's hint - the same chain as the method-by-method walk and as
+    the oracle, state by state, from the first sweep (K0 ~ 760, its whole
+    matrix one hinted launch) on."""
+    data = H.synth(35, 1200, 300, 90, 0.2)
+    steps = 40
+    nat = _chain_by_steps(P, 'learn', data, steps, 21, (.25, .25), '1',
+        monkeypatch)
+    ref = _chain_by_steps(P, 'learn', data, steps, 21, (.25, .25), '0',
+        monkeypatch)
+    orc = _chain_by_steps(O, 'learn', data, steps, 21, (.25, .25), '0',
+        monkeypatch, peek=False)
+    K_end = len(nat[0][-1][1])
+    assert 80 <= K_end <= 110, K_end
+    assert nat[1]['native_steps'] == steps, nat[1]
+    assert ref[1]['native_steps'] == 0
+    # from the second sweep on nearly every cell is decided from its record
+    assert nat[1]['hint_used'] > 0.8 * nat[1]['swept'], nat[1]
+    assert ref[1]['hint_used'] > 0.8 * ref[1]['swept'], ref[1]
+    for i, (a, b) in enumerate(zip(nat[0], ref[0])):
+        for x, y in zip(a, b):
+            if isinstance(x, np.ndarray):
+                assert x.dtype == y.dtype and np.array_equal(x, y), i
+            else:
+                assert x == y, (i, x, y)
+    for key in nat[2]:
+        assert np.array_equal(nat[2][key], ref[2][key]), key
+    for i, (a, c) in enumerate(zip(nat[0], orc[0])):
+        assert np.array_equal(a[0], c[0]), i
+        assert a[1] == c[1], i
+        np.testing.assert_allclose(a[7], c[7], rtol=1e-9)
 
 
 def test_fused_restricted_scan_changes_nothing(monkeypatch):
@@ -1082,9 +1120,22 @@ def _screen_case(rng, ctx, data, K, theta_mode, prior, FP, FN, u_mode):
             * rng.choice([-1, 1], (K, M))
         u = np.clip(near * (1 + eps), 1e-300, 1 - 1e-16)
         new, A, decline, _ = exact(u)
-    flags = ctx.mh_screen(0, old, sd, (sd_idx, U, u), P.TMIN, P.TMAX, FP, FN,
-        prior[0], prior[1], probe.beta_prior_uniform)
+    flags, new32 = ctx.mh_screen(0, old, sd, (sd_idx, U, u), P.TMIN, P.TMAX,
+        FP, FN, prior[0], prior[1], probe.beta_prior_uniform, with_theta=True)
+    # flag 3: accepted for certain AND the device vouches for the proposal's
+    # float32 bits - they are the exact path's, bit for bit
+    given = flags == 3
+    assert not (given & decline).any()
+    assert np.array_equal(new32[given].view(np.int32),
+        new[given].view(np.int32)), np.argwhere(
+            given & (new32.view(np.int32) != new.view(np.int32)))[:3]
+    _screen_case.given += int(given.sum())
+    _screen_case.accepted += int((flags >= 2).sum())
+    flags = np.where(given, 2, flags).astype(np.uint8)
     return flags, decline, A, u
+
+
+_screen_case.given = _screen_case.accepted = 0
 
 
 def test_mh_screen_never_rules_out_a_proposal_the_exact_arithmetic_accepts():
@@ -1100,7 +1151,19 @@ def test_mh_screen_never_rules_out_a_proposal_the_exact_arithmetic_accepts():
     data = H.synth(4, 3000, 257, 5, 0.2)
     ctx = _lib.Context(data=data)
     ruled, declined_total = 0, 0
+    _screen_case.given = _screen_case.accepted = 0
     try:
+        # (the proposals the device vouches for, flag 3, on half a million
+        # entries per case: clusters of one or two cells accept most of them)
+        for theta_mode in ('uniform', 'posterior'):
+            for prior in ((.25, .25), (1, 1)):
+                _screen_case(rng, ctx, data, 2000, theta_mode, prior, .01, .2,
+                    'random')
+        # nearly every accepted proposal comes with its bits (not the ones
+        # within 0.4 % of a rounding boundary, not those below ~1e-4)
+        assert _screen_case.given > 200000 \
+            and _screen_case.given > 0.9 * _screen_case.accepted, \
+            (_screen_case.given, _screen_case.accepted)
         for K in (2, 9, 40):
             for theta_mode in ('uniform', 'posterior', 'edges'):
                 for prior in ((.25, .25), (1, 1), (.75, 2.)):
@@ -1362,10 +1425,58 @@ def test_native_step_hands_phases_back_and_resumes(monkeypatch):
                     assert x == y, (env, i, x, y)
 
 
+def test_step_whose_recording_is_handed_back(monkeypatch):
+    """NEED_RECORD: the concentration parameter at or below the location of
+    its Gamma prior (`-ap 0.01 30` on a data set of two clones: DP_a is
+    floored at 1 + eps, the prior's support starts at 30) has log-density
+    -inf in the reference, a value the
+    library leaves to SciPy - every step's recording goes back to the binding
+    (put_state), with the step's tallies complete; the same chain as the
+    oracle's, MAP = -inf included.  Also: do_step without a recording target
+    followed by update_results (the reference driver's two calls)."""
+    from bnpc_amd.mcmc import MCMC
+    import contextlib
+    import io
+    data = H.synth(36, 300, 80, 2, 0.1)
+
+    def run(mod, two_calls=False):
+        model = mod.CRP_errors_learning(data, DP_alpha=[0.01, 30.],
+            param_beta=[.25, .25], FP_mean=0.01, FP_sd=0.01, FN_mean=0.2,
+            FN_sd=0.1)
+        mcmc = MCMC(model, sm_prob=.33, dpa_prob=.5, error_prob=.25,
+            sm_ratios=[.75, .25], sm_steps=3)
+        if two_calls:
+            from bnpc_amd import mcmc as mcmc_mod
+            monkeypatch.setattr(mcmc_mod.Chain, 'step',
+                lambda self, step, burn_in=True: (self.do_step(),
+                    self.update_results(step, burn_in)))
+        with contextlib.redirect_stdout(io.StringIO()):
+            mcmc.run((40, 13), 9, 1, 0, '', True)
+        if two_calls:
+            monkeypatch.undo()
+        ran = mcmc.chains[0].model      # (the chain steps a copy)
+        stats = ran.host_stats() if hasattr(ran, 'host_stats') else {}
+        return mcmc.get_results()[0], stats
+    ro, _ = run(O)
+    rp, stats = run(P)
+    assert stats['native_steps'] == 40, stats
+    assert np.array_equal(ro['assignments'], rp['assignments'])
+    assert np.isneginf(ro['MAP']).sum() > 20 \
+        and np.array_equal(np.isneginf(ro['MAP']), np.isneginf(rp['MAP']))
+    fin = np.isfinite(ro['MAP'])
+    np.testing.assert_allclose(rp['MAP'][fin], ro['MAP'][fin], rtol=1e-9)
+    np.testing.assert_allclose(rp['ML'], ro['ML'], rtol=1e-9)
+    np.testing.assert_allclose(rp['FN'], ro['FN'], rtol=1e-9)
+    r2, stats2 = run(P, two_calls=True)
+    assert stats2['native_steps'] == 40, stats2
+    for key in ('assignments', 'ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
+        assert np.array_equal(rp[key], r2[key]), key
+
+
 @pytest.mark.parametrize('switch,value', [('BNPC_MH_SCREEN', '0'),
     ('BNPC_NATIVE_BETA', '0'), ('BNPC_STREAM_LIVE', '0'),
     ('BNPC_STREAM_LIVE', 'rng'), ('BNPC_ZERO_COPY', '0'),
-    ('BNPC_DONE_WORDS', '0')])
+    ('BNPC_DONE_WORDS', '0'), ('BNPC_SCREEN_THETA', '0')])
 def test_fallback_switches_walk_the_same_chain(switch, value, monkeypatch):
     """The documented fallbacks (README, environment switches) that no other
     test flips: the parameter batches without the device screen, Beta draws

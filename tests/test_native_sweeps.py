@@ -701,6 +701,97 @@ def test_sweep_hints_fuzz():
     assert pairs > 0.1 * cells and triples > 0.05 * cells, (pairs, triples)
 
 
+@pytest.mark.parametrize('K', [65, 150, 400, 1500])
+def test_sweep_hints_with_hundreds_of_columns(K):
+    """The same comparison for sweeps of MORE than 64 columns (a running
+    chain with hundreds of clusters; the first sweep of a data set whose
+    matrix fits the host budget): the hint's columns are found in the live
+    list by bisection instead of a table, pairs and triples are decided among
+    hundreds of floor entries.  Two kinds of matrices: settled ones (clear
+    winners, torn cells) and first-sweep ones (every column near every other
+    one - all cells scanned - until clusters are born that dominate)."""
+    decided = cells = pairs = triples = 0
+    for seed in range(12):
+        rng = np.random.RandomState(9000 + 31 * K + seed)
+        N = int(rng.choice([2 * K, 3 * K + 7, 4 * K]))
+        first_sweep = seed % 3 == 2
+        if first_sweep:
+            ll = -400 - rng.random_sample((N, K)) * 6
+        else:
+            ll = -rng.random_sample((N, K)) * 300 - 200       # far below
+            a = rng.randint(0, K, N)
+            b = (a + 1 + rng.randint(0, K - 1, N)) % K
+            ll[np.arange(N), a] = -50 - rng.random_sample(N) * 5
+            kind = rng.random_sample(N)
+            two = kind < 0.3
+            ll[two, b[two]] = ll[two, a[two]] \
+                - rng.random_sample(two.sum()) * 3
+            three = kind > 0.8
+            c = (b + 1) % K
+            c[c == a] = (c[c == a] + 1) % K
+            ll[three, b[three]] = ll[three, a[three]] \
+                - rng.random_sample(three.sum()) * 3
+            ll[three, c[three]] = ll[three, a[three]] \
+                - rng.random_sample(three.sum()) * 20
+            four = kind > 0.97
+            d = (c + 1) % K
+            d[(d == a) | (d == b) | (d == c)] = -1
+            sel = four & (d >= 0)
+            ll[sel, d[sel]] = ll[sel, a[sel]] - 25
+            # exact ties between two columns (first in list order wins)
+            tie = (kind > 0.3) & (kind < 0.33)
+            ll[tie, b[tie]] = ll[tie, a[tie]]
+        post_new = -rng.random_sample(N) * 50 - 300
+        if seed % 4 == 0:       # a few cells that may open a cluster
+            near = rng.random_sample(N) < 0.04
+            post_new[near] = -60 - rng.random_sample(near.sum()) * 10
+        if first_sweep:
+            post_new = -395 - rng.random_sample(N) * 6
+        alpha = 2.5
+        crp_prior = np.append(0, O.CRP.log_CRP_prior(
+            np.append(np.arange(1, N + 1), alpha), N, alpha))
+        labels = rng.randint(0, K, N)
+        if not first_sweep:     # most cells sit in the cluster they like best
+            labels = np.where(rng.random_sample(N) < 0.8, a, labels)
+        labels[rng.permutation(N)[:K]] = np.arange(K)
+        ids = rng.permutation(N)[:K]
+        assignment = ids[labels]
+        sizes = {int(i): int((assignment == i).sum()) for i in ids}
+        if first_sweep:
+            # born clusters: each far above everything for a tenth of the cells
+            new_columns = []
+            for j in range(N + 1):
+                col = -400 - rng.random_sample(N) * 300
+                col[rng.random_sample(N) < 0.1] = -60 - rng.random_sample() * 5
+                new_columns.append(col)
+        else:
+            new_columns = [-rng.random_sample(N) * 300 - 100
+                for _ in range(N + 1)]
+        col_prior = np.ascontiguousarray(
+            crp_prior[np.fromiter(sizes.values(), dtype=np.int64)])
+        hint = _lib.hints_from_matrix(ll, col_prior)
+        outs, used = [], []
+        for h in (None, (hint, col_prior)):
+            np.random.seed(seed)
+            got = native_gibbs(ll, post_new, crp_prior, assignment, sizes,
+                new_columns, hint=h, used=used)
+            outs.append((got[0], list(got[1].items()), got[2],
+                np.random.random(2)))
+        assert np.array_equal(outs[0][0], outs[1][0]), seed
+        assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], seed
+        assert np.array_equal(outs[0][3], outs[1][3]), seed
+        if not first_sweep:
+            decided += used[1]
+            pairs += native_gibbs.last[1]
+            triples += native_gibbs.last[2]
+            cells += N
+        else:
+            assert got[2] > 0 and used[1] > 0, (seed, got[2], used[1])
+    # (a cell whose favourite cluster has died since the launch is scanned)
+    assert decided > 0.7 * cells, (decided, cells)
+    assert pairs > 0.1 * cells and triples > 0.05 * cells, (pairs, triples)
+
+
 # ------------------------------------------------ native split / merge moves
 def test_np_sum_restated_is_numpys():
     """bnpc_sm_move sums the per-mutation terms of the likelihood ratio the
