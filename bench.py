@@ -233,6 +233,26 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t[0])
 
+    def gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (gloo)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def identity(self, own_steps_s=None):
+        """What this rank ran on: its device ordinal, the PCI bus id behind
+        it (two ranks on ONE GPU report the same one) and its own rate."""
+        from bnpc_amd import _lib
+        try:
+            bus = _lib.device_pci_bus_id(self.device)
+        except (RuntimeError, OSError):     # no GPU: the CPU harness tests
+            bus = None
+        return {'rank': self.rank, 'local_rank': self.local_rank,
+            'device': self.device, 'pci_bus_id': bus,
+            'steps_s': own_steps_s}
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
@@ -240,19 +260,55 @@ class Ranks:
 
 def timed_steps(ranks, step_fn, first, last):
     """Time steps first..last inclusive: barrier + device sync on both sides,
-    MAX over ranks."""
+    MAX over ranks.  ranks.own_s keeps this rank's own time up to the end of
+    its last step (before the closing barrier)."""
     ranks.barrier_sync()
     t0 = time.perf_counter()
     for i in range(first, last + 1):
         step_fn(i)
+    if ranks.ctx is not None:
+        ranks.ctx.sync()
+    ranks.own_s = time.perf_counter() - t0
     ranks.barrier_sync()
     return ranks.max_over_ranks(time.perf_counter() - t0)
 
 
-PMC_FILE = ('profiles', 'r04', 'pmc_final.json')
+def devices_of(ranks, steps):
+    """Every rank's device, gathered on all ranks: (list of identities,
+    number of DISTINCT GPUs among them - by PCI bus id; None without GPUs)."""
+    own = getattr(ranks, 'own_s', None)
+    ids = ranks.gather(ranks.identity(
+        None if not own else round(steps / own, 3)))
+    buses = {d['pci_bus_id'] for d in ids}
+    return ids, (None if None in buses else len(buses))
 
 
-def load_pmc_traffic(kernel_substr):
+def pmc_file(config='c3'):
+    """The newest profiles/r*/pmc_final.json (config 3; pmc_<config>.json for
+    the others) taken with THIS build's sources (its _meta.source_digest), as
+    (relative path, contents); else the newest one there is (refused below,
+    with the reason), else (None, None)."""
+    import glob
+    from bnpc_amd import build
+    want = build.source_digest()
+    newest = None
+    name = 'pmc_final.json' if config == 'c3' else f'pmc_{config}.json'
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', name)),
+            reverse=True):
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if (pmc.get('_meta') or {}).get('source_digest') == want:
+            return rel, pmc
+        if newest is None:
+            newest = (rel, pmc)
+    return newest or (None, None)
+
+
+def load_pmc_traffic(kernel_substr, config='c3'):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC
     passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units), or None.
     The counters cannot be read from inside this process, so the file must be
@@ -267,19 +323,15 @@ def load_pmc_traffic(kernel_substr):
     doubled (calibrated in round 3 against the same launch with the prefetch
     off: 68.3 MiB of scalar-stream fetches = 2.02 x 33.8;
     profiles/r03/README.md).  WRITE_SIZE is taken as it reads."""
-    path = os.path.join(ROOT, *PMC_FILE)
-    rel = os.path.join(*PMC_FILE)
-    try:
-        with open(path) as f:
-            pmc = json.load(f)
-    except (OSError, ValueError):
-        return None, f'no {rel}'
+    rel, pmc = pmc_file(config)
+    if pmc is None:
+        return None, f'no PMC passes of config {config} under profiles/'
     from bnpc_amd import build
     have = (pmc.get('_meta') or {}).get('source_digest')
     want = build.source_digest()
     if have != want:
         return None, (f'{rel} refused: taken with sources {have}, this '
-            f'build is {want} (re-run tools/r04_evidence.sh)')
+            f'build is {want} (re-run the evidence script)')
     for name, ctr in pmc.items():
         if name != '_meta' and kernel_substr in name:
             try:
@@ -403,6 +455,7 @@ def main():
     clock.on = False
     K_end = len(model.cells_per_cluster)
     ml_end = float(chain.results['ML'][total])
+    devices, distinct_gpus = devices_of(ranks, args.steps)   # (collective)
 
     # ---- roofline of the dominant kernel, measured live -------------------
     roofline = roofline_converged = None
@@ -413,10 +466,9 @@ def main():
         # the first-sweep shape: the launch that dominates the device time of
         # a chain (not inside the timed region, which is the converged regime)
         roofline, evals = ll_roofline(ctx, rng, N, M, K0, args.kernel_reps)
-        if args.config == 'c3':
-            # the committed PMC passes were taken on config 3's K0 shape
-            roofline['traffic'], roofline['traffic_source'] = \
-                load_pmc_traffic(roofline['kernel'])
+        # (the committed PMC passes of this config and this build, if any)
+        roofline['traffic'], roofline['traffic_source'] = \
+            load_pmc_traffic(roofline['kernel'], args.config)
         extra['ll_evals_per_s_K0'] = evals
         # the launch that IS inside the timed region: K_end clusters
         roofline_converged, _ = ll_roofline(ctx, rng, N, M, K_end,
@@ -426,15 +478,16 @@ def main():
             'microseconds of work, latency-bound; eval_ms = element tables + '
             'sums + combine; traffic: mean per launch of the split sums '
             'kernel + the combine pass over the bench run of the PMC passes')
-        if args.config == 'c3':
-            parts = [load_pmc_traffic(name) for name in
-                ('k_ll8_asm<2, true>', 'k_ll_combine')]
-            if all(p[0] is not None for p in parts):
-                roofline_converged['traffic'] = sum(p[0] for p in parts)
-                roofline_converged['traffic_source'] = parts[0][1]
-            else:
-                roofline_converged['traffic_source'] = \
-                    [p[1] for p in parts if p[0] is None][0]
+        names = ['k_ll8_asm<2, true>']
+        if 'combine' in roofline_converged['kernel']:
+            names.append('k_ll_combine')
+        parts = [load_pmc_traffic(name, args.config) for name in names]
+        if all(p[0] is not None for p in parts):
+            roofline_converged['traffic'] = sum(p[0] for p in parts)
+            roofline_converged['traffic_source'] = parts[0][1]
+        else:
+            roofline_converged['traffic_source'] = \
+                [p[1] for p in parts if p[0] is None][0]
         for Kc in sorted({10, 64, K_end}):
             r, ev = ll_roofline(ctx, rng, N, M, Kc, max(20, args.kernel_reps))
             extra[f'll_evals_per_s_K{Kc}'] = ev
@@ -442,7 +495,7 @@ def main():
             extra[f'll_eval_us_K{Kc}'] = round(r['eval_ms'] * 1e3, 2)
 
     # ---- CPU baseline: the oracle from the same state, 1 core -------------
-    cpu = None
+    cpu = parity = None
     if snap is not None:
         from oracle import crp_numpy as O
         om = make_model(O, O, data, learned)
@@ -457,6 +510,30 @@ def main():
         for i in range(1, args.cpu_steps + 1):
             step(ochain, i, 0)
         cpu_s = time.perf_counter() - t0
+        # the parity gate of this line: the oracle
+        # walked its steps from the GPU chain's post-warm-up snapshot on the
+        # same stream, so they ARE the GPU chain's first timed steps -
+        # identical assignments, log-likelihoods to 1e-9 - or the line is
+        # not printed
+        n_chk = min(args.cpu_steps, args.steps)
+        gpu_res, cpu_res = chain.results, ochain.results
+        same = all(np.array_equal(
+            gpu_res['assignments'][args.warmup + i],
+            cpu_res['assignments'][i]) for i in range(1, n_chk + 1))
+        g_ml = np.asarray(gpu_res['ML'][args.warmup + 1:
+            args.warmup + n_chk + 1], dtype=np.float64)
+        c_ml = np.asarray(cpu_res['ML'][1:n_chk + 1], dtype=np.float64)
+        ml_rel = float(np.max(np.abs(g_ml / c_ml - 1))) if n_chk else 0.0
+        parity = {'steps': n_chk, 'assignments_identical': bool(same),
+            'ml_max_rel': ml_rel, 'tolerance': 1e-9,
+            'against': 'oracle/crp_numpy.py from the same snapshot and '
+                'stream position'}
+        if not same or not ml_rel <= 1e-9:
+            print(json.dumps({'parity_check': parity, 'error':
+                'the GPU chain and the CPU oracle part ways'}),
+                file=sys.stderr)
+            ranks.close()
+            sys.exit(3)
         # kernel-level: _calc_ll of a few cells against K0 clusters
         theta = np.clip(np.random.RandomState(1).uniform(size=(K0, M)),
             1e-5, 1 - 1e-5).astype(np.float32)
@@ -518,7 +595,10 @@ def main():
                 else f'MCMC steps/s, {N} cells x {M} muts')
                 + ' (+ cell x cluster log-lik evals/s in ll_evals_per_s_K0)',
             'value': round(value, 3), 'unit': 'steps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            # the number of DISTINCT GPUs the ranks ran on (PCI bus ids): ranks
+            # that share one GPU count once
+            'n_gpus': distinct_gpus if distinct_gpus is not None else world,
+            'ranks': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -533,6 +613,10 @@ def main():
                 'chains': world, 'data_seed': 0, 'mcmc_seed': args.seed,
                 'K0': K0, 'K_after_warmup': K_warm, 'K_end': K_end,
             },
+            'devices': devices,
+            'per_rank_steps_s': [d['steps_s'] for d in devices],
+            'ranks_share_a_gpu': distinct_gpus is not None
+                and distinct_gpus < world,
             'host': host_info,
             'first_step_s': None if first_step_s is None
                 else round(first_step_s, 4),
@@ -543,6 +627,7 @@ def main():
             'roofline': roofline,
             'roofline_converged': roofline_converged,
             'cpu_baseline': cpu,
+            'parity_check': parity,
         }
         line.update(extra)
         if cpu:

@@ -70,7 +70,8 @@ class GibbsState(C.Structure):
         ('beta_q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
         ('FP', C.c_double), ('FN', C.c_double), ('gauss', C.c_void_p),
         ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64),
-        ('triple_used', _i64)]
+        ('triple_used', _i64), ('hint_rows_narrow', _i64),
+        ('rows_wait', C.c_void_p), ('rows_wait_arg', C.c_void_p)]
 
 
 class MoveState(C.Structure):
@@ -102,7 +103,8 @@ class MHArgs(C.Structure):
         ('prior_out', C.c_void_p), ('A', C.c_void_p),
         ('log_prob', C.c_void_p), ('declined', C.c_void_p),
         ('threads', C.c_int), ('screen', C.c_void_p),
-        ('screen_theta', C.c_void_p)]
+        ('screen_theta', C.c_void_p), ('flagged_estimate', _i64),
+        ('flag_counts', C.c_void_p)]
 
 
 class LogAArgs(C.Structure):
@@ -200,6 +202,10 @@ SIGNATURES = {
         C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
     'bnpc_matrix_wait': (C.c_int, [_ctx]),
     'bnpc_hints_wait': (C.c_int, [_ctx]),
+    'bnpc_ll_theta_perm_top2_issue': (C.c_int, [_ctx, C.c_int, _pi64, _pf,
+        _i64, C.c_double, C.c_double, _i64, _pd, _i64, _ppd,
+        C.POINTER(C.c_void_p)]),
+    'bnpc_rows_wait': (C.c_int, [_ctx, _i64, C.POINTER(_i64)]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, _ppd]),
@@ -381,6 +387,16 @@ def device_count():
     n = C.c_int(0)
     check(load().bnpc_device_count(C.byref(n)), 'device_count')
     return n.value
+
+
+def device_pci_bus_id(device=0):
+    """PCI bus id of a device ordinal (domain:bus:device.function): what tells
+    two GPUs apart whatever the visible-device lists say."""
+    mark_gpu_touched()
+    buf = C.create_string_buffer(32)
+    check(load().bnpc_device_pci_bus_id(int(device), buf, 32),
+        'device_pci_bus_id')
+    return buf.value.decode().lower()
 
 
 def device_info(device=0):

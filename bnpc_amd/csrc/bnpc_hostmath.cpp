@@ -615,8 +615,9 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         constexpr int64_t SEG = 256;
         // how many elements are flagged (what the thread count goes by): eight
         // flags at a time
-        int64_t flagged_all = 0;
-        {
+        int64_t flagged_all = a->flagged_estimate;
+        if (flagged_all <= 0) {
+            flagged_all = 0;
             const uint8_t *sc = a->screen;
             const int64_t E = G * M;
             int64_t e = 0, light = 0;   // light: flag 3 with the device's bits
@@ -635,8 +636,10 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 flagged_all += sc[e] != 0;
                 light += sc[e] == 3;
             }
-            // (a value taken and one density: a quarter of the full proposal)
-            if (a->screen_theta) flagged_all -= light - light / 4;
+            // (a value taken and one density - two special-function calls
+            // against ten: measured ~60 against ~300 ns - counted as half an
+            // entry: the segment's own pass, copies and compare come on top)
+            if (a->screen_theta) flagged_all -= light / 2;
         }
         const int64_t segs = (M + SEG - 1) / SEG;
         const int64_t n_tasks = G * segs;
@@ -649,7 +652,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // per 4 blocks from 16 blocks on - config 5 267 -> 282 steps/s, config
         // 4 1177 -> 1262; from 8 on, or a rank per 3: no further gain)
         const int64_t blocks = (flagged_all + BLK / 2 - 1) / (BLK / 2);
-        const int64_t per = blocks >= 16 ? 4 : 12;
+        // (32 blocks and more are the parts of a pipelined batch: the team
+        // is awake, spinning between the parts, and rank 0 spends the part
+        // issuing the next but one - the others should be done when it
+        // joins: a rank per 2 blocks)
+        const int64_t per = blocks >= 32 ? 2 : (blocks >= 16 ? 4 : 12);
         if (threads > (blocks + per - 1) / per)
             threads = (int)((blocks + per - 1) / per);
         if (threads > n_tasks) threads = (int)n_tasks;
@@ -751,12 +758,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                     ok = mh_block(k, a, c, g, sure + lo, 0,
                                   std::min(BLK / 2, ns - lo), true);
                 if (!ok) bail.store(1, std::memory_order_relaxed);
-                if (trace) {
-                    n_todo.fetch_add(nt, std::memory_order_relaxed);
-                    n_sure.fetch_add(ns, std::memory_order_relaxed);
-                    n_given.fetch_add(ng, std::memory_order_relaxed);
+                if (nt) n_todo.fetch_add(nt, std::memory_order_relaxed);
+                if (ns) n_sure.fetch_add(ns, std::memory_order_relaxed);
+                if (ng) n_given.fetch_add(ng, std::memory_order_relaxed);
+                if (trace)
                     n_miss.fetch_add(missed, std::memory_order_relaxed);
-                }
             }
         };
         const long t_prep = trace ? since() : 0;
@@ -785,6 +791,11 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                     (long long)n_sure.load(), (long long)n_given.load(),
                     (long long)(G * M), (long long)n_miss.load(), threads,
                     since() / 1e3, t_prep / 1e3);
+        if (a->flag_counts) {
+            a->flag_counts[0] = n_todo.load();
+            a->flag_counts[1] = n_sure.load();
+            a->flag_counts[2] = n_given.load();
+        }
         if (bail.load()) {
             *status = 1;
             return 0;

@@ -122,6 +122,7 @@ struct Tunables {
                                     // record)
 #define HINT_THROUGH_MAX 1024       // ... up to which rows that will be scanned
                                     // are written through to the host
+#define HINT_CHUNKS_MAX 16          // row chunks of a pipelined hinted sweep
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
 
@@ -151,6 +152,11 @@ struct DoneSignal {
     unsigned *count;    // device word, zero between launches
     unsigned *flag;     // pinned host word (device address)
     unsigned seq;
+};
+
+// the column priors of a hint launch of up to 64 columns (kernel argument)
+struct Top2Prior {
+    double v[64];
 };
 
 struct bnpc_ctx {
@@ -201,6 +207,22 @@ struct bnpc_ctx {
     void *hint_pin = nullptr;       // the sweep's per-cell hints (pinned)
     size_t hint_cap = 0;
     DevBuf hint_prior;              // priors of a hinted sweep with > 64 columns
+    void *hint_prior_pin = nullptr; // ... staged here (pinned, HINT_COLS_MAX)
+    // A hinted sweep in ROW CHUNKS (bnpc_ll_theta_perm_top2_issue): the sums
+    // and the hints of chunk c are launched per chunk, the hint kernel of
+    // each writes a completion word; the host walks chunk c while the device
+    // works on c + 1 ...
+    struct {
+        bool active = false;        // the launch in progress is chunked
+        int64_t rows = 0;           // rows per chunk (a multiple of 64)
+        int n = 0;                  // chunks issued by the last such sweep
+        int64_t end[HINT_CHUNKS_MAX] = {};
+        unsigned seq[HINT_CHUNKS_MAX] = {};
+        int64_t K = 0, ldo = 0;
+        Top2Prior prior;            // K <= 64
+        void *hint_dev = nullptr;
+        double *rows_dev = nullptr;
+    } chunk;
     // pinned block of a screened parameter batch (bnpc_mh_batch_dev): the
     // draws, the old parameter rows and the screen's verdicts, read / written
     // in place by k_mh_screen
@@ -1481,17 +1503,14 @@ __global__ __launch_bounds__(256) void k_stage_copy(
 // priors travel as kernel arguments (no memory to fetch them from); the matrix
 // was just written and is read from L2.
 // ---------------------------------------------------------------------------
-struct Top2Prior {
-    double v[64];
-};
-
 __global__ __launch_bounds__(256) void k_row_top2(
     const double *__restrict__ ll, long long n, long long ldo, int K,
     Top2Prior prior, bnpc_top2 *__restrict__ out,
-    double *__restrict__ host_ll)
+    double *__restrict__ host_ll, DoneSignal done)
 {
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (slot >= n) return;
+    // (no early return: every thread reaches signal_done)
+    if (slot < n) {
     const double *__restrict__ r = ll + (size_t)slot * ldo;
     double best = -INFINITY, second = -INFINITY, third = -INFINITY;
     double fourth = -INFINITY;
@@ -1553,6 +1572,8 @@ __global__ __launch_bounds__(256) void k_row_top2(
     }
     t.row_here = (int16_t)through;
     out[slot] = t;
+    }
+    signal_done(done);
 }
 
 // The same record for rows of MORE than 64 columns (a running chain with
@@ -1597,11 +1618,12 @@ __device__ __forceinline__ void top4_insert(Top4 &q, double v, double l, int k)
 __global__ __launch_bounds__(256) void k_row_top4_wave(
     const double *__restrict__ ll, long long n, long long ldo, int K,
     const double *__restrict__ prior, bnpc_top2 *__restrict__ out,
-    double *__restrict__ host_ll, int through_max)
+    double *__restrict__ host_ll, int through_max, DoneSignal done)
 {
     const int lane = threadIdx.x & 63;
     const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= n) return;
+    // (no early return: every wave reaches signal_done)
+    if (slot < n) {
     const double *__restrict__ r = ll + (size_t)slot * ldo;
     const int none = 0x7fffffff;
     Top4 q = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0, 0.0, 0.0,
@@ -1650,6 +1672,8 @@ __global__ __launch_bounds__(256) void k_row_top4_wave(
         t.row_here = (int16_t)through;
         out[slot] = t;
     }
+    }
+    signal_done(done);
 }
 
 // ---------------------------------------------------------------------------
@@ -2250,6 +2274,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
+    if (c->hint_prior_pin) (void)hipHostFree(c->hint_prior_pin);
     if (c->mh_pin) (void)hipHostFree(c->mh_pin);
     for (int p = 0; p < 2; p++)
         if (c->mh_ev[p]) (void)hipEventDestroy(c->mh_ev[p]);
@@ -2596,6 +2621,9 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     return 0;
 }
 
+static int chunk_hint_launch(bnpc_ctx *c, int64_t row0, int64_t rows,
+                             const double *d_out);
+
 template <int KW>
 static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                      bool from_theta, double FP, double FN, double *d_out,
@@ -2633,6 +2661,25 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                            c->tab_src + (size_t)K * c->M,
                            (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
     HIPCHK(hipGetLastError());
+    if (c->chunk.active && c->chunk.rows > 0 && from_theta) {
+        // row chunks: the sums of a chunk, then its hints (chunk_hint_launch)
+        const int64_t cb = c->chunk.rows / 64;
+        c->chunk.n = 0;
+        for (int64_t b0 = 0; b0 < v.nblk; b0 += cb) {
+            View sub;
+            sub.masks.p = (ulonglong2 *)v.masks.p + (size_t)b0 * c->Mpad;
+            sub.nblk = std::min<int64_t>(cb, v.nblk - b0);
+            sub.n = std::min<int64_t>(sub.nblk * 64, v.n - b0 * 64);
+            int ms, mc;
+            pick_msplit(c->tun, sub.nblk * G, c->Mt, c->tun.msplit != 0, &ms,
+                        &mc);
+            if (issue_ll<KW>(c, sub, K, ldo, d_out + (size_t)b0 * 64 * ldo, ms,
+                             mc))
+                return 1;
+            if (int rc = chunk_hint_launch(c, b0 * 64, sub.n, d_out)) return rc;
+        }
+        return 0;
+    }
     if (issue_ll<KW>(c, v, K, ldo, d_out, MS, m_chunk)) return 1;
     return 0;
 }
@@ -2695,6 +2742,8 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
         && v.nblk * ((K + 7) / 8) < msplit_limit(c->tun))
         kw = 8;
     if (c->tun.force_kw) kw = c->tun.force_kw;
+    // (row chunks are small launches of their own: the hand-placed kernel)
+    if (c->chunk.active && from_theta && K >= 2) kw = 8;
     // Sums over caller-built tables keep the strict mutation order (they are
     // the bit-exact path); device-built tables may split the mutations.
     int MS, m_chunk;
@@ -2872,16 +2921,70 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     return 0;
 }
 
+// the hint kernel over rows [row0, row0 + rows) of the matrix at d_ll (row
+// stride ldo): up to 64 columns one thread per row with the priors as kernel
+// arguments, more one wave per row with the priors in c->hint_prior
+static int hint_launch(bnpc_ctx *c, const double *d_ll, int64_t row0,
+                       int64_t rows, int64_t K, int64_t ldo,
+                       const Top2Prior &pr, void *hint_dev, double *rows_dev,
+                       DoneSignal sig)
+{
+    const double *ll = d_ll + (size_t)row0 * ldo;
+    bnpc_top2 *out = (bnpc_top2 *)hint_dev + row0;
+    double *through = rows_dev ? rows_dev + (size_t)row0 * ldo : nullptr;
+    if (K <= 64)
+        hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((rows + 255) / 256)),
+                           dim3(256), 0, c->stream, ll, (long long)rows,
+                           (long long)ldo, (int)K, pr, out, through, sig);
+    else
+        hipLaunchKernelGGL(k_row_top4_wave, dim3((unsigned)((rows + 3) / 4)),
+                           dim3(256), 0, c->stream, ll, (long long)rows,
+                           (long long)ldo, (int)K,
+                           (const double *)c->hint_prior.p, out, through,
+                           (int)HINT_THROUGH_MAX, sig);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// the hints of one row chunk of a pipelined sweep, with their completion word
+// (slot 1: nothing else signals there while a sweep is being walked)
+static int chunk_hint_launch(bnpc_ctx *c, int64_t row0, int64_t rows,
+                             const double *d_out)
+{
+    ARGCHK(c->chunk.n < HINT_CHUNKS_MAX, "too many row chunks");
+    unsigned seq = 0;
+    const DoneSignal sig = make_signal(c, 1, &seq);
+    if (int rc = hint_launch(c, d_out, row0, rows, c->chunk.K, c->chunk.ldo,
+                             c->chunk.prior, c->chunk.hint_dev,
+                             c->chunk.rows_dev, sig))
+        return rc;
+    c->chunk.end[c->chunk.n] = row0 + rows;
+    c->chunk.seq[c->chunk.n] = seq;     // 0: no completion words
+    c->chunk.n++;
+    return 0;
+}
+
+// perm != NULL: the rows of the matrix and of the hints are the POSITIONS of
+// the visiting order `perm` (view `view` is set to it first), evaluated in
+// row chunks of chunk_rows (bnpc_ll_theta_perm_top2_issue)
 static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
                         double FP, double FN, int64_t ldo,
                         const double *col_prior, double **host,
-                        bnpc_top2 **top2, bool wait)
+                        bnpc_top2 **top2, bool wait,
+                        const int64_t *perm = nullptr, int64_t chunk_rows = 0)
 {
     ARGCHK(c && host && top2 && col_prior, "NULL argument");
     ARGCHK(K > 0 && K <= HINT_COLS_MAX, "K out of range for the hint");
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
     *top2 = nullptr;
+    c->chunk.n = 0;
     if (ldo == 0) ldo = K;
+    ARGCHK(!c->any_tile_pending(),
+           "not available while an issued tile is in flight");
+    if (perm) {
+        ARGCHK(view >= 1, "the visiting order needs a view of its own");
+        if (int rc = bnpc_view_set(c, view, perm, c->N)) return rc;
+    }
     const int64_t n = c->views[view].n;
     // the hints of all slots, written in place into pinned host memory of
     // their own: they must outlive the calls made DURING the sweep (a column
@@ -2905,73 +3008,80 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     ARGCHK(theta, "theta is NULL");
     ARGCHK(ldo >= K, "ldo smaller than K");
     *host = nullptr;
-    ARGCHK(!c->any_tile_pending(),
-           "not available while an issued tile is in flight");
     const size_t bytes = (size_t)n * ldo * sizeof(double);
     if (bytes && ensure_pin(c, bytes)) return 1;
     // did the previous hinted sweep read its matrix?
     c->matrix_eager = c->lazy_fetched;
     c->lazy_fetched = false;
-    int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
-    if (rc) return rc;
-    if (bytes == 0) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        return 0;
-    }
-    if (hint) {
-        // the host's copy of the matrix as the device sees it (rows the
-        // sweep is going to scan are written through by the hint kernel)
+    // the host's copy of the matrix as the device sees it (rows the sweep is
+    // going to scan are written through by the hint kernel)
+    double *rows_dev = nullptr;
+    Top2Prior pr;
+    if (hint && bytes) {
         void *pin_dev = nullptr;
-        double *rows_dev = nullptr;
         if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
             rows_dev = (double *)pin_dev;
         else
             (void)hipGetLastError();        // not mapped: no write-through
         if (K <= 64) {
-            Top2Prior pr;
             for (int k = 0; k < 64; k++) pr.v[k] = k < K ? col_prior[k] : 0.0;
-            hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
-                               dim3(256), 0, c->stream,
-                               (const double *)c->out.p, (long long)n,
-                               (long long)ldo, (int)K, pr, (bnpc_top2 *)zc_dev,
-                               rows_dev);
         } else {
             // more columns than fit the kernel's arguments: the priors in
-            // device memory (staged in the arena behind the parameters and
-            // moved by a copy kernel - every wave reads all of them, which
-            // the host link should see once; a DMA copy when the arena is
-            // full), one wave per row
+            // device memory - every wave reads all of them, which the host
+            // link should see once: staged in a pinned block of their own
+            // (the arena is reset by the evaluation below) and moved by a
+            // copy kernel ahead of everything else
             const size_t pb = (size_t)K * sizeof(double);
             const size_t pb2 = (pb + 15) & ~(size_t)15;
             if (ensure(c->hint_prior, pb2)) return 1;
-            const double *staged = (const double *)stage_in_place(c, col_prior,
-                                                                  pb);
-            if (staged) {
-                const long long n2 = (long long)(pb2 / 16);
-                hipLaunchKernelGGL(k_stage_copy,
-                                   dim3((unsigned)((n2 + 255) / 256)),
-                                   dim3(256), 0, c->stream,
-                                   (const double2 *)staged,
-                                   (double2 *)c->hint_prior.p, n2);
-            } else {
-                HIPCHK(hipMemcpyAsync(c->hint_prior.p, col_prior, pb,
-                                      hipMemcpyHostToDevice, c->stream));
-            }
-            hipLaunchKernelGGL(k_row_top4_wave, dim3((unsigned)((n + 3) / 4)),
-                               dim3(256), 0, c->stream,
-                               (const double *)c->out.p, (long long)n,
-                               (long long)ldo, (int)K,
-                               (const double *)c->hint_prior.p,
-                               (bnpc_top2 *)zc_dev, rows_dev,
-                               (int)HINT_THROUGH_MAX);
-            // a row of thousands of columns is not written through: the
-            // sweep that meets such a matrix (a first sweep: nothing is
-            // decided before its first births) reads it from its first cell
-            // on - the copy is queued at once
-            if (K > HINT_THROUGH_MAX) c->matrix_eager = true;
+            if (!c->hint_prior_pin)
+                HIPCHK(hipHostMalloc(&c->hint_prior_pin,
+                                     ((size_t)HINT_COLS_MAX + 1) * 8,
+                                     hipHostMallocDefault));
+            void *pp_dev = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&pp_dev, c->hint_prior_pin, 0));
+            memcpy(c->hint_prior_pin, col_prior, pb);
+            const long long n2 = (long long)(pb2 / 16);
+            hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+                               dim3(256), 0, c->stream, (const double2 *)pp_dev,
+                               (double2 *)c->hint_prior.p, n2);
+            HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipGetLastError());
     }
+    const bool chunked = perm && hint && bytes && chunk_rows >= 64
+        && chunk_rows < n;
+    if (chunked) {
+        c->chunk.active = true;
+        c->chunk.rows = (chunk_rows + 63) / 64 * 64;
+        if ((n + c->chunk.rows - 1) / c->chunk.rows > HINT_CHUNKS_MAX)
+            c->chunk.rows = ((n + HINT_CHUNKS_MAX - 1) / HINT_CHUNKS_MAX + 63)
+                / 64 * 64;
+        c->chunk.K = K;
+        c->chunk.ldo = ldo;
+        c->chunk.prior = pr;
+        c->chunk.hint_dev = zc_dev;
+        c->chunk.rows_dev = rows_dev;
+    }
+    int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
+    c->chunk.active = false;
+    if (rc) {
+        c->chunk.n = 0;
+        return rc;
+    }
+    if (bytes == 0) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    if (hint && c->chunk.n == 0) {
+        if (int rh = hint_launch(c, (const double *)c->out.p, 0, n, K, ldo, pr,
+                                 zc_dev, rows_dev,
+                                 DoneSignal{nullptr, nullptr, 0}))
+            return rh;
+    }
+    // a row of thousands of columns is not written through: the sweep that
+    // meets such a matrix (a first sweep: nothing is decided before its first
+    // births) reads it from its first cell on - the copy is queued at once
+    if (hint && K > HINT_THROUGH_MAX) c->matrix_eager = true;
     if (hint) {
         // the caller gets the hints now; the matrix stays on the device and
         // is copied if and when the sweep first needs a row of it
@@ -3037,6 +3147,88 @@ extern "C" int bnpc_matrix_wait(bnpc_ctx *c)
                               c->stream));
     c->pin_copy_queued = false;
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// A hinted sweep whose rows are the POSITIONS of the visiting order, in row
+// chunks (include/bnpc_hip.h): view `view` is set to perm, the element tables
+// are built once, then per chunk the sums (+ combine) and the hint kernel,
+// which ends with a completion word - the host walks chunk c while the device
+// works on chunk c + 1.  chunk_rows = 0: four chunks, whole workgroups of the
+// sums kernel (512 rows), none for fewer than 2048 rows.
+extern "C" int bnpc_ll_theta_perm_top2_issue(bnpc_ctx *c, int view,
+                                             const int64_t *perm,
+                                             const float *theta, int64_t K,
+                                             double FP, double FN,
+                                             int64_t ldo,
+                                             const double *col_prior,
+                                             int64_t chunk_rows,
+                                             double **host, bnpc_top2 **top2)
+{
+    ARGCHK(c && perm, "NULL argument");
+    if (chunk_rows <= 0) {
+        chunk_rows = ((c->N + 3) / 4 + 511) / 512 * 512;
+        if (c->N < 2048) chunk_rows = c->N;
+    }
+    return ll_top2_impl(c, view, theta, K, FP, FN, ldo, col_prior, host, top2,
+                        false, perm, chunk_rows);
+}
+
+// Rows [0, *ready_end) of the hints of the last chunked sweep are complete on
+// return, *ready_end > pos: waits for the chunk that holds position `pos`
+// (its completion word, polled for up to ~20 ms; then - or without completion
+// words - the stream).  A sweep that was not chunked: all rows, through
+// bnpc_hints_wait.
+extern "C" int bnpc_rows_wait(bnpc_ctx *c, int64_t pos, int64_t *ready_end)
+{
+    ARGCHK(c && ready_end, "NULL argument");
+    const int64_t n_all = c->chunk.n ? c->chunk.end[c->chunk.n - 1] : 0;
+    if (c->chunk.n == 0 || pos >= n_all) {
+        *ready_end = INT64_MAX;
+        return bnpc_hints_wait(c);
+    }
+    int ci = 0;
+    while (ci < c->chunk.n - 1 && c->chunk.end[ci] <= pos) ci++;
+    const unsigned seq = c->chunk.seq[ci];
+    bool seen = false;
+    if (seq && c->done_pin) {
+        const volatile unsigned *f = c->done_pin + 16 * 1;
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0;; spins++) {
+            if ((int)(*f - seq) >= 0) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                seen = true;
+                break;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((spins & 1023) == 1023) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000L
+                        + (t1.tv_nsec - t0.tv_nsec) > 20000000L)
+                    break;
+            }
+        }
+    }
+    if (!seen) {
+        // everything queued so far: all chunks
+        HIPCHK(hipSetDevice(c->device));
+        if (c->ev_hints && c->pin_lazy_bytes)
+            HIPCHK(hipEventSynchronize(c->ev_hints));
+        else
+            HIPCHK(hipStreamSynchronize(c->stream));
+        *ready_end = INT64_MAX;
+        return 0;
+    }
+    // later chunks that have finished meanwhile count too
+    const unsigned word = *(const volatile unsigned *)(c->done_pin + 16 * 1);
+    while (ci + 1 < c->chunk.n && c->chunk.seq[ci + 1]
+           && (int)(word - c->chunk.seq[ci + 1]) >= 0)
+        ci++;
+    *ready_end = ci == c->chunk.n - 1 ? INT64_MAX : c->chunk.end[ci];
     return 0;
 }
 
@@ -3798,6 +3990,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     }
     if (trace) clock_gettime(CLOCK_MONOTONIC, &ts1);
     int64_t kept = 0;
+    double weighted_per_row = 0.0;      // flagged entries of the parts so far
     *status = 0;
     for (int p = 0; p < parts; p++) {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
@@ -3833,6 +4026,14 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         b.declined += g0;
         b.screen = h.flags + at;
         b.screen_theta = h.new32 + at;
+        // (the flags sit in memory the device has just written: a pass over
+        // them - to size the team, to count what was left - is 10-15 us of
+        // misses per part on the calling thread; the team counts while it
+        // works, and the parts of one batch leave about the same share)
+        int64_t counts[3] = {0, 0, 0};
+        b.flag_counts = counts;
+        b.flagged_estimate = p == 0 ? 0
+            : std::max<int64_t>(1, (int64_t)(weighted_per_row * (double)Gp));
         int st = 0;
         // rank 0 of this part's evaluation issues the next part but one first
         int hook_rc = 0;
@@ -3848,8 +4049,9 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
             return rc;
         }
         if (st) *status = 1;
-        for (size_t i = 0; i < (size_t)Gp * M; i++)
-            kept += h.flags[at + i] != 0;
+        kept += counts[0] + counts[1] + counts[2];
+        weighted_per_row = ((double)(counts[0] + counts[1])
+            + 0.5 * (double)counts[2]) / (double)Gp;
         if (trace) clock_gettime(CLOCK_MONOTONIC, &t_hosted[p]);
     }
     c->screened += (int64_t)E;
@@ -3942,11 +4144,11 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
     b.u = h.u;
     b.screen = h.flags;
     b.screen_theta = h.new32;
+    int64_t counts[3] = {0, 0, 0};
+    b.flag_counts = counts;
     if (int rc = bnpc_mh_batch(k, nullptr, &b, status)) return rc;
-    int64_t kept = 0;
-    for (size_t i = 0; i < E; i++) kept += h.flags[i] != 0;
     c->screened += (int64_t)E;
-    c->screen_kept += kept;
+    c->screen_kept += counts[0] + counts[1] + counts[2];
     if (*status != 0) {
         memcpy(a->sd_idx, h.sd_idx, E * 4);
         memcpy(a->U, h.U, E * 8);

@@ -637,7 +637,12 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                              && st->hint_cols <= st->n_cols && FLOOR_STEP > 0)
         ? st->hint : nullptr;
     const int64_t hint_cols = hint ? st->hint_cols : 0;
-    const bool narrow = hint && !tile_rows;
+    // (narrow records on rows that are positions: a whole-matrix sweep in
+    // visiting order, bnpc_ll_theta_perm_top2_issue)
+    const bool narrow = hint && (!tile_rows || st->hint_rows_narrow);
+    // rows that arrive while the loop runs (row chunks of a pipelined sweep)
+    const bool rows_arrive = tile_rows && st->rows_wait != nullptr;
+    int64_t rows_ready = rows_arrive ? 0 : INT64_MAX;
     const int64_t hint_rows = !hint ? 0
         : (tile_rows ? st->pos_end - st->row_base : N);
     // The hints sit in pinned memory the device has just written: every line
@@ -653,7 +658,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     // (up to 1 MiB of hints, 16 384 cells: at config 5's 3.2 MB the pass
     // itself runs at 2 GB/s and costs more than the misses it saves - Gibbs
     // step 3.6-4.5 against 2.05 ms - while 640 KB at config 4 still gain)
-    if (hint && (size_t)hint_rows * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
+    // (rows that arrive in order are read in order: no copy - it would have
+    // to wait for all of them)
+    if (hint && !rows_arrive
+        && (size_t)hint_rows * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
         // (a sweep resumed after a birth in the caller finds its copy; the
         // pinned buffers of tiles are re-used, so a tile copies at its start)
         const int64_t start = tile_rows ? st->row_base : 0;
@@ -718,6 +726,13 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 
     int64_t free_hint = 0;      // no id below it is free (native births)
     while (st->pos < st->pos_end) {
+        if (st->pos - st->row_base >= rows_ready) {
+            if (st->rows_wait(st->rows_wait_arg, st->pos - st->row_base,
+                              &rows_ready)) {
+                bnpc_set_error("waiting for a row chunk of the sweep failed");
+                return 5;
+            }
+        }
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
         // per-cell scalars) of a cell a few positions ahead into the cache
@@ -850,7 +865,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         bool pair = false;
         int64_t pair_second = 0;
         if (narrow && !hinted && A <= QUICK_PICK_MAX && shortcuts) {
-            const bnpc_top2 &h = hint[cell];
+            const bnpc_top2 &h = hint[hrow];
             const int64_t c1 = h.col, c2 = h.col2;
             int64_t a1 = -1, a2 = -1;
             if (c1 >= 0 && c1 < hint_cols && c2 >= 0 && c2 < hint_cols
@@ -893,7 +908,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         double u_saved = 0.0;
         if (narrow && !hinted && !pair && A <= QUICK_PICK_MAX && A >= 2
             && shortcuts) {
-            const bnpc_top2 &h = hint[cell];
+            const bnpc_top2 &h = hint[hrow];
             const int64_t c[3] = {h.col, h.col2, h.col3};
             int64_t a3[3] = {-1, -1, -1};
             bool ok = c[0] != c[1] && c[0] != c[2] && c[1] != c[2];
@@ -938,7 +953,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             // - which the hint kernel has written through for the rows it
             // could tell would be scanned - and columns born since, which
             // were written here after the matrix had arrived
-            if (!(narrow && hint[cell].row_here == 1
+            if (!(narrow && hint[hrow].row_here == 1
                   && (A == 0 || order[A - 1] < hint_cols)))
                 NEED_MATRIX()
         }

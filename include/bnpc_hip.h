@@ -184,6 +184,24 @@ int bnpc_ll_theta_pinned_top2_issue(bnpc_ctx *ctx, int view,
                                     bnpc_top2 **top2);
 /* the hints of the last ..._issue call are complete on return */
 int bnpc_hints_wait(bnpc_ctx *ctx);
+/* The same evaluation with the rows in VISITING ORDER, in row chunks, so that
+ * the sequential loop (libs/CRP.py:260-288 needs row c only when it reaches
+ * cell perm[c]) runs under the kernels: view `view` (>= 1) is set to the N
+ * cells of perm; row r of *host and of *top2 belongs to cell perm[r]; the
+ * element tables are built once, then per chunk of chunk_rows rows (0: four
+ * chunks) the sums and the hints are launched and the hint kernel ends with
+ * a completion word.  bnpc_rows_wait(ctx, r, &end) returns once rows [0, end)
+ * of the hints are complete, end > r (INT64_MAX: all of them).  The loop
+ * takes them through bnpc_gibbs_state.rows_wait with row_base = 0 and
+ * hint_rows_narrow = 1.  Pays from ~1e9 element evaluations on (a running
+ * chain on 50 000 x 5 000: the loop runs under the sums instead of after
+ * them, and reads its hints in order). */
+int bnpc_ll_theta_perm_top2_issue(bnpc_ctx *ctx, int view,
+                                  const int64_t *perm, const float *theta,
+                                  int64_t K, double FP, double FN, int64_t ldo,
+                                  const double *col_prior, int64_t chunk_rows,
+                                  double **host, bnpc_top2 **top2);
+int bnpc_rows_wait(bnpc_ctx *ctx, int64_t row, int64_t *ready_end);
 /* When *top2 is returned non-NULL the matrix behind *host has NOT been copied
  * yet: it stays on the device until bnpc_matrix_wait fetches it (the sweep
  * reads it only where a hint is in doubt - a settled sweep never does; when
@@ -449,6 +467,13 @@ typedef struct bnpc_mh_args {
      * evaluated them in float64 and found them further from both float32
      * rounding boundaries than its value and SciPy's can be apart) */
     const float *screen_theta;
+    /* screened batches, optional: flagged_estimate > 0 = about how many
+     * entries carry a non-zero flag (the team is sized by it; 0: the flags are
+     * counted first, one pass of the calling thread); flag_counts != NULL
+     * receives the numbers found: [0] in doubt, [1] accepted for certain,
+     * [2] accepted with the device's bits */
+    int64_t flagged_estimate;
+    int64_t *flag_counts;
 } bnpc_mh_args;
 
 /* *status = 0: done.  *status = 1: the draws were taken (sd_idx, U, u are
@@ -651,6 +676,18 @@ typedef struct bnpc_gibbs_state {
     int64_t born_cap, n_born;
     int64_t triple_used;    /* out: of hint_used, cells decided among the row's
                              * three best columns */
+    /* row_base >= 0 with hint_rows_narrow != 0: the hint records are the
+     * NARROW ones (bnpc_ll_theta_perm_top2_issue: a whole-matrix sweep whose
+     * rows are the positions of the visiting order) although the rows are
+     * positions - the pair / triple tests apply */
+    int64_t hint_rows_narrow;
+    /* if not NULL: rows (positions - row_base) of hint / ll become available
+     * in order while the loop runs; called with (rows_wait_arg, row, &end)
+     * before the first use of a row >= the end reported last (0 at the
+     * start): returns once rows [0, end) are complete, end > row
+     * (bnpc_rows_wait with its context) */
+    int (*rows_wait)(void *, int64_t, int64_t *);
+    void *rows_wait_arg;
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

@@ -62,7 +62,8 @@ def _rank_main(rank, world, port, out):
     ranks = bench.Ranks().init()
     delay = 0.01 * (rank + 1)           # rank 1 is the slow one
     el = bench.timed_steps(ranks, lambda i: time.sleep(delay), 1, 5)
-    out.put((rank, el))
+    devices, distinct = bench.devices_of(ranks, 5)
+    out.put((rank, (el, devices, distinct)))
     ranks.close()
 
 
@@ -80,8 +81,21 @@ def test_bench_rank_harness_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     # both ranks report the MAX over ranks: the slow rank's 5 x 20 ms
-    assert abs(got[0] - got[1]) < 1e-9
-    assert 0.09 < got[0] < 0.5
+    assert abs(got[0][0] - got[1][0]) < 1e-9
+    assert 0.09 < got[0][0] < 0.5
+    # ... and every rank's identity (device ordinal, PCI bus id, own rate) is
+    # gathered on all of them: what the line's `devices`, `per_rank_steps_s`
+    # and `n_gpus` (distinct bus ids) are made of.  No GPU here: no bus id,
+    # no count of distinct GPUs.
+    for r in (0, 1):
+        devices, distinct = got[r][1], got[r][2]
+        assert [d['rank'] for d in devices] == [0, 1]
+        assert all(d['pci_bus_id'] is None for d in devices)
+        assert distinct is None
+        # own rates: rank 0 sleeps 10 ms a step, rank 1 20 ms
+        assert 60 < devices[0]['steps_s'] < 101
+        assert 30 < devices[1]['steps_s'] < 51
+    assert got[0][1] == got[1][1]
 
 
 def test_lugsail_mode_extends_chains_until_psrf_cutoff(monkeypatch):
