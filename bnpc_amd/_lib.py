@@ -70,8 +70,7 @@ class GibbsState(C.Structure):
         ('beta_q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
         ('FP', C.c_double), ('FN', C.c_double), ('gauss', C.c_void_p),
         ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64),
-        ('triple_used', _i64), ('hint_rows_narrow', _i64),
-        ('rows_wait', C.c_void_p), ('rows_wait_arg', C.c_void_p)]
+        ('triple_used', _i64), ('hint_in_order', _i64)]
 
 
 class MoveState(C.Structure):
@@ -202,10 +201,10 @@ SIGNATURES = {
         C.c_double, C.c_double, _i64, _pd, _ppd, C.POINTER(C.c_void_p)]),
     'bnpc_matrix_wait': (C.c_int, [_ctx]),
     'bnpc_hints_wait': (C.c_int, [_ctx]),
-    'bnpc_ll_theta_perm_top2_issue': (C.c_int, [_ctx, C.c_int, _pi64, _pf,
-        _i64, C.c_double, C.c_double, _i64, _pd, _i64, _ppd,
+    'bnpc_ll_theta_pinned_sums_issue': (C.c_int, [_ctx, C.c_int, _pf, _i64,
+        C.c_double, C.c_double, _i64, _pd, _ppd]),
+    'bnpc_hints_in_order_issue': (C.c_int, [_ctx, _pi64,
         C.POINTER(C.c_void_p)]),
-    'bnpc_rows_wait': (C.c_int, [_ctx, _i64, C.POINTER(_i64)]),
     'bnpc_theta_put': (C.c_int, [_ctx, _i64, _pf, _i64]),
     'bnpc_ll_rows_pinned': (C.c_int, [_ctx, C.c_int, _pi64, _i64, C.c_double,
         C.c_double, _i64, _ppd]),
@@ -1440,6 +1439,32 @@ class Context:
             'll_theta_pinned_top2')
         if n == 0:
             return np.empty((0, ld)), None
+        mat = np.ctypeslib.as_array(host, shape=(n, ld))
+        if not hint.value:
+            return mat, None
+        raw = (C.c_char * (n * TOP2.itemsize)).from_address(hint.value)
+        return mat, np.frombuffer(raw, dtype=TOP2, count=n)
+
+    def ll_theta_pinned_top2_in_order(self, view, theta, FP, FN, ld,
+                col_prior, order):
+        """The two halves the native step makes of a hinted sweep
+        (bnpc_ll_theta_pinned_sums_issue, then bnpc_hints_in_order_issue once
+        the visiting order is known): (matrix view - rows by slot -, hint
+        records with record r made from row order[r]), hints complete."""
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        K = theta.shape[0]
+        col_prior = np.ascontiguousarray(col_prior, dtype=np.float64)
+        order = as_i64(order)
+        n = self.view_size(view)
+        assert col_prior.size == K and order.size == n
+        host = _host_pd()
+        check(self._lib.bnpc_ll_theta_pinned_sums_issue(self._h, view,
+            ptr(theta, C.c_float), K, float(FP), float(FN), ld,
+            ptr(col_prior), C.byref(host)), 'll_theta_pinned_sums_issue')
+        hint = C.c_void_p()
+        check(self._lib.bnpc_hints_in_order_issue(self._h,
+            ptr(order, C.c_int64), C.byref(hint)), 'hints_in_order_issue')
+        self.hints_wait()
         mat = np.ctypeslib.as_array(host, shape=(n, ld))
         if not hint.value:
             return mat, None

@@ -122,7 +122,6 @@ struct Tunables {
                                     // record)
 #define HINT_THROUGH_MAX 1024       // ... up to which rows that will be scanned
                                     // are written through to the host
-#define HINT_CHUNKS_MAX 16          // row chunks of a pipelined hinted sweep
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
 
@@ -208,21 +207,19 @@ struct bnpc_ctx {
     size_t hint_cap = 0;
     DevBuf hint_prior;              // priors of a hinted sweep with > 64 columns
     void *hint_prior_pin = nullptr; // ... staged here (pinned, HINT_COLS_MAX)
-    // A hinted sweep in ROW CHUNKS (bnpc_ll_theta_perm_top2_issue): the sums
-    // and the hints of chunk c are launched per chunk, the hint kernel of
-    // each writes a completion word; the host walks chunk c while the device
-    // works on c + 1 ...
+    // bnpc_ll_theta_pinned_sums_issue: a hinted sweep whose hint kernel is
+    // launched later (bnpc_hints_in_order_issue), when the caller has drawn
+    // its visiting order under the sums - what that launch needs
     struct {
-        bool active = false;        // the launch in progress is chunked
-        int64_t rows = 0;           // rows per chunk (a multiple of 64)
-        int n = 0;                  // chunks issued by the last such sweep
-        int64_t end[HINT_CHUNKS_MAX] = {};
-        unsigned seq[HINT_CHUNKS_MAX] = {};
-        int64_t K = 0, ldo = 0;
-        Top2Prior prior;            // K <= 64
+        bool pending = false;
+        int64_t n = 0, K = 0, ldo = 0;
+        size_t bytes = 0;
+        Top2Prior prior;            // K <= 64 (more: c->hint_prior)
         void *hint_dev = nullptr;
         double *rows_dev = nullptr;
-    } chunk;
+    } hint_later;
+    void *order_pin = nullptr;      // the visiting order, pinned (N entries)
+    DevBuf order_dev;               // ... and on the device
     // pinned block of a screened parameter batch (bnpc_mh_batch_dev): the
     // draws, the old parameter rows and the screen's verdicts, read / written
     // in place by k_mh_screen
@@ -1506,12 +1503,14 @@ __global__ __launch_bounds__(256) void k_stage_copy(
 __global__ __launch_bounds__(256) void k_row_top2(
     const double *__restrict__ ll, long long n, long long ldo, int K,
     Top2Prior prior, bnpc_top2 *__restrict__ out,
-    double *__restrict__ host_ll, DoneSignal done)
+    double *__restrict__ host_ll, const long long *__restrict__ order)
 {
     const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
-    // (no early return: every thread reaches signal_done)
-    if (slot < n) {
-    const double *__restrict__ r = ll + (size_t)slot * ldo;
+    if (slot >= n) return;
+    // (order: record `slot` is made from row order[slot] - the hints in the
+    // sweep's visiting order)
+    const long long row = order ? order[slot] : slot;
+    const double *__restrict__ r = ll + (size_t)row * ldo;
     double best = -INFINITY, second = -INFINITY, third = -INFINITY;
     double fourth = -INFINITY;
     double lb = 0.0, ls = 0.0, lt = 0.0;
@@ -1566,14 +1565,12 @@ __global__ __launch_bounds__(256) void k_row_top2(
     // to wait for the whole matrix to be copied (row_here = 1).
     int through = 0;
     if (host_ll && fourth > second - 72.0 && second > best - 48.0) {
-        double *__restrict__ h = host_ll + (size_t)slot * ldo;
+        double *__restrict__ h = host_ll + (size_t)row * ldo;
         for (int k = 0; k < K; k++) h[k] = r[k];
         through = 1;
     }
     t.row_here = (int16_t)through;
     out[slot] = t;
-    }
-    signal_done(done);
 }
 
 // The same record for rows of MORE than 64 columns (a running chain with
@@ -1618,13 +1615,14 @@ __device__ __forceinline__ void top4_insert(Top4 &q, double v, double l, int k)
 __global__ __launch_bounds__(256) void k_row_top4_wave(
     const double *__restrict__ ll, long long n, long long ldo, int K,
     const double *__restrict__ prior, bnpc_top2 *__restrict__ out,
-    double *__restrict__ host_ll, int through_max, DoneSignal done)
+    double *__restrict__ host_ll, int through_max,
+    const long long *__restrict__ order)
 {
     const int lane = threadIdx.x & 63;
     const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    // (no early return: every wave reaches signal_done)
-    if (slot < n) {
-    const double *__restrict__ r = ll + (size_t)slot * ldo;
+    if (slot >= n) return;
+    const long long row = order ? order[slot] : slot;
+    const double *__restrict__ r = ll + (size_t)row * ldo;
     const int none = 0x7fffffff;
     Top4 q = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, 0.0, 0.0, 0.0,
               none, none, none};
@@ -1653,7 +1651,7 @@ __global__ __launch_bounds__(256) void k_row_top4_wave(
     }
     int through = 0;
     if (host_ll && K <= through_max && q.f > q.s - 72.0 && q.s > q.b - 48.0) {
-        double *__restrict__ h = host_ll + (size_t)slot * ldo;
+        double *__restrict__ h = host_ll + (size_t)row * ldo;
         for (int k = lane; k < K; k += 64) h[k] = r[k];
         through = 1;
     }
@@ -1672,8 +1670,6 @@ __global__ __launch_bounds__(256) void k_row_top4_wave(
         t.row_here = (int16_t)through;
         out[slot] = t;
     }
-    }
-    signal_done(done);
 }
 
 // ---------------------------------------------------------------------------
@@ -2263,7 +2259,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
                       &c->chunks, &c->cnt, &c->partial, &c->part,
                       &c->lab_cnt, &c->theta_store, &c->row_idx,
                       &c->side_theta, &c->side_tabs, &c->side_out,
-                      &c->side_part, &c->hint_prior};
+                      &c->side_part, &c->hint_prior, &c->order_dev};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (View &v : c->views)
@@ -2275,6 +2271,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->zc_out) (void)hipHostFree(c->zc_out);
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
     if (c->hint_prior_pin) (void)hipHostFree(c->hint_prior_pin);
+    if (c->order_pin) (void)hipHostFree(c->order_pin);
     if (c->mh_pin) (void)hipHostFree(c->mh_pin);
     for (int p = 0; p < 2; p++)
         if (c->mh_ev[p]) (void)hipEventDestroy(c->mh_ev[p]);
@@ -2621,9 +2618,6 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     return 0;
 }
 
-static int chunk_hint_launch(bnpc_ctx *c, int64_t row0, int64_t rows,
-                             const double *d_out);
-
 template <int KW>
 static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                      bool from_theta, double FP, double FN, double *d_out,
@@ -2661,25 +2655,6 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                            c->tab_src + (size_t)K * c->M,
                            (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
     HIPCHK(hipGetLastError());
-    if (c->chunk.active && c->chunk.rows > 0 && from_theta) {
-        // row chunks: the sums of a chunk, then its hints (chunk_hint_launch)
-        const int64_t cb = c->chunk.rows / 64;
-        c->chunk.n = 0;
-        for (int64_t b0 = 0; b0 < v.nblk; b0 += cb) {
-            View sub;
-            sub.masks.p = (ulonglong2 *)v.masks.p + (size_t)b0 * c->Mpad;
-            sub.nblk = std::min<int64_t>(cb, v.nblk - b0);
-            sub.n = std::min<int64_t>(sub.nblk * 64, v.n - b0 * 64);
-            int ms, mc;
-            pick_msplit(c->tun, sub.nblk * G, c->Mt, c->tun.msplit != 0, &ms,
-                        &mc);
-            if (issue_ll<KW>(c, sub, K, ldo, d_out + (size_t)b0 * 64 * ldo, ms,
-                             mc))
-                return 1;
-            if (int rc = chunk_hint_launch(c, b0 * 64, sub.n, d_out)) return rc;
-        }
-        return 0;
-    }
     if (issue_ll<KW>(c, v, K, ldo, d_out, MS, m_chunk)) return 1;
     return 0;
 }
@@ -2742,8 +2717,6 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
         && v.nblk * ((K + 7) / 8) < msplit_limit(c->tun))
         kw = 8;
     if (c->tun.force_kw) kw = c->tun.force_kw;
-    // (row chunks are small launches of their own: the hand-placed kernel)
-    if (c->chunk.active && from_theta && K >= 2) kw = 8;
     // Sums over caller-built tables keep the strict mutation order (they are
     // the bit-exact path); device-built tables may split the mutations.
     int MS, m_chunk;
@@ -2921,70 +2894,66 @@ extern "C" int bnpc_ll_theta_pinned(bnpc_ctx *c, int view, const float *theta,
     return 0;
 }
 
-// the hint kernel over rows [row0, row0 + rows) of the matrix at d_ll (row
-// stride ldo): up to 64 columns one thread per row with the priors as kernel
-// arguments, more one wave per row with the priors in c->hint_prior
-static int hint_launch(bnpc_ctx *c, const double *d_ll, int64_t row0,
-                       int64_t rows, int64_t K, int64_t ldo,
-                       const Top2Prior &pr, void *hint_dev, double *rows_dev,
-                       DoneSignal sig)
+// the hint kernel over the n rows of the matrix at d_ll (row stride ldo): up
+// to 64 columns one thread per row with the priors as kernel arguments, more
+// one wave per row with the priors in c->hint_prior.  order != NULL: record r
+// is made from row order[r] (the hints in visiting order).
+static int hint_launch(bnpc_ctx *c, const double *d_ll, int64_t n, int64_t K,
+                       int64_t ldo, const Top2Prior &pr, void *hint_dev,
+                       double *rows_dev, const long long *order)
 {
-    const double *ll = d_ll + (size_t)row0 * ldo;
-    bnpc_top2 *out = (bnpc_top2 *)hint_dev + row0;
-    double *through = rows_dev ? rows_dev + (size_t)row0 * ldo : nullptr;
     if (K <= 64)
-        hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((rows + 255) / 256)),
-                           dim3(256), 0, c->stream, ll, (long long)rows,
-                           (long long)ldo, (int)K, pr, out, through, sig);
+        hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
+                           dim3(256), 0, c->stream, d_ll, (long long)n,
+                           (long long)ldo, (int)K, pr, (bnpc_top2 *)hint_dev,
+                           rows_dev, order);
     else
-        hipLaunchKernelGGL(k_row_top4_wave, dim3((unsigned)((rows + 3) / 4)),
-                           dim3(256), 0, c->stream, ll, (long long)rows,
+        hipLaunchKernelGGL(k_row_top4_wave, dim3((unsigned)((n + 3) / 4)),
+                           dim3(256), 0, c->stream, d_ll, (long long)n,
                            (long long)ldo, (int)K,
-                           (const double *)c->hint_prior.p, out, through,
-                           (int)HINT_THROUGH_MAX, sig);
+                           (const double *)c->hint_prior.p,
+                           (bnpc_top2 *)hint_dev, rows_dev,
+                           (int)HINT_THROUGH_MAX, order);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-// the hints of one row chunk of a pipelined sweep, with their completion word
-// (slot 1: nothing else signals there while a sweep is being walked)
-static int chunk_hint_launch(bnpc_ctx *c, int64_t row0, int64_t rows,
-                             const double *d_out)
+// what follows the hint kernel: the event the host waits for, the copy of the
+// matrix where the sweep is known to need it
+static int hints_queued(bnpc_ctx *c, int64_t K, size_t bytes, bool wait)
 {
-    ARGCHK(c->chunk.n < HINT_CHUNKS_MAX, "too many row chunks");
-    unsigned seq = 0;
-    const DoneSignal sig = make_signal(c, 1, &seq);
-    if (int rc = hint_launch(c, d_out, row0, rows, c->chunk.K, c->chunk.ldo,
-                             c->chunk.prior, c->chunk.hint_dev,
-                             c->chunk.rows_dev, sig))
-        return rc;
-    c->chunk.end[c->chunk.n] = row0 + rows;
-    c->chunk.seq[c->chunk.n] = seq;     // 0: no completion words
-    c->chunk.n++;
+    // a row of thousands of columns is not written through: the sweep that
+    // meets such a matrix (a first sweep: nothing is decided before its first
+    // births) reads it from its first cell on - the copy is queued at once
+    if (K > HINT_THROUGH_MAX) c->matrix_eager = true;
+    // the caller gets the hints now; the matrix stays on the device and is
+    // copied if and when the sweep first needs a row of it (bnpc_matrix_wait)
+    // - a converged sweep never does
+    if (!c->ev_hints)
+        HIPCHK(hipEventCreateWithFlags(&c->ev_hints, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->ev_hints, c->stream));
+    if (c->matrix_eager) {
+        HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
+                              c->stream));
+        c->pin_copy_queued = true;
+    }
+    if (wait) HIPCHK(hipEventSynchronize(c->ev_hints));
+    c->pin_lazy_bytes = bytes;
     return 0;
 }
 
-// perm != NULL: the rows of the matrix and of the hints are the POSITIONS of
-// the visiting order `perm` (view `view` is set to it first), evaluated in
-// row chunks of chunk_rows (bnpc_ll_theta_perm_top2_issue)
+// later: the sums only; the hint kernel follows with bnpc_hints_in_order_issue
 static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
                         double FP, double FN, int64_t ldo,
                         const double *col_prior, double **host,
-                        bnpc_top2 **top2, bool wait,
-                        const int64_t *perm = nullptr, int64_t chunk_rows = 0)
+                        bnpc_top2 **top2, bool wait, bool later = false)
 {
-    ARGCHK(c && host && top2 && col_prior, "NULL argument");
+    ARGCHK(c && host && col_prior && (top2 || later), "NULL argument");
     ARGCHK(K > 0 && K <= HINT_COLS_MAX, "K out of range for the hint");
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
-    *top2 = nullptr;
-    c->chunk.n = 0;
+    if (top2) *top2 = nullptr;
+    c->hint_later.pending = false;
     if (ldo == 0) ldo = K;
-    ARGCHK(!c->any_tile_pending(),
-           "not available while an issued tile is in flight");
-    if (perm) {
-        ARGCHK(view >= 1, "the visiting order needs a view of its own");
-        if (int rc = bnpc_view_set(c, view, perm, c->N)) return rc;
-    }
     const int64_t n = c->views[view].n;
     // the hints of all slots, written in place into pinned host memory of
     // their own: they must outlive the calls made DURING the sweep (a column
@@ -3008,6 +2977,8 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     ARGCHK(theta, "theta is NULL");
     ARGCHK(ldo >= K, "ldo smaller than K");
     *host = nullptr;
+    ARGCHK(!c->any_tile_pending(),
+           "not available while an issued tile is in flight");
     const size_t bytes = (size_t)n * ldo * sizeof(double);
     if (bytes && ensure_pin(c, bytes)) return 1;
     // did the previous hinted sweep read its matrix?
@@ -3048,62 +3019,35 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
             HIPCHK(hipGetLastError());
         }
     }
-    const bool chunked = perm && hint && bytes && chunk_rows >= 64
-        && chunk_rows < n;
-    if (chunked) {
-        c->chunk.active = true;
-        c->chunk.rows = (chunk_rows + 63) / 64 * 64;
-        if ((n + c->chunk.rows - 1) / c->chunk.rows > HINT_CHUNKS_MAX)
-            c->chunk.rows = ((n + HINT_CHUNKS_MAX - 1) / HINT_CHUNKS_MAX + 63)
-                / 64 * 64;
-        c->chunk.K = K;
-        c->chunk.ldo = ldo;
-        c->chunk.prior = pr;
-        c->chunk.hint_dev = zc_dev;
-        c->chunk.rows_dev = rows_dev;
-    }
     int rc = ll_theta_impl(c, view, theta, K, FP, FN, nullptr, ldo, false);
-    c->chunk.active = false;
-    if (rc) {
-        c->chunk.n = 0;
-        return rc;
-    }
+    if (rc) return rc;
     if (bytes == 0) {
         HIPCHK(hipStreamSynchronize(c->stream));
         return 0;
     }
-    if (hint && c->chunk.n == 0) {
-        if (int rh = hint_launch(c, (const double *)c->out.p, 0, n, K, ldo, pr,
-                                 zc_dev, rows_dev,
-                                 DoneSignal{nullptr, nullptr, 0}))
-            return rh;
+    *host = (double *)c->pin;
+    if (hint && later) {
+        c->hint_later.pending = true;
+        c->hint_later.n = n;
+        c->hint_later.K = K;
+        c->hint_later.ldo = ldo;
+        c->hint_later.bytes = bytes;
+        c->hint_later.prior = pr;
+        c->hint_later.hint_dev = zc_dev;
+        c->hint_later.rows_dev = rows_dev;
+        return 0;
     }
-    // a row of thousands of columns is not written through: the sweep that
-    // meets such a matrix (a first sweep: nothing is decided before its first
-    // births) reads it from its first cell on - the copy is queued at once
-    if (hint && K > HINT_THROUGH_MAX) c->matrix_eager = true;
     if (hint) {
-        // the caller gets the hints now; the matrix stays on the device and
-        // is copied if and when the sweep first needs a row of it
-        // (bnpc_matrix_wait) - a converged sweep never does
-        if (!c->ev_hints)
-            HIPCHK(hipEventCreateWithFlags(&c->ev_hints,
-                                           hipEventDisableTiming));
-        HIPCHK(hipEventRecord(c->ev_hints, c->stream));
-        if (c->matrix_eager) {
-            HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes,
-                                  hipMemcpyDeviceToHost, c->stream));
-            c->pin_copy_queued = true;
-        }
-        if (wait) HIPCHK(hipEventSynchronize(c->ev_hints));
-        c->pin_lazy_bytes = bytes;
+        if (int rh = hint_launch(c, (const double *)c->out.p, n, K, ldo, pr,
+                                 zc_dev, rows_dev, nullptr))
+            return rh;
+        if (int rq = hints_queued(c, K, bytes, wait)) return rq;
     } else {
         HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    *host = (double *)c->pin;
-    *top2 = hint;
+    if (top2) *top2 = hint;
     return 0;
 }
 
@@ -3150,85 +3094,60 @@ extern "C" int bnpc_matrix_wait(bnpc_ctx *c)
     return 0;
 }
 
-// A hinted sweep whose rows are the POSITIONS of the visiting order, in row
-// chunks (include/bnpc_hip.h): view `view` is set to perm, the element tables
-// are built once, then per chunk the sums (+ combine) and the hint kernel,
-// which ends with a completion word - the host walks chunk c while the device
-// works on chunk c + 1.  chunk_rows = 0: four chunks, whole workgroups of the
-// sums kernel (512 rows), none for fewer than 2048 rows.
-extern "C" int bnpc_ll_theta_perm_top2_issue(bnpc_ctx *c, int view,
-                                             const int64_t *perm,
-                                             const float *theta, int64_t K,
-                                             double FP, double FN,
-                                             int64_t ldo,
-                                             const double *col_prior,
-                                             int64_t chunk_rows,
-                                             double **host, bnpc_top2 **top2)
+// bnpc_ll_theta_pinned_top2_issue in two halves, for a sweep that reads its
+// hints IN VISITING ORDER (include/bnpc_hip.h): the sums now ...
+extern "C" int bnpc_ll_theta_pinned_sums_issue(bnpc_ctx *c, int view,
+                                               const float *theta, int64_t K,
+                                               double FP, double FN,
+                                               int64_t ldo,
+                                               const double *col_prior,
+                                               double **host)
 {
-    ARGCHK(c && perm, "NULL argument");
-    if (chunk_rows <= 0) {
-        chunk_rows = ((c->N + 3) / 4 + 511) / 512 * 512;
-        if (c->N < 2048) chunk_rows = c->N;
-    }
-    return ll_top2_impl(c, view, theta, K, FP, FN, ldo, col_prior, host, top2,
-                        false, perm, chunk_rows);
+    return ll_top2_impl(c, view, theta, K, FP, FN, ldo, col_prior, host,
+                        nullptr, false, true);
 }
 
-// Rows [0, *ready_end) of the hints of the last chunked sweep are complete on
-// return, *ready_end > pos: waits for the chunk that holds position `pos`
-// (its completion word, polled for up to ~20 ms; then - or without completion
-// words - the stream).  A sweep that was not chunked: all rows, through
-// bnpc_hints_wait.
-extern "C" int bnpc_rows_wait(bnpc_ctx *c, int64_t pos, int64_t *ready_end)
+// ... the hints when the caller has its visiting order: record r of *top2 is
+// made from row order[r] of the matrix.  The order travels through a pinned
+// buffer of its own and a copy kernel (every wave of the wide hint kernel
+// reads one entry: the host link should see the list once, in whole lines).
+// *top2 = NULL: no hints (no zero-copy memory) - the matrix is complete on
+// the host instead.
+extern "C" int bnpc_hints_in_order_issue(bnpc_ctx *c, const int64_t *order,
+                                         bnpc_top2 **top2)
 {
-    ARGCHK(c && ready_end, "NULL argument");
-    const int64_t n_all = c->chunk.n ? c->chunk.end[c->chunk.n - 1] : 0;
-    if (c->chunk.n == 0 || pos >= n_all) {
-        *ready_end = INT64_MAX;
-        return bnpc_hints_wait(c);
-    }
-    int ci = 0;
-    while (ci < c->chunk.n - 1 && c->chunk.end[ci] <= pos) ci++;
-    const unsigned seq = c->chunk.seq[ci];
-    bool seen = false;
-    if (seq && c->done_pin) {
-        const volatile unsigned *f = c->done_pin + 16 * 1;
-        timespec t0;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        for (unsigned spins = 0;; spins++) {
-            if ((int)(*f - seq) >= 0) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                seen = true;
-                break;
-            }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-            if ((spins & 1023) == 1023) {
-                timespec t1;
-                clock_gettime(CLOCK_MONOTONIC, &t1);
-                if ((t1.tv_sec - t0.tv_sec) * 1000000000L
-                        + (t1.tv_nsec - t0.tv_nsec) > 20000000L)
-                    break;
-            }
-        }
-    }
-    if (!seen) {
-        // everything queued so far: all chunks
-        HIPCHK(hipSetDevice(c->device));
-        if (c->ev_hints && c->pin_lazy_bytes)
-            HIPCHK(hipEventSynchronize(c->ev_hints));
-        else
-            HIPCHK(hipStreamSynchronize(c->stream));
-        *ready_end = INT64_MAX;
-        return 0;
-    }
-    // later chunks that have finished meanwhile count too
-    const unsigned word = *(const volatile unsigned *)(c->done_pin + 16 * 1);
-    while (ci + 1 < c->chunk.n && c->chunk.seq[ci + 1]
-           && (int)(word - c->chunk.seq[ci + 1]) >= 0)
-        ci++;
-    *ready_end = ci == c->chunk.n - 1 ? INT64_MAX : c->chunk.end[ci];
+    ARGCHK(c && order && top2, "NULL argument");
+    *top2 = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    // (sums issued without a hint buffer: the matrix was copied there)
+    if (!c->hint_later.pending) return 0;
+    c->hint_later.pending = false;
+    const int64_t n = c->hint_later.n;
+    for (int64_t i = 0; i < n; i++)
+        ARGCHK(order[i] >= 0 && order[i] < n, "order entry out of range");
+    const size_t ob = (size_t)n * sizeof(long long);
+    const size_t ob2 = (ob + 15) & ~(size_t)15;
+    if (!c->order_pin)
+        HIPCHK(hipHostMalloc(&c->order_pin, ((size_t)c->N + 2) * 8,
+                             hipHostMallocDefault));
+    ARGCHK(n <= c->N, "more rows than cells");
+    if (ensure(c->order_dev, ob2)) return 1;
+    void *op_dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&op_dev, c->order_pin, 0));
+    memcpy(c->order_pin, order, ob);
+    const long long n2 = (long long)(ob2 / 16);
+    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+                       dim3(256), 0, c->stream, (const double2 *)op_dev,
+                       (double2 *)c->order_dev.p, n2);
+    HIPCHK(hipGetLastError());
+    if (int rh = hint_launch(c, (const double *)c->out.p, n, c->hint_later.K,
+                             c->hint_later.ldo, c->hint_later.prior,
+                             c->hint_later.hint_dev, c->hint_later.rows_dev,
+                             (const long long *)c->order_dev.p))
+        return rh;
+    if (int rq = hints_queued(c, c->hint_later.K, c->hint_later.bytes, false))
+        return rq;
+    *top2 = (bnpc_top2 *)c->hint_pin;
     return 0;
 }
 

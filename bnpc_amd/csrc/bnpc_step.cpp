@@ -221,29 +221,6 @@ bool error_prior(const bnpc_host_kernels *k, const bnpc_chain *ch, Work &w,
     return true;
 }
 
-// the view a sweep in visiting order gathers its cells into (the first of the
-// tile views: no tile is in flight during a whole-matrix sweep)
-const int VIEW_ORDER = 3;
-
-// bnpc_gibbs_state.rows_wait of a sweep in row chunks: bnpc_rows_wait, its
-// time counted as the sweep's wait for the device
-struct RowsWait {
-    bnpc_ctx *ctx;
-    bnpc_chain *ch;
-    int64_t ns;
-    static int wait(void *arg, int64_t row, int64_t *end)
-    {
-        RowsWait *r = (RowsWait *)arg;
-        const Clock::time_point t0 = Clock::now();
-        const int rc = bnpc_rows_wait(r->ctx, row, end);
-        const int64_t dt = std::chrono::duration_cast<
-            std::chrono::nanoseconds>(Clock::now() - t0).count();
-        r->ns += dt;
-        r->ch->clock_ns[9] += dt;
-        return rc;
-    }
-};
-
 // ---------------------------------------------------------------- the phases
 // CRP.update_assignments_Gibbs (bnpc_amd/model.py; libs/CRP.py:254-288) for a
 // sweep whose whole matrix is one hinted launch.  *done = false: not this
@@ -307,34 +284,19 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const Clock::time_point tg1 = Clock::now();
     double *ll = nullptr;
     bnpc_top2 *top2 = nullptr;
-    // A sweep whose evaluation is long enough to be worth hiding (from ~4e8
-    // element evaluations on: config 4, config 5, hundreds of clusters) has
-    // its rows in VISITING ORDER and is evaluated in row chunks: the loop
-    // below walks chunk c while the device sums chunk c + 1, and reads its
-    // hints in order instead of all over 3 MB of pinned memory.  The order
-    // is drawn first then - it is the sweep's first draw either way.
-    static const double chunk_min = [] {
-        const char *e = getenv("BNPC_SWEEP_CHUNK_MIN");
-        return e ? atof(e) : 4e8;
-    }();
-    const bool in_order = K >= 2 && N >= 2048
-        && (double)N * (double)K * (double)M >= chunk_min;
-    w.perm.resize((size_t)N);
-    int rc;
-    if (in_order) {
-        mt_fill_permutation(rng, N, w.perm.data());
-        rc = bnpc_ll_theta_perm_top2_issue(ctx, VIEW_ORDER, w.perm.data(),
-                                           w.rows.data(), K, FP, FN, ld,
-                                           w.col_prior.data(), 0, &ll, &top2);
-    } else {
-        rc = bnpc_ll_theta_pinned_top2_issue(ctx, 0, w.rows.data(), K, FP, FN,
-                                             ld, w.col_prior.data(), &ll,
-                                             &top2);
-    }
+    // The sums are queued first; the visiting order - the sweep's first draw,
+    // which consumes no result of the device - is drawn under them, and the
+    // hint kernel, queued behind, makes its records IN that order: the loop
+    // below reads them front to back.
+    int rc = bnpc_ll_theta_pinned_sums_issue(ctx, 0, w.rows.data(), K, FP, FN,
+                                             ld, w.col_prior.data(), &ll);
     if (rc) return rc;
     const Clock::time_point tg2 = Clock::now();
-    // under the launch: the visiting order and the sweep's private state
-    if (!in_order) mt_fill_permutation(rng, N, w.perm.data());
+    w.perm.resize((size_t)N);
+    mt_fill_permutation(rng, N, w.perm.data());
+    rc = bnpc_hints_in_order_issue(ctx, w.perm.data(), &top2);
+    if (rc) return rc;
+    // under the launches: the sweep's private state
     w.assign.assign(ch->assignment, ch->assignment + N);
     w.col_of_id.assign((size_t)N, -1);
     w.col_id.assign((size_t)ld, -1);
@@ -355,8 +317,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     w.scratch.resize((size_t)2 * (ld + 1));
     w.born.resize((size_t)N);
     const Clock::time_point tg3 = Clock::now();
-    RowsWait rows_wait = {ctx, ch, 0};
-    if (!(in_order && top2)) {
+    {
         // how long the sweep waits for its evaluation (tables, sums, combine,
         // hint: four launches) once the visiting order and its state are
         // ready - the part of the device's work that is NOT hidden
@@ -364,8 +325,6 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         rc = bnpc_hints_wait(ctx);
         ch->clock_ns[9] += std::chrono::duration_cast<
             std::chrono::nanoseconds>(Clock::now() - t0).count();
-        ch->clock_calls[9]++;
-    } else {
         ch->clock_calls[9]++;
     }
     if (rc) return rc;
@@ -380,7 +339,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     st.pos = 0;
     st.new_cell = -1;
     st.pos_end = N;
-    st.row_base = in_order ? 0 : -1;
+    st.row_base = -1;
     st.threads = ch->threads;
     if (top2) {
         st.hint = top2;
@@ -388,16 +347,10 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         st.hint_cols = K;
         st.matrix_wait = (int (*)(void *))bnpc_matrix_wait;
         st.matrix_wait_arg = ctx;
-        if (in_order) {
-            // (the waits for the row chunks are the sweep's waits for the
-            // device: clocked in RowsWait::wait)
-            st.hint_rows_narrow = 1;
-            st.rows_wait = RowsWait::wait;
-            st.rows_wait_arg = &rows_wait;
-        }
+        st.hint_in_order = 1;
     }
     st.birth_ctx = ctx;
-    st.birth_view = in_order ? VIEW_ORDER : 0;
+    st.birth_view = 0;
     st.birth_put = 0;
     st.birth_rows = N;
     st.theta_host = ch->parameters;
@@ -456,12 +409,11 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             return std::chrono::duration_cast<std::chrono::nanoseconds>(
                 b - a).count() / 1e3;
         };
-        fprintf(stderr, "[gibbs] N=%lld K=%lld%s: rows "
-                "%.1f, issue %.1f, order + state %.1f, wait %.1f, loop %.1f "
-                "us (of which waiting for row chunks %.1f)\n", (long long)N,
-                (long long)K, in_order ? " in visiting order" : "",
+        fprintf(stderr, "[gibbs] N=%lld K=%lld: rows "
+                "%.1f, issue %.1f, order + hints issue + state %.1f, wait "
+                "%.1f, loop %.1f us\n", (long long)N, (long long)K,
                 us(tg0, tg1), us(tg1, tg2), us(tg2, tg3), us(tg3, tg4),
-                us(tg4, Clock::now()), rows_wait.ns / 1e3);
+                us(tg4, Clock::now()));
     }
     // commit: the live clusters in dict order, the new labels
     for (int64_t a = 0; a < st.n_active; a++) {

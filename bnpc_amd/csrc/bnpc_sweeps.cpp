@@ -637,12 +637,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                              && st->hint_cols <= st->n_cols && FLOOR_STEP > 0)
         ? st->hint : nullptr;
     const int64_t hint_cols = hint ? st->hint_cols : 0;
-    // (narrow records on rows that are positions: a whole-matrix sweep in
-    // visiting order, bnpc_ll_theta_perm_top2_issue)
-    const bool narrow = hint && (!tile_rows || st->hint_rows_narrow);
-    // rows that arrive while the loop runs (row chunks of a pipelined sweep)
-    const bool rows_arrive = tile_rows && st->rows_wait != nullptr;
-    int64_t rows_ready = rows_arrive ? 0 : INT64_MAX;
+    const bool narrow = hint && !tile_rows;
+    // (the records of a whole-matrix sweep in visiting order: hint[p] is the
+    // cell at position p, bnpc_hints_in_order_issue)
+    const bool in_order = narrow && st->hint_in_order;
     const int64_t hint_rows = !hint ? 0
         : (tile_rows ? st->pos_end - st->row_base : N);
     // The hints sit in pinned memory the device has just written: every line
@@ -658,10 +656,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     // (up to 1 MiB of hints, 16 384 cells: at config 5's 3.2 MB the pass
     // itself runs at 2 GB/s and costs more than the misses it saves - Gibbs
     // step 3.6-4.5 against 2.05 ms - while 640 KB at config 4 still gain)
-    // (rows that arrive in order are read in order: no copy - it would have
-    // to wait for all of them)
-    if (hint && !rows_arrive
-        && (size_t)hint_rows * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
+    // (records in visiting order - 3.2 MB of them at config 5 - are read
+    // front to back by the loop itself; a small set is copied all the same:
+    // the copy streams at 30 GB/s, the loop's reads wait for every line)
+    if (hint && (size_t)hint_rows * sizeof(bnpc_top2) <= ((size_t)1 << 20)) {
         // (a sweep resumed after a birth in the caller finds its copy; the
         // pinned buffers of tiles are re-used, so a tile copies at its start)
         const int64_t start = tile_rows ? st->row_base : 0;
@@ -726,13 +724,6 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 
     int64_t free_hint = 0;      // no id below it is free (native births)
     while (st->pos < st->pos_end) {
-        if (st->pos - st->row_base >= rows_ready) {
-            if (st->rows_wait(st->rows_wait_arg, st->pos - st->row_base,
-                              &rows_ready)) {
-                bnpc_set_error("waiting for a row chunk of the sweep failed");
-                return 5;
-            }
-        }
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
         // per-cell scalars) of a cell a few positions ahead into the cache
@@ -745,7 +736,8 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 if (hint) {
                     // the row itself is only read if the hint is in doubt
                     __builtin_prefetch(&hint[tile_rows
-                        ? st->pos + ahead_by - st->row_base : ahead], 0, 1);
+                        ? st->pos + ahead_by - st->row_base
+                        : (in_order ? st->pos + ahead_by : ahead)], 0, 1);
                 } else {
                     const size_t bytes = (size_t)st->n_cols * sizeof(double);
                     const char *end = r + (bytes < 512 ? bytes : 512);
@@ -806,7 +798,8 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         double best = -INFINITY;
         double second = -INFINITY;          // largest entry that is not `top`
         bool hinted = false;
-        const int64_t hrow = tile_rows ? st->pos - st->row_base : cell;
+        const int64_t hrow = tile_rows ? st->pos - st->row_base
+            : (in_order ? st->pos : cell);
         if (hint) {
             const bnpc_top2 &h = hint[hrow];
             // (a wide record carries its column as 32 bits in col | col2)

@@ -184,24 +184,25 @@ int bnpc_ll_theta_pinned_top2_issue(bnpc_ctx *ctx, int view,
                                     bnpc_top2 **top2);
 /* the hints of the last ..._issue call are complete on return */
 int bnpc_hints_wait(bnpc_ctx *ctx);
-/* The same evaluation with the rows in VISITING ORDER, in row chunks, so that
- * the sequential loop (libs/CRP.py:260-288 needs row c only when it reaches
- * cell perm[c]) runs under the kernels: view `view` (>= 1) is set to the N
- * cells of perm; row r of *host and of *top2 belongs to cell perm[r]; the
- * element tables are built once, then per chunk of chunk_rows rows (0: four
- * chunks) the sums and the hints are launched and the hint kernel ends with
- * a completion word.  bnpc_rows_wait(ctx, r, &end) returns once rows [0, end)
- * of the hints are complete, end > r (INT64_MAX: all of them).  The loop
- * takes them through bnpc_gibbs_state.rows_wait with row_base = 0 and
- * hint_rows_narrow = 1.  Pays from ~1e9 element evaluations on (a running
- * chain on 50 000 x 5 000: the loop runs under the sums instead of after
- * them, and reads its hints in order). */
-int bnpc_ll_theta_perm_top2_issue(bnpc_ctx *ctx, int view,
-                                  const int64_t *perm, const float *theta,
-                                  int64_t K, double FP, double FN, int64_t ldo,
-                                  const double *col_prior, int64_t chunk_rows,
-                                  double **host, bnpc_top2 **top2);
-int bnpc_rows_wait(bnpc_ctx *ctx, int64_t row, int64_t *ready_end);
+/* bnpc_ll_theta_pinned_top2_issue in two halves, for a sweep that reads its
+ * hints IN VISITING ORDER: ..._sums_issue queues the element tables and the
+ * sums and returns; the caller draws its visiting order under that launch
+ * (np.random.permutation is the sweep's first draw, libs/CRP.py:259, and
+ * consumes no result of the device); bnpc_hints_in_order_issue(ctx, order,
+ * &top2) then queues the hint kernel with record r of *top2 made from row
+ * order[r] of the matrix - the loop (libs/CRP.py:260-288) walks the records
+ * front to back instead of all over 3 MB of device-written memory (config 5:
+ * 14 -> 11 ns per cell) and the order's 0.2 ms are hidden.  The matrix
+ * itself stays indexed by cell.  bnpc_hints_wait as usual; the loop takes the
+ * records with bnpc_gibbs_state.hint_in_order = 1.  (A sweep in visiting
+ * order AND in row chunks, the loop running under the sums, was measured in
+ * round 5 and is slower: profiles/r05/chunked_sweep_experiment.) */
+int bnpc_ll_theta_pinned_sums_issue(bnpc_ctx *ctx, int view,
+                                    const float *theta, int64_t K, double FP,
+                                    double FN, int64_t ldo,
+                                    const double *col_prior, double **host);
+int bnpc_hints_in_order_issue(bnpc_ctx *ctx, const int64_t *order,
+                              bnpc_top2 **top2);
 /* When *top2 is returned non-NULL the matrix behind *host has NOT been copied
  * yet: it stays on the device until bnpc_matrix_wait fetches it (the sweep
  * reads it only where a hint is in doubt - a settled sweep never does; when
@@ -676,18 +677,10 @@ typedef struct bnpc_gibbs_state {
     int64_t born_cap, n_born;
     int64_t triple_used;    /* out: of hint_used, cells decided among the row's
                              * three best columns */
-    /* row_base >= 0 with hint_rows_narrow != 0: the hint records are the
-     * NARROW ones (bnpc_ll_theta_perm_top2_issue: a whole-matrix sweep whose
-     * rows are the positions of the visiting order) although the rows are
-     * positions - the pair / triple tests apply */
-    int64_t hint_rows_narrow;
-    /* if not NULL: rows (positions - row_base) of hint / ll become available
-     * in order while the loop runs; called with (rows_wait_arg, row, &end)
-     * before the first use of a row >= the end reported last (0 at the
-     * start): returns once rows [0, end) are complete, end > row
-     * (bnpc_rows_wait with its context) */
-    int (*rows_wait)(void *, int64_t, int64_t *);
-    void *rows_wait_arg;
+    /* row_base < 0 and != 0: hint[p] belongs to the cell at POSITION p of
+     * perm (bnpc_hints_in_order_issue), not to cell p; the rows of ll stay
+     * indexed by cell */
+    int64_t hint_in_order;
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,

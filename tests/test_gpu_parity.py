@@ -1025,6 +1025,23 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
                 ('ll_third', 'col3')):
             there = want[col] >= 0
             assert np.array_equal(hint[lik][there], want[lik][there]), (K, lik)
+        # the two halves of the native step's sweep: the sums, then - the
+        # visiting order drawn meanwhile - the records IN that order (record
+        # r from row order[r]); the matrix stays indexed by cell, rows that
+        # will be scanned are written through at their own place
+        order = rng.permutation(N)
+        ll2, hint2 = ctx.ll_theta_pinned_top2_in_order(0, theta, .01, .2,
+            K + 3, prior, order)
+        hint2 = hint2.copy()
+        for name in hint.dtype.names:
+            assert np.array_equal(hint2[name], hint[name][order],
+                equal_nan=True), (K, name)
+        here2 = np.zeros(N, dtype=bool)
+        here2[order] = hint2['row_here'] == 1
+        assert np.array_equal(here2, here)
+        assert np.array_equal(ll2[here2, :K], ll[here2, :K])
+        ctx.matrix_wait()
+        assert np.array_equal(ll2[:, :K], ll[:, :K])
     ctx.close()
 
 

@@ -45,7 +45,7 @@ def reference_gibbs(ll, post_new, crp_prior, assignment, sizes, new_columns):
 
 
 def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns,
-            hint=None, used=None):
+            hint=None, used=None, in_order=False):
     lib = _lib.load()
     N, K = ll0.shape
     ld = K + 2                                  # forces the growth path
@@ -65,7 +65,11 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns,
     scratch = np.empty(2 * (ld + 1))
     st = _lib.GibbsState(N, ld, K, K, 0, -1, N, -1)
     if hint is not None:        # (hints, priors at launch) for columns 0..K-1
-        st.hint = hint[0].ctypes.data
+        records = hint[0]
+        if in_order:            # record p = the cell at position p of perm
+            records = np.ascontiguousarray(records[perm])
+            st.hint_in_order = 1
+        st.hint = records.ctypes.data
         st.hint_prior = hint[1].ctypes.data
         st.hint_cols = K
     rng, extra = _lib.rng_export()
@@ -684,15 +688,19 @@ def test_sweep_hints_fuzz():
             crp_prior[np.fromiter(sizes.values(), dtype=np.int64)])
         hint = _lib.hints_from_matrix(ll, col_prior)
         outs, used = [], []
-        for h in (None, (hint, col_prior)):
+        # (no hints / records by cell / records in visiting order)
+        for h, in_order in ((None, False), ((hint, col_prior), False),
+                ((hint, col_prior), True)):
             np.random.seed(seed)
             got = native_gibbs(ll, post_new, crp_prior, assignment, sizes,
-                new_columns, hint=h, used=used)
+                new_columns, hint=h, used=used, in_order=in_order)
             outs.append((got[0], list(got[1].items()), got[2],
                 np.random.random(2)))
-        assert np.array_equal(outs[0][0], outs[1][0]), seed
-        assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], seed
-        assert np.array_equal(outs[0][3], outs[1][3]), seed
+        for other in outs[1:]:
+            assert np.array_equal(outs[0][0], other[0]), seed
+            assert outs[0][1] == other[1] and outs[0][2] == other[2], seed
+            assert np.array_equal(outs[0][3], other[3]), seed
+        assert used[1] == used[2], seed
         decided += used[1]
         pairs += native_gibbs.last[1]
         triples += native_gibbs.last[2]
@@ -771,15 +779,18 @@ def test_sweep_hints_with_hundreds_of_columns(K):
             crp_prior[np.fromiter(sizes.values(), dtype=np.int64)])
         hint = _lib.hints_from_matrix(ll, col_prior)
         outs, used = [], []
-        for h in (None, (hint, col_prior)):
+        for h, in_order in ((None, False), ((hint, col_prior), False),
+                ((hint, col_prior), True)):
             np.random.seed(seed)
             got = native_gibbs(ll, post_new, crp_prior, assignment, sizes,
-                new_columns, hint=h, used=used)
+                new_columns, hint=h, used=used, in_order=in_order)
             outs.append((got[0], list(got[1].items()), got[2],
                 np.random.random(2)))
-        assert np.array_equal(outs[0][0], outs[1][0]), seed
-        assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], seed
-        assert np.array_equal(outs[0][3], outs[1][3]), seed
+        for other in outs[1:]:
+            assert np.array_equal(outs[0][0], other[0]), seed
+            assert outs[0][1] == other[1] and outs[0][2] == other[2], seed
+            assert np.array_equal(outs[0][3], other[3]), seed
+        assert used[1] == used[2], seed
         if not first_sweep:
             decided += used[1]
             pairs += native_gibbs.last[1]
