@@ -104,6 +104,8 @@ struct Tunables {
                                     // parameter batches
     int done_words = 1;             // BNPC_DONE_WORDS: completion words written
                                     // by the kernels (0: stream synchronisation)
+    int msplit_chunks = 0;          // BNPC_MSPLIT_CHUNKS: force the chunk count of
+                                    // split launches (tools/msplit_sweep.py)
     int screen_theta = 1;           // BNPC_SCREEN_THETA: the screen also hands
                                     // over the float32 bits of the proposals it
                                     // accepts, where they are beyond doubt
@@ -143,6 +145,7 @@ static void read_tunables(Tunables &t)
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
     t.done_words = env_int("BNPC_DONE_WORDS", 1);
     t.screen_theta = env_int("BNPC_SCREEN_THETA", 1);
+    t.msplit_chunks = env_int("BNPC_MSPLIT_CHUNKS", 0);
 }
 
 #define DONE_SLOTS 3     // 0, 1: the launches of a call; 2: the deferred total
@@ -2492,7 +2495,19 @@ static void pick_msplit(const Tunables &tun, int64_t waves, int Mt,
     const int64_t target = waves >= 512 && waves < 2048 ? 16384 : 8192;
     int64_t want = (target + waves - 1) / waves;
     want = (want + 3) / 4 * 4;
+    if (waves >= 1024) {
+        // round 5 (tools/msplit_sweep.py, profiles/r05/msplit_sweep.md): from
+        // a thousand waves on a launch wants ~4000 workgroups of the split
+        // kernel (4 chunks each) as long as a chunk keeps 256 mutations -
+        // 50000 x 5000 x 20: 4 chunks 565 us, 16 chunks 440; x 50: 1001 ->
+        // 983 with 8; 5000 x 1000 x 200: 12 chunks 92 us, 4 chunks 79
+        want = ((32768 + waves - 1) / waves + 3) / 4 * 4;
+        const int64_t by_len = (int64_t)Mt / 256 / 4 * 4;
+        if (want > by_len) want = by_len;
+        if (want < 4) want = 4;
+    }
     const int64_t cap = MSPLIT_MAX;
+    if (tun.msplit_chunks > 0) want = (tun.msplit_chunks + 3) / 4 * 4;
     if (want > cap) want = cap;
     int chunk = (int)((Mt + want - 1) / want);
     chunk = (chunk + 7) / 8 * 8;

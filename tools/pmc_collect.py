@@ -34,8 +34,9 @@ summary = {k: {c: {'launches': len(v), 'mean': sum(v) / len(v), 'max': max(v)}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bnpc_amd import build as _build  # noqa: E402
 summary['_meta'] = {'source_digest': _build.source_digest(),
-    'command': 'rocprofv3 --pmc <counter> -- python3 bench.py --steps 20 '
-        '--warmup 5 --cpu-steps 0 (one pass per counter set)'}
+    'command': os.environ.get('PMC_COMMAND', 'rocprofv3 --pmc <counter> -- '
+        'python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 (one pass per '
+        'counter set)')}
 with open(out, 'w') as fh:
     json.dump(summary, fh, indent=1)
 print(f'{len(files)} file(s), {len(summary)} kernels -> {out}')
