@@ -656,6 +656,10 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // is awake, spinning between the parts, and rank 0 spends the part
         // issuing the next but one - the others should be done when it
         // joins: a rank per 2 blocks)
+        // (round 5, config 3, two runs each: a rank per 4 or per 2 blocks for
+        // the small batches too, with 50 or 300 us of spinning: 1907-2145
+        // steps/s against 1971-2053 - inside the noise of the box, at twice
+        // the busy threads)
         const int64_t per = blocks >= 32 ? 2 : (blocks >= 16 ? 4 : 12);
         if (threads > (blocks + per - 1) / per)
             threads = (int)((blocks + per - 1) / per);

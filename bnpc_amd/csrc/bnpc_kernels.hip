@@ -104,11 +104,10 @@ struct Tunables {
                                     // parameter batches
     int done_words = 1;             // BNPC_DONE_WORDS: completion words written
                                     // by the kernels (0: stream synchronisation)
-    int msplit_chunks = 0;          // BNPC_MSPLIT_CHUNKS: force the chunk count of
-                                    // split launches (tools/msplit_sweep.py)
-    int screen_theta = 1;           // BNPC_SCREEN_THETA: the screen also hands
-                                    // over the float32 bits of the proposals it
-                                    // accepts, where they are beyond doubt
+    int msplit_chunks = 0;          // BNPC_MSPLIT = N >= 2: force the chunk count
+                                    // of split launches (tools/msplit_sweep.py)
+    int screen_theta = 1;           // BNPC_MH_SCREEN = 2: verdicts only - not the
+                                    // float32 bits of the proposals it accepts
 };
 
 #define MSPLIT_MAX 64               // chunks of a split launch at most
@@ -144,8 +143,8 @@ static void read_tunables(Tunables &t)
     t.mask_counts_max = env_int("BNPC_MASK_COUNTS_MAX", 64);
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
     t.done_words = env_int("BNPC_DONE_WORDS", 1);
-    t.screen_theta = env_int("BNPC_SCREEN_THETA", 1);
-    t.msplit_chunks = env_int("BNPC_MSPLIT_CHUNKS", 0);
+    t.screen_theta = t.mh_screen != 2;
+    t.msplit_chunks = t.msplit >= 2 ? t.msplit : 0;
 }
 
 #define DONE_SLOTS 3     // 0, 1: the launches of a call; 2: the deferred total

@@ -499,7 +499,7 @@ int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
  * U / u hold the draws; a->trans_prob must be 0. */
 /* ... 3 where, in addition to 2, the float32 bits of the proposal are
  * beyond doubt: new32[g, m] (optional output, defined where the flag is 3;
- * BNPC_SCREEN_THETA=0: no 3s). */
+ * BNPC_MH_SCREEN=2: no 3s). */
 int bnpc_mh_screen(bnpc_ctx *ctx, int counts_src, const bnpc_mh_args *a,
                    uint8_t *flags, float *new32);
 /* bnpc_mh_batch with that screen in front: the draws are taken (rng != NULL)

@@ -791,15 +791,21 @@ def test_config5_steady_state_at_full_size_matches_oracle_fixture(golden_dir):
 
 
 def test_first_sweep_at_config5_size_does_not_depend_on_the_tiling(
-        monkeypatch):
+        monkeypatch, golden_dir):
     """The first sweep of config 5 at FULL size (50000 x 5000 from K0 ~ 31600
     clusters: a 12.6 GB matrix, never materialised) with the default 256 MiB
     tiles (36 tiles of 1024+ cells, side-lane columns for clusters reborn in
     between), with 64 MiB tiles (115 tiles of ~265 cells) and with 2 GiB
     tiles (6 tiles) - other tile boundaries, other launch shapes: same assignment, same clusters in the
     same order, same parameter rows, same position of the random stream.
-    Oracle identity of the tiled sweep itself is shown at forced-small tiles
-    (test_tiled_sweep_on_device); this is its self-consistency at scale."""
+    Oracle identity of the tiled sweep is shown at forced-small tiles
+    (test_tiled_sweep_on_device) and, at THIS size, on the sweep's first 96
+    cells: the CPU oracle walked them from the same seed
+    (tests/golden/make_c5_first_cells.py: the cluster every one of them drew -
+    two thirds open a cluster of their own, whose profile is drawn from the
+    stream - among 31 644 clusters), and a cell is visited once per sweep, so
+    the labels the device's whole sweep leaves them with must be those -
+    tiles of k_ll8_lds sums, wide hints, births, stream position included."""
     import bench
     import libs.CRP_learning_errors as dev
     N, M, C_, miss, learned = bench.CONFIGS['c5']
@@ -828,6 +834,10 @@ def test_first_sweep_at_config5_size_does_not_depend_on_the_tiling(
         assert a[1] == b[1] and a[3] == b[3]
         assert np.array_equal(a[2], b[2])
     assert len(a[1]) < 200                      # the sweep collapsed K0
+    first = np.load(os.path.join(golden_dir, 'c5_first_cells.npz'))
+    assert int(first['seed']) == 42 and int(first['K0']) == K0
+    assert first['cells'].size >= 64 and first['born'].sum() >= 8
+    assert np.array_equal(a[0][first['cells']], first['drawn'])
 
 
 def test_pinned_result_buffer():
@@ -1493,7 +1503,7 @@ def test_step_whose_recording_is_handed_back(monkeypatch):
 @pytest.mark.parametrize('switch,value', [('BNPC_MH_SCREEN', '0'),
     ('BNPC_NATIVE_BETA', '0'), ('BNPC_STREAM_LIVE', '0'),
     ('BNPC_STREAM_LIVE', 'rng'), ('BNPC_ZERO_COPY', '0'),
-    ('BNPC_DONE_WORDS', '0'), ('BNPC_SCREEN_THETA', '0')])
+    ('BNPC_DONE_WORDS', '0'), ('BNPC_MH_SCREEN', '2')])
 def test_fallback_switches_walk_the_same_chain(switch, value, monkeypatch):
     """The documented fallbacks (README, environment switches) that no other
     test flips: the parameter batches without the device screen, Beta draws

@@ -40,6 +40,15 @@ sys.path.insert(0, tmp)            # `libs` resolves to the scratch tree
 from bnpc_amd import _lib  # noqa: E402
 from fake_device import FakeContext  # noqa: E402
 _lib.Context = FakeContext
+try:
+    _lib.load()
+except (OSError, RuntimeError) as exc:
+    # conda's libstdc++ shadows the one libbnpc_hip.so was linked against
+    shutil.rmtree(tmp)
+    sys.exit(f'cannot load {_lib.LIB_PATH}: {exc}\n'
+        'run this tool as\n    LD_PRELOAD=/usr/lib/x86_64-linux-gnu/'
+        'libstdc++.so.6 /opt/conda/bin/python3.9 '
+        'tools/check_dropin_under_reference.py')
 
 import libs.MCMC as ref_mcmc  # noqa: E402  (the reference's driver)
 import libs.dpmmIO as ref_io  # noqa: E402
