@@ -684,10 +684,31 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             if (order[a] < hint_cols) pos_of_col[order[a]] = a;
     };
     // position of a live column in the live list, or -1: a table for hints of
-    // up to 64 columns, a bisection for more (the list is ascending in column
-    // index; verified by the comparison at the end)
+    // up to 64 columns, re-made at every death; for more columns a bisection
+    // (the list is ascending in column index; verified by the comparison at
+    // the end) - and, while no cluster dies, a table as well: a bisection over
+    // 200 live clusters is eight unpredictable branches per cell (a sweep of a
+    // converged chain with 200 clusters: 37 ns per cell against 10 with 14),
+    // but re-making a table of thousands of entries at every death of a first
+    // sweep would cost more than it saves - so the table is made after a
+    // stretch of look-ups without a death and dropped at the next one.
+    static thread_local std::vector<int32_t> pos_big;
+    bool big_valid = false;
+    int64_t bisected = 0;
     auto pos_of = [&](int64_t c) -> int64_t {
         if (pos_table) return pos_of_col[c];
+        if (narrow) {
+            if (big_valid) return pos_big[(size_t)c];
+            if (++bisected > st->n_active / 16 + 8) {
+                pos_big.assign((size_t)hint_cols, -1);
+                for (int64_t a = 0; a < st->n_active; a++)
+                    if (order[a] < hint_cols)
+                        pos_big[(size_t)order[a]] = (int32_t)a;
+                big_valid = true;
+                bisected = 0;
+                return pos_big[(size_t)c];
+            }
+        }
         int64_t a = 0, b = st->n_active;
         while (a < b) {
             const int64_t mid = (a + b) >> 1;
@@ -784,6 +805,8 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             col_of_id[old_id] = -1;
             if (old_id < free_hint) free_hint = old_id;
             if (hint) index_live();
+            big_valid = false;
+            bisected = 0;
         } else {
             col_size[old_col]--;
             cpr[old_col] = crp_prior[col_size[old_col]];
