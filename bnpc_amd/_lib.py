@@ -1445,31 +1445,51 @@ class Context:
         raw = (C.c_char * (n * TOP2.itemsize)).from_address(hint.value)
         return mat, np.frombuffer(raw, dtype=TOP2, count=n)
 
-    def ll_theta_pinned_top2_in_order(self, view, theta, FP, FN, ld,
-                col_prior, order):
-        """The two halves the native step makes of a hinted sweep
-        (bnpc_ll_theta_pinned_sums_issue, then bnpc_hints_in_order_issue once
-        the visiting order is known): (matrix view - rows by slot -, hint
-        records with record r made from row order[r]), hints complete."""
+    def ll_theta_pinned_sums_issue(self, view, theta, FP, FN, ld, col_prior):
+        """First half of a hinted sweep in visiting order
+        (bnpc_ll_theta_pinned_sums_issue): the element tables and the sums
+        are queued; returns the matrix view (rows by slot; complete after
+        matrix_wait).  The caller draws its visiting order, then calls
+        hints_in_order_issue - nothing else on the context in between."""
         theta = np.ascontiguousarray(theta, dtype=np.float32)
         K = theta.shape[0]
         col_prior = np.ascontiguousarray(col_prior, dtype=np.float64)
-        order = as_i64(order)
         n = self.view_size(view)
-        assert col_prior.size == K and order.size == n
+        assert col_prior.size == K
         host = _host_pd()
         check(self._lib.bnpc_ll_theta_pinned_sums_issue(self._h, view,
             ptr(theta, C.c_float), K, float(FP), float(FN), ld,
             ptr(col_prior), C.byref(host)), 'll_theta_pinned_sums_issue')
+        self._sums_rows = n
+        if n == 0:
+            return np.empty((0, ld))
+        return np.ctypeslib.as_array(host, shape=(n, ld))
+
+    def hints_in_order_issue(self, order):
+        """Second half (bnpc_hints_in_order_issue): the hint kernel is queued
+        with record r made from row order[r]; returns the records (a view of
+        pinned memory, valid after hints_wait) or None (no hint buffer: the
+        matrix is complete on the host instead)."""
+        order = as_i64(order)
+        n = self._sums_rows
+        assert order.size == n
         hint = C.c_void_p()
         check(self._lib.bnpc_hints_in_order_issue(self._h,
             ptr(order, C.c_int64), C.byref(hint)), 'hints_in_order_issue')
-        self.hints_wait()
-        mat = np.ctypeslib.as_array(host, shape=(n, ld))
-        if not hint.value:
-            return mat, None
+        if not hint.value or n == 0:
+            return None
         raw = (C.c_char * (n * TOP2.itemsize)).from_address(hint.value)
-        return mat, np.frombuffer(raw, dtype=TOP2, count=n)
+        return np.frombuffer(raw, dtype=TOP2, count=n)
+
+    def ll_theta_pinned_top2_in_order(self, view, theta, FP, FN, ld,
+                col_prior, order):
+        """Both halves and the wait (tests): (matrix view - rows by slot -,
+        hint records with record r made from row order[r])."""
+        mat = self.ll_theta_pinned_sums_issue(view, theta, FP, FN, ld,
+            col_prior)
+        hint = self.hints_in_order_issue(order)
+        self.hints_wait()
+        return mat, hint
 
     def hints_wait(self):
         """The hints of the last ll_theta_pinned_top2(wait=False) are

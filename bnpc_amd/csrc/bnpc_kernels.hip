@@ -213,7 +213,9 @@ struct bnpc_ctx {
     // launched later (bnpc_hints_in_order_issue), when the caller has drawn
     // its visiting order under the sums - what that launch needs
     struct {
-        bool pending = false;
+        // 0: no sums issued; 1: issued, the hint kernel is to be launched;
+        // 2: issued without a hint buffer (the matrix was copied instead)
+        int state = 0;
         int64_t n = 0, K = 0, ldo = 0;
         size_t bytes = 0;
         Top2Prior prior;            // K <= 64 (more: c->hint_prior)
@@ -2716,6 +2718,7 @@ static int ll_common(bnpc_ctx *c, int view, int64_t K, int64_t ldo,
     if (ldo == 0) ldo = K;
     ARGCHK(ldo >= K, "ldo smaller than K");
     c->pin_lazy_bytes = 0;      // (a matrix left on the device is given up)
+    c->hint_later.state = 0;    // (... and so are hints not yet launched)
     const size_t out_bytes = (size_t)v.n * ldo * sizeof(double);
     // a small result that the caller wants on the host is written by the
     // kernels straight into pinned host memory (no copy-engine launch)
@@ -2966,7 +2969,7 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     ARGCHK(K > 0 && K <= HINT_COLS_MAX, "K out of range for the hint");
     ARGCHK(view >= 0 && view < BNPC_MAX_VIEWS, "view out of range");
     if (top2) *top2 = nullptr;
-    c->hint_later.pending = false;
+    c->hint_later.state = 0;
     if (ldo == 0) ldo = K;
     const int64_t n = c->views[view].n;
     // the hints of all slots, written in place into pinned host memory of
@@ -3001,7 +3004,7 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     // the host's copy of the matrix as the device sees it (rows the sweep is
     // going to scan are written through by the hint kernel)
     double *rows_dev = nullptr;
-    Top2Prior pr;
+    Top2Prior pr = {};
     if (hint && bytes) {
         void *pin_dev = nullptr;
         if (hipHostGetDevicePointer(&pin_dev, c->pin, 0) == hipSuccess)
@@ -3037,11 +3040,12 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
     if (rc) return rc;
     if (bytes == 0) {
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (later) c->hint_later.state = 2;
         return 0;
     }
     *host = (double *)c->pin;
     if (hint && later) {
-        c->hint_later.pending = true;
+        c->hint_later.state = 1;
         c->hint_later.n = n;
         c->hint_later.K = K;
         c->hint_later.ldo = ldo;
@@ -3060,6 +3064,7 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
         HIPCHK(hipMemcpyAsync(c->pin, c->out.p, bytes, hipMemcpyDeviceToHost,
                               c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (later) c->hint_later.state = 2;
     }
     if (top2) *top2 = hint;
     return 0;
@@ -3133,18 +3138,28 @@ extern "C" int bnpc_hints_in_order_issue(bnpc_ctx *c, const int64_t *order,
     ARGCHK(c && order && top2, "NULL argument");
     *top2 = nullptr;
     HIPCHK(hipSetDevice(c->device));
+    const int state = c->hint_later.state;
+    c->hint_later.state = 0;
+    // (another evaluation since - it reuses the matrix's device buffer - or
+    // none at all: the rows the records would be made from are not there)
+    ARGCHK(state != 0, "no sums issued for these hints "
+                       "(bnpc_ll_theta_pinned_sums_issue comes first)");
     // (sums issued without a hint buffer: the matrix was copied there)
-    if (!c->hint_later.pending) return 0;
-    c->hint_later.pending = false;
+    if (state == 2) return 0;
     const int64_t n = c->hint_later.n;
-    for (int64_t i = 0; i < n; i++)
-        ARGCHK(order[i] >= 0 && order[i] < n, "order entry out of range");
+    ARGCHK(n <= c->N, "more rows than cells");
+    {
+        // every entry a row of the matrix (one pass the compiler vectorises)
+        uint64_t out_of_range = 0;
+        for (int64_t i = 0; i < n; i++)
+            out_of_range |= (uint64_t)((uint64_t)order[i] >= (uint64_t)n);
+        ARGCHK(!out_of_range, "order entry out of range");
+    }
     const size_t ob = (size_t)n * sizeof(long long);
     const size_t ob2 = (ob + 15) & ~(size_t)15;
     if (!c->order_pin)
         HIPCHK(hipHostMalloc(&c->order_pin, ((size_t)c->N + 2) * 8,
                              hipHostMallocDefault));
-    ARGCHK(n <= c->N, "more rows than cells");
     if (ensure(c->order_dev, ob2)) return 1;
     void *op_dev = nullptr;
     HIPCHK(hipHostGetDevicePointer(&op_dev, c->order_pin, 0));

@@ -858,18 +858,28 @@ class CRP:
             hint = None
             if ids.size + spare <= _lib.HINT_COLS_MAX \
                     and _lib.env('BNPC_SWEEP_HINT', '1') != '0':
-                # queued, not waited for: the permutation is drawn and the
-                # sweep's private state copied under the launch (no draw of
-                # the stream sits between them in the reference either: the
-                # launch consumes none)
+                # the sums are queued, not waited for: the permutation - the
+                # sweep's first draw, which needs nothing from the device - is
+                # drawn under them, then the hint kernel is queued with that
+                # order (record r = the cell visited r-th: the loop reads its
+                # records front to back) and the sweep's private state is
+                # copied under it
                 col_prior = np.ascontiguousarray(crp_prior[sizes])
-                ll, top2 = ctx.ll_theta_pinned_top2(VIEW_ALL,
-                    self.parameters[ids], self.FP, self.FN, ids.size + spare,
-                    col_prior, wait=False)
-                perm, assignment = self._sweep_order(N)
+                in_order = hasattr(ctx, 'hints_in_order_issue')
+                if in_order:
+                    ll = ctx.ll_theta_pinned_sums_issue(VIEW_ALL,
+                        self.parameters[ids], self.FP, self.FN,
+                        ids.size + spare, col_prior)
+                    perm, assignment = self._sweep_order(N)
+                    top2 = ctx.hints_in_order_issue(perm)
+                else:
+                    ll, top2 = ctx.ll_theta_pinned_top2(VIEW_ALL,
+                        self.parameters[ids], self.FP, self.FN,
+                        ids.size + spare, col_prior, wait=False)
+                    perm, assignment = self._sweep_order(N)
                 ctx.hints_wait()
                 if top2 is not None:
-                    hint = (top2, col_prior)
+                    hint = (top2, col_prior, in_order)
             else:
                 perm, assignment = self._sweep_order(N)
                 ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids],
@@ -1078,6 +1088,8 @@ class CRP:
             st.hint = _lib.ptr(hint[0])
             st.hint_prior = _lib.ptr(hint[1])
             st.hint_cols = cols.size
+            # (the records of a whole-matrix sweep may be in visiting order)
+            st.hint_in_order = int(whole and len(hint) > 2 and bool(hint[2]))
             hook = getattr(ctx, 'matrix_wait_hook', None) if whole else None
             if hook is not None:
                 # the matrix is copied behind the loop, which waits for it

@@ -78,6 +78,22 @@ class FakeContext:
         hint = hints_from_matrix(mat[:, :K], col_prior)
         return mat, hint
 
+    def ll_theta_pinned_sums_issue(self, view, theta, FP, FN, ld, col_prior):
+        mat = self.ll_theta_pinned(view, theta, FP, FN, ld)
+        self._sums = (mat, np.asarray(theta).shape[0],
+            np.array(col_prior, dtype=np.float64))
+        return mat
+
+    def hints_in_order_issue(self, order):
+        from bnpc_amd._lib import hints_from_matrix, HINT_COLS_MAX
+        mat, K, col_prior = self._sums
+        self._sums = None
+        if K > HINT_COLS_MAX:
+            return None
+        order = np.asarray(order, dtype=np.int64)
+        return np.ascontiguousarray(
+            hints_from_matrix(mat[:, :K], col_prior)[order])
+
     def matrix_wait(self):
         pass
 

@@ -1052,6 +1052,32 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
         assert np.array_equal(ll2[here2, :K], ll[here2, :K])
         ctx.matrix_wait()
         assert np.array_equal(ll2[:, :K], ll[:, :K])
+    # the second half without the first, or with another evaluation in
+    # between (it reuses the matrix's device buffer), is refused
+    import ctypes as C
+    lib = _lib.load()
+    order = _lib.as_i64(rng.permutation(N))
+    hint_p, host_p = C.c_void_p(), C.POINTER(C.c_double)()
+    assert lib.bnpc_hints_in_order_issue(ctx._h, _lib.ptr(order, C.c_int64),
+        C.byref(hint_p)) == 2
+    assert 'no sums issued' in lib.bnpc_last_error().decode()
+    theta = np.ascontiguousarray(theta[:5])
+    prior = np.zeros(5)
+    assert lib.bnpc_ll_theta_pinned_sums_issue(ctx._h, 0,
+        _lib.ptr(theta, C.c_float), 5, .01, .2, 8, _lib.ptr(prior),
+        C.byref(host_p)) == 0
+    ctx.ll_theta(0, theta[:1], .02, .3)
+    assert lib.bnpc_hints_in_order_issue(ctx._h, _lib.ptr(order, C.c_int64),
+        C.byref(hint_p)) == 2
+    bad = order.copy()
+    bad[7] = N
+    assert lib.bnpc_ll_theta_pinned_sums_issue(ctx._h, 0,
+        _lib.ptr(theta, C.c_float), 5, .01, .2, 8, _lib.ptr(prior),
+        C.byref(host_p)) == 0
+    assert lib.bnpc_hints_in_order_issue(ctx._h, _lib.ptr(bad, C.c_int64),
+        C.byref(hint_p)) == 2
+    assert 'out of range' in lib.bnpc_last_error().decode()
+    ctx.sync()
     ctx.close()
 
 
