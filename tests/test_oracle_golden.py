@@ -307,3 +307,26 @@ def test_trajectory_learned_errors_prefix(G, golden_dir):
     close(res['ML'][:n], g['ex_learn_ML'][:n], rtol=1e-8)
     close(res['FN'][:n], g['ex_learn_FN'][:n], rtol=1e-8)
     close(res['FP'][:n], g['ex_learn_FP'][:n], rtol=1e-8)
+
+
+def test_config5_first_cells_fixture_is_what_its_maker_describes(golden_dir):
+    """c5_first_cells.npz (tests/golden/make_c5_first_cells.py: the oracle's
+    first cells of config 5's first sweep at full size; re-making it takes
+    ten CPU-minutes, so here only its shape): distinct cells, the cluster each
+    drew, a new cluster = the lowest free id at that moment, the cluster
+    count moving by at most one per cell."""
+    g = np.load(os.path.join(golden_dir, 'c5_first_cells.npz'))
+    cells, drawn, K_after, born = (g[k] for k in ('cells', 'drawn', 'K_after',
+        'born'))
+    n = cells.size
+    assert n >= 64 and drawn.size == K_after.size == born.size == n
+    assert np.unique(cells).size == n and cells.min() >= 0 \
+        and cells.max() < 50000
+    assert int(g['seed']) == 42 and 31000 < int(g['K0']) < 32000
+    assert 8 <= born.sum() <= n
+    steps = np.diff(np.concatenate([[int(g['K0'])], K_after]))
+    assert np.all(np.abs(steps) <= 1)
+    # a cell that opens a cluster never lowers the count; one that joins an
+    # existing cluster never raises it
+    assert np.all(steps[born] >= 0) and np.all(steps[~born] <= 0)
+    assert 0.0 <= float(g['peek']) < 1.0
