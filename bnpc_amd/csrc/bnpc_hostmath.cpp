@@ -62,8 +62,11 @@ class Team {
 public:
     Team() : pid_(getpid())
     {
+        // (300 us: the ranks a converged step uses stay awake from one of its
+        // batches to the next; a chain that shares its NUMA node with others
+        // is given 5 by its driver - bnpc_amd.mcmc, bench.py)
         const char *e = getenv("BNPC_HOST_SPIN_US");
-        spin_ns_ = (e ? atol(e) : 50) * 1000L;
+        spin_ns_ = (e ? atol(e) : 300) * 1000L;
     }
     int size() const { return ranks_.load(std::memory_order_acquire); }
     pid_t pid() const { return pid_; }
@@ -656,11 +659,21 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // is awake, spinning between the parts, and rank 0 spends the part
         // issuing the next but one - the others should be done when it
         // joins: a rank per 2 blocks)
-        // (round 5, config 3, two runs each: a rank per 4 or per 2 blocks for
-        // the small batches too, with 50 or 300 us of spinning: 1907-2145
-        // steps/s against 1971-2053 - inside the noise of the box, at twice
-        // the busy threads)
-        const int64_t per = blocks >= 32 ? 2 : (blocks >= 16 ? 4 : 12);
+        // The small batches (config 3's parameter update: a dozen blocks; the
+        // scans of a move: half a dozen) take a rank per 2 blocks as well
+        // when this chain has the host's cores to itself - with the team
+        // spinning 300 us between jobs, i.e. across a whole converged step
+        // (Team::Team) - and a rank per 12 when chains share a NUMA node
+        // (BNPC_HOST_SHARE > 1: every woken rank is taken from a neighbour).
+        // Round 5, config 3, five interleaved runs on one box: 2054-2147
+        // steps/s (median 2140) with a rank per 12 blocks and 50 us of
+        // spinning, 2107-2275 (median 2234) with a rank per 2 and 300 us, at
+        // 3.4 busy threads instead of 1.4; a rank per 3 and 150 us: 2128.
+        static const int64_t per_small = [] {
+            const char *e = getenv("BNPC_HOST_SHARE");
+            return (e && atol(e) > 1) ? (int64_t)12 : (int64_t)2;
+        }();
+        const int64_t per = blocks >= 32 ? 2 : (blocks >= 16 ? 4 : per_small);
         if (threads > (blocks + per - 1) / per)
             threads = (int)((blocks + per - 1) / per);
         if (threads > n_tasks) threads = (int)n_tasks;
