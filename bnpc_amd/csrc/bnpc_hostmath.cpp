@@ -150,10 +150,16 @@ private:
         bool worked = false;    // a rank the last job did not want parks at
                                 // once: only the ranks in use spin for the
                                 // next job (a wake-up reaches every sleeper)
+        int last_slot = 0;      // ... and only the first few of them for long:
+                                // the small batches of a converged step use
+                                // ranks 1-7 again within the spin; the two
+                                // dozen more of a wide batch would burn a
+                                // core each until the next one
         for (;;) {
             uint32_t w;
             const long t0 = now_ns();
-            const long spin = worked ? spin_ns_ : 0;
+            const long spin = !worked ? 0
+                : (last_slot < 8 || spin_ns_ < 50000 ? spin_ns_ : 50000);
             int polls = 0;
             while ((w = word_.load(std::memory_order_acquire)) == seen) {
                 cpu_relax();
@@ -179,6 +185,7 @@ private:
                 }
             }
             worked = slot > 0;
+            if (worked) last_slot = slot;
             if (worked) {
                 // (published before the word: the acquire load above pairs
                 // with the seq_cst store in run())
@@ -669,6 +676,9 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // steps/s (median 2140) with a rank per 12 blocks and 50 us of
         // spinning, 2107-2275 (median 2234) with a rank per 2 and 300 us, at
         // 3.4 busy threads instead of 1.4; a rank per 3 and 150 us: 2128.
+        // Three interleaved runs each on a loaded box (load average 34), new
+        // against old: config 3 2145 / 2098, config 4 1518 / 1457, config 5
+        // 314 / 299 (means).
         static const int64_t per_small = [] {
             const char *e = getenv("BNPC_HOST_SHARE");
             return (e && atol(e) > 1) ? (int64_t)12 : (int64_t)2;
