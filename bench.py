@@ -399,6 +399,10 @@ def main():
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--cpu-steps', type=int, default=12,
         help='oracle steps timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=60.,
+        help='... but no further step once this much CPU time is spent (at '
+            'least one step is made: a warm-up of 0 puts the first sweep, '
+            'minutes on the CPU, into the leg)')
     ap.add_argument('--kernel-reps', type=int, default=5)
     args = ap.parse_args()
 
@@ -507,15 +511,19 @@ def main():
         np.random.set_state(snap['rng'])
         ochain = new_chain(om, learned, args.cpu_steps, args.config)
         t0 = time.perf_counter()
+        cpu_done = 0
         for i in range(1, args.cpu_steps + 1):
             step(ochain, i, 0)
+            cpu_done = i
+            if time.perf_counter() - t0 > args.cpu_seconds:
+                break
         cpu_s = time.perf_counter() - t0
         # the parity gate of this line: the oracle
         # walked its steps from the GPU chain's post-warm-up snapshot on the
         # same stream, so they ARE the GPU chain's first timed steps -
         # identical assignments, log-likelihoods to 1e-9 - or the line is
         # not printed
-        n_chk = min(args.cpu_steps, args.steps)
+        n_chk = min(cpu_done, args.steps)
         gpu_res, cpu_res = chain.results, ochain.results
         same = all(np.array_equal(
             gpu_res['assignments'][args.warmup + i],
@@ -544,9 +552,9 @@ def main():
         kt = time.perf_counter() - t0
         import scipy
         cpu = {
-            'value': round(args.cpu_steps / cpu_s, 4), 'unit': 'steps/s',
+            'value': round(cpu_done / cpu_s, 4), 'unit': 'steps/s',
             'cores': 1, 'kind': 'port',
-            'sample': f'{args.cpu_steps} MCMC steps (do_step+update_results) '
+            'sample': f'{cpu_done} MCMC steps (do_step+update_results) '
                 f'of the NumPy oracle from the GPU chain\'s post-warm-up '
                 f'state (K={K_warm}), {cpu_s:.1f} s',
             'll_evals_per_s_K0': ncell * K0 / kt,

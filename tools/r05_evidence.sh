@@ -51,7 +51,7 @@ python3 bench.py --config c2 --steps 200 > $out/bench_config2.json 2> /dev/null
 python3 bench.py --config c3k --steps 100 --cpu-steps 3 > $out/bench_c3k.json 2> /dev/null
 python3 bench.py --config k150 --steps 200 --cpu-steps 6 > $out/bench_k150.json 2> /dev/null
 python3 bench.py --config c4 --steps 100 --cpu-steps 4 > $out/bench_config4.json 2> /dev/null
-python3 bench.py --config c5 --steps 60 --warmup 10 --cpu-steps 2 > $out/bench_config5.json 2> $out/bench_config5.err
+python3 bench.py --config c5 --steps 60 --warmup 10 --cpu-steps 2 --cpu-seconds 400 > $out/bench_config5.json 2> $out/bench_config5.err
 
 # 4. host side: phase traces, screen timelines, moves, microbench, first sweep
 python3 tools/python_overhead.py c3 300 > $out/python_overhead.log 2>&1

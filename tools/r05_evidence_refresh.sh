@@ -27,7 +27,7 @@ cp $out/pmc_c5.json profiles/r05/pmc_c5.json
 for i in 1 2 3; do python3 bench.py --cpu-steps $([ $i = 1 ] && echo 12 || echo 0) > $out/bench_final_$i.json 2> $out/bench_final_$i.err; done
 cp $out/bench_final_1.json $out/bench_final.json
 BNPC_NATIVE_STEP=0 python3 bench.py --cpu-steps 0 > $out/bench_step_by_methods.json 2>/dev/null
-python3 bench.py --config c5 --steps 60 --warmup 10 --cpu-steps 2 > $out/bench_config5.json 2> $out/bench_config5.err
+python3 bench.py --config c5 --steps 60 --warmup 10 --cpu-steps 2 --cpu-seconds 400 > $out/bench_config5.json 2> $out/bench_config5.err
 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $out/prof_bench -o bench -f csv -- \
     python3 bench.py --cpu-steps 0 > $out/bench_under_rocprof.json 2> $out/rocprof_bench.err
 uptime >> $out/box_load.log
