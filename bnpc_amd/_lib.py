@@ -51,7 +51,8 @@ class MT19937(C.Structure):
 
 # bnpc_top2 (include/bnpc_hip.h) as a NumPy record
 TOP2 = np.dtype([('best', np.float64), ('second', np.float64),
-    ('third', np.float64), ('fourth', np.float64), ('ll_best', np.float64),
+    ('third', np.float32), ('fourth', np.float32), ('e2', np.float32),
+    ('e3', np.float32), ('ll_best', np.float64),
     ('ll_second', np.float64), ('ll_third', np.float64), ('col', np.int16),
     ('col2', np.int16), ('col3', np.int16), ('row_here', np.int16)])
 assert TOP2.itemsize == 64
@@ -162,7 +163,7 @@ STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
 
 # the version bnpc_abi_version() of a matching library reports (bumped with
 # every change of a structure or signature of include/bnpc_hip.h)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
@@ -1070,6 +1071,17 @@ def rg_scan_step(ctx, kernels, view, n, rg_assignment, DP_a, theta3, sd, tmin,
         log_prob)
 
 
+def f32_up(x):
+    """float32 values not below the float64 ones (rounded to nearest, one step
+    up where that fell short): the record's bounds third / fourth."""
+    x = np.asarray(x, dtype=np.float64)
+    with np.errstate(all='ignore'):
+        f = x.astype(np.float32)
+        low = f.astype(np.float64) < x
+        return np.where(low, np.nextafter(f, np.float32(np.inf)), f) \
+            .astype(np.float32)
+
+
 def hints_from_matrix(mat, col_prior):
     """The hint records the device returns for the first K = len(col_prior)
     columns of `mat` (k_row_top2: the four largest entries of ll + prior,
@@ -1088,12 +1100,20 @@ def hints_from_matrix(mat, col_prior):
             ('second', 'll_second', 'col2'), ('third', 'll_third', 'col3'))):
         if rank < K:
             c = order[:, rank]
-            hint[val] = post[rows, c]
+            hint[val] = f32_up(post[rows, c]) if val == 'third' \
+                else post[rows, c]
             hint[lik] = ll[rows, c]
             hint[col] = np.where(np.isfinite(hint[val]) | (rank == 0), c, -1)
         else:
             hint[val], hint[col] = -np.inf, -1
-    hint['fourth'] = post[rows, order[:, 3]] if K > 3 else -np.inf
+    hint['fourth'] = f32_up(post[rows, order[:, 3]]) if K > 3 else -np.inf
+    # the weights of the second / third column relative to the first, priors
+    # left out (float32)
+    with np.errstate(all='ignore'):
+        hint['e2'] = np.where(hint['col2'] >= 0,
+            np.exp(hint['ll_second'] - hint['ll_best']), 0.0)
+        hint['e3'] = np.where(hint['col3'] >= 0,
+            np.exp(hint['ll_third'] - hint['ll_best']), 0.0)
     return hint
 
 

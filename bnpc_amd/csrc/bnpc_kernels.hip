@@ -54,7 +54,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 9; }
+extern "C" int bnpc_abi_version(void) { return 10; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -1504,6 +1504,18 @@ __global__ __launch_bounds__(256) void k_stage_copy(
 // priors travel as kernel arguments (no memory to fetch them from); the matrix
 // was just written and is read from L2.
 // ---------------------------------------------------------------------------
+// (the record's float fields: third / fourth rounded UP - they are upper
+// bounds on "everything else"; e2 / e3 = the likelihood weights of the second
+// / third column relative to the first, see bnpc_top2 in the header)
+__device__ __forceinline__ void top2_floats(bnpc_top2 &t, double third,
+    double fourth, double lb, double ls, double lt, bool has2, bool has3)
+{
+    t.third = __double2float_ru(third);
+    t.fourth = __double2float_ru(fourth);
+    t.e2 = has2 ? (float)exp(ls - lb) : 0.0f;
+    t.e3 = has3 ? (float)exp(lt - lb) : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void k_row_top2(
     const double *__restrict__ ll, long long n, long long ldo, int K,
     Top2Prior prior, bnpc_top2 *__restrict__ out,
@@ -1553,14 +1565,13 @@ __global__ __launch_bounds__(256) void k_row_top2(
     bnpc_top2 t;
     t.best = best;
     t.second = second;
-    t.third = third;
-    t.fourth = fourth;
     t.ll_best = lb;
     t.ll_second = ls;
     t.ll_third = lt;
     t.col = (int16_t)col;
     t.col2 = (int16_t)col2;
     t.col3 = (int16_t)col3;
+    top2_floats(t, third, fourth, lb, ls, lt, col2 >= 0, col3 >= 0);
     // A row without a clear winner and with a fourth entry within reach of
     // the runner-up is one the sweep will have to scan (the host decides
     // cells among up to three candidates from the hint alone; a clear winner
@@ -1568,7 +1579,8 @@ __global__ __launch_bounds__(256) void k_row_top2(
     // copy of the matrix here, with the hints, so that the scan does not have
     // to wait for the whole matrix to be copied (row_here = 1).
     int through = 0;
-    if (host_ll && fourth > second - 72.0 && second > best - 48.0) {
+    // (on the record's own rounded value: the host can tell from the record)
+    if (host_ll && (double)t.fourth > second - 72.0 && second > best - 48.0) {
         double *__restrict__ h = host_ll + (size_t)row * ldo;
         for (int k = 0; k < K; k++) h[k] = r[k];
         through = 1;
@@ -1654,23 +1666,30 @@ __global__ __launch_bounds__(256) void k_row_top4_wave(
         if (o.f > q.f) q.f = o.f;
     }
     int through = 0;
-    if (host_ll && K <= through_max && q.f > q.s - 72.0 && q.s > q.b - 48.0) {
+    const float f_up = __double2float_ru(q.f);
+    if (host_ll && K <= through_max && (double)f_up > q.s - 72.0
+        && q.s > q.b - 48.0) {
         double *__restrict__ h = host_ll + (size_t)row * ldo;
         for (int k = lane; k < K; k += 64) h[k] = r[k];
         through = 1;
     }
+    // (the record's two exponentials side by side on lanes 0 and 1)
+    const float e_mine = (float)exp((lane == 0 ? q.ls : q.lt) - q.lb);
+    const float e_next = __shfl(e_mine, 1);
     if (lane == 0) {
         bnpc_top2 t;
         t.best = q.b;
         t.second = q.s;
-        t.third = q.t;
-        t.fourth = q.f;
         t.ll_best = q.lb;
         t.ll_second = q.ls;
         t.ll_third = q.lt;
         t.col = (int16_t)(q.cb == none ? 0 : q.cb);
         t.col2 = (int16_t)(q.cs == none || !(q.s > -INFINITY) ? -1 : q.cs);
         t.col3 = (int16_t)(q.ct == none || !(q.t > -INFINITY) ? -1 : q.ct);
+        t.third = __double2float_ru(q.t);
+        t.fourth = f_up;
+        t.e2 = t.col2 >= 0 ? e_mine : 0.0f;
+        t.e3 = t.col3 >= 0 ? e_next : 0.0f;
         t.row_here = (int16_t)through;
         out[slot] = t;
     }
@@ -1740,6 +1759,7 @@ __global__ __launch_bounds__(256) void k_row_top2_wide(
         t.second = second;
         t.third = -INFINITY;
         t.fourth = -INFINITY;
+        t.e2 = t.e3 = 0.0f;
         t.ll_best = t.ll_second = t.ll_third = 0.0;
         const unsigned c32 = (unsigned)(col == 0x7fffffff ? 0 : col);
         t.col = (int16_t)(uint16_t)(c32 & 0xffffu);

@@ -364,23 +364,36 @@ int bnpc_sweep_open_cluster(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 // 1e-11 from both ends of one of the two wide intervals picks what the full
 // arithmetic picks; -1 = nearer than that (or inside a floor sliver): the
 // caller evaluates the cell in full.
-static inline int64_t pair_pick_quick(double d2, int64_t A, int64_t top,
-                                      int64_t sec, double u)
+//
+// pair_pick_weights: the same from the two entries' WEIGHTS (any common
+// scale; known to a relative `band` / 4 or better): w = 1 and exp(d2) here;
+// the sweep loop passes size1 and e2 * size2 - the likelihood ratio the hint
+// kernel has already exponentiated (bnpc_top2.e2, a float32: band 1e-6) times
+// the ratio of the CURRENT sizes, which IS the ratio of the priors
+// (log(size) - common term, libs/CRP.py:83-85): no exp() in the loop.
+static inline int64_t pair_pick_weights(double w_a, double w_b, int64_t a,
+                                        int64_t b, int64_t A, double u,
+                                        double band)
 {
-    const double x = d2 > -746.0 ? exp(d2) : 0.0;
-    const double p_top = 1.0 / (1.0 + x), p_sec = x * p_top;
-    const int64_t m1 = top < sec ? top : sec;
-    const int64_t m2 = top < sec ? sec : top;
-    const double e1 = m1 == top ? p_top : p_sec;
-    const double e2 = m1 == top ? p_sec : p_top;
+    const double inv = 1.0 / (w_a + w_b);
+    const int64_t m1 = a < b ? a : b;
+    const int64_t m2 = a < b ? b : a;
+    const double e1 = (a < b ? w_a : w_b) * inv;
+    const double e2 = (a < b ? w_b : w_a) * inv;
     const double un = u * (1.0 + (double)(A - 1) * EXP_LOG_EPS);
     const double lo1 = (double)m1 * EXP_LOG_EPS, hi1 = lo1 + e1;
     const double lo2 = hi1 + (double)(m2 - m1 - 1) * EXP_LOG_EPS;
     const double hi2 = lo2 + e2;
-    const double band = 1e-11;
     if (un > lo1 + band && un < hi1 - band) return m1;
     if (un > lo2 + band && un < hi2 - band) return m2;
     return -1;
+}
+
+static inline int64_t pair_pick_quick(double d2, int64_t A, int64_t top,
+                                      int64_t sec, double u)
+{
+    const double x = d2 > -746.0 ? exp(d2) : 0.0;
+    return pair_pick_weights(1.0, x, top, sec, A, u, 1e-11);
 }
 
 // The same pick by the scan's own arithmetic (_normalize_log_probs,
@@ -446,24 +459,19 @@ static inline int two_way_pick_full(double d, int big, double u, double *l0,
 // x_i / (1 + x_b + x_c) from two exp(); an entry the scan would clip to the
 // floor differs from that by less than 1e-15.  -1 = u is within 1e-11 of an
 // interval end: the caller scans the cell (with the same uniform).
-static inline int64_t triple_pick_quick(const double q[3], const int64_t a[3],
-                                        int64_t A, double u)
+//
+// triple_pick_weights: from the three entries' weights (any common scale,
+// relative error below band / 4), as pair_pick_weights.
+static inline int64_t triple_pick_weights(const double x[3],
+                                          const int64_t a[3], int64_t A,
+                                          double u, double band)
 {
-    int t = 0;
-    for (int i = 1; i < 3; i++)
-        if (q[i] > q[t] || (q[i] == q[t] && a[i] < a[t])) t = i;
-    double x[3], Z = 0.0;
-    for (int i = 0; i < 3; i++) {
-        const double d = q[i] - q[t];
-        x[i] = i == t ? 1.0 : (d > -746.0 ? exp(d) : 0.0);
-        Z += x[i];
-    }
+    const double Z = x[0] + x[1] + x[2];
     int o[3] = {0, 1, 2};                       // by list position
     if (a[o[0]] > a[o[1]]) { const int w = o[0]; o[0] = o[1]; o[1] = w; }
     if (a[o[1]] > a[o[2]]) { const int w = o[1]; o[1] = o[2]; o[2] = w; }
     if (a[o[0]] > a[o[1]]) { const int w = o[0]; o[0] = o[1]; o[1] = w; }
     const double un = u * (1.0 + (double)(A - 2) * EXP_LOG_EPS);
-    const double band = 1e-11;
     double edge = 0.0;
     int64_t prev = -1;
     for (int j = 0; j < 3; j++) {
@@ -475,6 +483,20 @@ static inline int64_t triple_pick_quick(const double q[3], const int64_t a[3],
         prev = a[i];
     }
     return -1;
+}
+
+static inline int64_t triple_pick_quick(const double q[3], const int64_t a[3],
+                                        int64_t A, double u)
+{
+    int t = 0;
+    for (int i = 1; i < 3; i++)
+        if (q[i] > q[t] || (q[i] == q[t] && a[i] < a[t])) t = i;
+    double x[3];
+    for (int i = 0; i < 3; i++) {
+        const double d = q[i] - q[t];
+        x[i] = i == t ? 1.0 : (d > -746.0 ? exp(d) : 0.0);
+    }
+    return triple_pick_weights(x, a, A, u, 1e-11);
 }
 
 // _normalize_log_probs + choice for a scanned cell whose maximum (`top`,
@@ -671,6 +693,21 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             hint_local_of = hint;
         }
         hint = hint_local.data();
+    }
+    // The quick picks among two / three candidates weigh them by e * size
+    // (bnpc_top2.e2 / e3 times the current size of the column's cluster), which
+    // is right when the prior table is log(size) + a common term, as the
+    // reference's is (libs/CRP.py:83-85).  A table of another shape (a caller
+    // of the C-ABI is free to pass one) is told by a few samples and gets the
+    // exponentials of the re-scored entries instead.
+    bool size_weights = narrow && shortcuts;
+    if (size_weights) {
+        const int64_t probe[6] = {2, 3, 5, 64, N / 2, N};
+        for (int i = 0; i < 6 && size_weights; i++) {
+            const int64_t m = probe[i] < 1 ? 1 : (probe[i] > N ? N : probe[i]);
+            const double d = crp_prior[m] - crp_prior[1];
+            size_weights = fabs(d - log((double)m)) < 1e-12 * (1.0 + fabs(d));
+        }
     }
     const double *cpr0 = st->hint_prior;
     double drift = 0.0;
@@ -878,8 +915,9 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // exp() (the 60-below-the-runner-up rule) and the floor probability:
         // the cell is decided from the two entries, bit for bit as the scan
         // decides it, without reading its row.
-        bool pair = false;
+        bool pair = false, pair_w = false;
         int64_t pair_second = 0;
+        double pair_wtop = 0.0, pair_wsec = 0.0;
         if (narrow && !hinted && A <= QUICK_PICK_MAX && shortcuts) {
             const bnpc_top2 &h = hint[hrow];
             const int64_t c1 = h.col, c2 = h.col2;
@@ -907,6 +945,15 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                     best = first ? q1 : q2;
                     second = first ? q2 : q1;
                     pair = true;
+                    // (weights of the entries at a1 / a2 for the quick pick; a
+                    // float that overflowed or a table of another shape: none)
+                    pair_w = size_weights && h.e2 < 1e30f;
+                    if (pair_w) {
+                        pair_wtop = first ? (double)col_size[c1]
+                            : (double)h.e2 * (double)col_size[c2];
+                        pair_wsec = first ? (double)h.e2 * (double)col_size[c2]
+                            : (double)col_size[c1];
+                    }
                     st->hint_used++;
                     st->pair_used++;
                 }
@@ -955,7 +1002,15 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                     && other < mid3 - 61.0) {
                     u_saved = mt_double(rng);
                     have_u = true;
-                    triple_pick = triple_pick_quick(q, a3, A, u_saved);
+                    if (size_weights && h.e2 < 1e30f && h.e3 < 1e30f) {
+                        const double w[3] = {(double)col_size[c[0]],
+                            (double)h.e2 * (double)col_size[c[1]],
+                            (double)h.e3 * (double)col_size[c[2]]};
+                        triple_pick = triple_pick_weights(w, a3, A, u_saved,
+                                                          1e-6);
+                    } else {
+                        triple_pick = triple_pick_quick(q, a3, A, u_saved);
+                    }
                     if (triple_pick >= 0) {
                         triple = true;
                         st->hint_used++;
@@ -1093,8 +1148,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             const double u = have_u ? u_saved : mt_double(rng);
             bool decided = false;
             if (pair && shortcuts) {
-                const int64_t quick = pair_pick_quick(second - ptop, A, top,
-                                                      pair_second, u);
+                const int64_t quick = pair_w
+                    ? pair_pick_weights(pair_wtop, pair_wsec, top, pair_second,
+                                        A, u, 1e-6)
+                    : pair_pick_quick(second - ptop, A, top, pair_second, u);
                 if (quick >= 0) {
                     lo = quick;
                     decided = true;

@@ -153,8 +153,18 @@ int bnpc_ll_theta_pinned(bnpc_ctx *ctx, int view, const float *theta,
  * into pinned host memory, valid until the next call on the context. */
 typedef struct bnpc_top2 {
     double best, second;    /* largest / second largest entry of the row */
-    double third;           /* third largest (-inf with fewer than 3 columns) */
-    double fourth;          /* fourth largest (-inf with fewer than 4) */
+    /* third / fourth largest (-inf with fewer columns) as float32 ROUNDED UP:
+     * they only bound "everything else" from above (61 below the candidates) */
+    float third, fourth;
+    /* exp(ll_second - ll_best), exp(ll_third - ll_best) as float32: the
+     * weights of the row's second / third column relative to its first
+     * WITHOUT the priors.  The prior of a live cluster is log(size) minus a
+     * term common to all (libs/CRP.py:83-85), so under the CURRENT sizes the
+     * candidates' probabilities are proportional to size1 : e2 size2 : e3
+     * size3 - no exp() in the loop; the float's 6e-8 is covered by the band of
+     * 1e-6 the quick picks keep between the uniform and an interval end
+     * (nearer: the scan's own arithmetic decides) */
+    float e2, e3;
     /* the log-likelihoods (no prior) behind best / second / third: with them
      * the loop re-scores the row's candidates under the CURRENT priors
      * exactly as a scan would (row[c] + prior[c]) - a cell torn between two

@@ -1035,6 +1035,14 @@ def test_sweep_hint_from_the_device_is_the_rows_top_two():
                 ('ll_third', 'col3')):
             there = want[col] >= 0
             assert np.array_equal(hint[lik][there], want[lik][there]), (K, lik)
+        # the weights of the second / third column relative to the first
+        # (float32 of the device's exp(): the loop allows 2.5e-7, a quarter of
+        # its band of 1e-6)
+        for e, col in (('e2', 'col2'), ('e3', 'col3')):
+            there = want[col] >= 0
+            assert np.all(hint[e][~there] == 0), (K, e)
+            assert np.allclose(hint[e][there], want[e][there], rtol=2.5e-7,
+                atol=1e-37), (K, e)      # (float32 denormals: absolute)
         # the two halves of the native step's sweep: the sums, then - the
         # visiting order drawn meanwhile - the records IN that order (record
         # r from row order[r]); the matrix stays indexed by cell, rows that

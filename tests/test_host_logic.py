@@ -739,6 +739,7 @@ def test_sweep_hint_is_used_and_falls_back():
     pair = np.zeros(N, dtype=_lib.TOP2)
     pair['col'], pair['col2'] = truth, rival
     pair['ll_best'], pair['ll_second'] = -100.0, -100.7
+    pair['e2'] = np.exp(-0.7)
     pair['best'] = -100.0 + col_prior[truth]
     pair['second'] = -100.7 + col_prior[rival]
     pair['third'] = -500.0 + col_prior.max()
@@ -748,6 +749,22 @@ def test_sweep_hint_is_used_and_falls_back():
     got = sweep(torn, pair)
     assert np.array_equal(got[0], want[0]) and got[1] == want[1]
     assert used[-1] >= 4        # (a cell whose hinted cluster died is scanned)
+    # (the same with a prior table that is NOT log(size) + const: the loop
+    # notices and takes the exponentials of the re-scored entries instead of
+    # the record's weights, which it poisons here)
+    crp_true = crp.copy()
+    crp[2:] += 0.01 * np.arange(crp.size - 2)
+    odd = pair.copy()
+    odd['best'] = -100.0 + crp[sizes][truth]
+    odd['second'] = -100.7 + crp[sizes][rival]
+    odd['e2'] = 1e3
+    col_prior[:] = crp[sizes]
+    want_odd = sweep(torn, None)
+    got = sweep(torn, odd)
+    assert np.array_equal(got[0], want_odd[0]) and got[1] == want_odd[1]
+    assert used[-1] >= 4
+    crp[:] = crp_true
+    col_prior[:] = crp[sizes]
     # ... but not when the third entry is within reach: every cell is scanned
     near = pair.copy()
     near['third'] = near['second'] - 30.0
