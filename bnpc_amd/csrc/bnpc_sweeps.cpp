@@ -547,6 +547,16 @@ extern "C" int bnpc_triple_pick(int quick, const double *q, const int64_t *a,
             bnpc_set_error("bad argument: triple_pick");
             return 2;
         }
+    if (quick == 2) {
+        // as the sweep loop decides it from a hint record: the weights of
+        // the second / third entry relative to the first as float32 (the
+        // record's e2 / e3 - here the priors are inside them), band 1e-6
+        const double w[3] = {1.0, (double)(float)exp(q[1] - q[0]),
+                             (double)(float)exp(q[2] - q[0])};
+        *pick = (w[1] < 1e30 && w[2] < 1e30)
+            ? triple_pick_weights(w, a, A, u, 1e-6) : -1;
+        return 0;
+    }
     if (quick) {
         *pick = triple_pick_quick(q, a, A, u);
         return 0;
@@ -581,8 +591,12 @@ extern "C" int bnpc_pair_pick(int quick, double d2, int64_t A, int64_t top,
         return 2;
     }
     std::vector<double> cdf((size_t)A + 1);
-    *pick = quick ? pair_pick_quick(d2, A, top, sec, u)
-                  : pair_pick_full(d2, A, top, sec, u, cdf.data());
+    if (quick == 2)     // the loop's form: float32 weight, band 1e-6
+        *pick = pair_pick_weights(1.0, (double)(float)exp(d2), top, sec, A, u,
+                                  1e-6);
+    else
+        *pick = quick ? pair_pick_quick(d2, A, top, sec, u)
+                      : pair_pick_full(d2, A, top, sec, u, cdf.data());
     return 0;
 }
 

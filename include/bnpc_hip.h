@@ -607,8 +607,11 @@ int bnpc_dominated_cdf(int64_t A, int64_t top, double *cdf);
  * (_normalize_log_probs / _normalize_log + np.random.choice, four libm calls);
  * quick = 1: the decision the native loops try first - one exp(), u compared
  * with the interval ends it implies, *pick = -1 when u is within 1e-11 of an
- * end (the loops then take the quick = 0 path).  A decided quick pick must
- * equal the full one: the tests compare them around the ends. */
+ * end (the loops then take the quick = 0 path); quick = 2 (pair and triple):
+ * the form the sweep loop uses with a hint record - the entries' weights with
+ * the exponential rounded to float32 (bnpc_top2.e2 / e3) and a band of 1e-6.
+ * A decided quick pick must equal the full one: the tests compare them around
+ * the ends. */
 int bnpc_pair_pick(int quick, double d2, int64_t A, int64_t top, int64_t sec,
                    double u, int64_t *pick);
 int bnpc_two_way_pick(int quick, double p0, double p1, double u,

@@ -905,7 +905,7 @@ def test_quick_picks_equal_the_full_arithmetic_around_every_boundary():
 
     offsets = [0.0] + [s * 10.0 ** e for e in range(-16, -2) for s in (1, -1)]
     floor = 1e-15
-    declined = decided = 0
+    declined = decided = declined32 = decided32 = 0
     for trial in range(4000):
         A = int(rng.randint(2, 65))
         top, sec = (int(x) for x in rng.permutation(A + 1)[:2])
@@ -935,10 +935,23 @@ def test_quick_picks_equal_the_full_arithmetic_around_every_boundary():
                 else:
                     decided += 1
                     assert quick == full, (d2, A, top, sec, u, off)
+                # the form the sweep loop uses with a hint record: the
+                # exponential as float32, a band of 1e-6
+                loop = pair(2, d2, A, top, sec, u)
+                if loop < 0:
+                    declined32 += 1
+                    assert abs(off) < 1e-5 or min(e1, e2) < 2 * abs(off) \
+                        + 1e-5, (d2, A, top, sec, off)
+                else:
+                    decided32 += 1
+                    assert loop == full, (d2, A, top, sec, u, off)
         for _ in range(4):              # anywhere: decided, and the same
             u = rng.random_sample()
             assert pair(1, d2, A, top, sec, u) == pair(0, d2, A, top, sec, u)
+            loop = pair(2, d2, A, top, sec, u)
+            assert loop < 0 or loop == pair(0, d2, A, top, sec, u)
     assert decided > 50000 and declined > 50000
+    assert decided32 > 30000 and declined32 > 70000
 
     declined = decided = 0
     for trial in range(6000):
@@ -1043,7 +1056,7 @@ def test_quick_pick_among_three_equals_the_scan_around_every_boundary():
 
     offsets = [0.0] + [s * 10.0 ** e for e in range(-16, -2) for s in (1, -1)]
     floor = 1e-15
-    declined = decided = 0
+    declined = decided = decided32 = 0
     for trial in range(3000):
         A = int(rng.randint(2, 65))
         a = np.ascontiguousarray(rng.permutation(A + 1)[:3], dtype=np.int64)
@@ -1073,11 +1086,21 @@ def test_quick_pick_among_three_equals_the_scan_around_every_boundary():
                 else:
                     decided += 1
                     assert quick == triple(0, q, a, A, u), (q, a, A, u, off)
+                # (the loop's form: float32 weights, a band of 1e-6)
+                loop = triple(2, q, a, A, u)
+                if loop >= 0:
+                    decided32 += 1
+                    assert loop == triple(0, q, a, A, u), (q, a, A, u, off)
+                else:
+                    assert abs(off) < 1e-5 or p.min() < 2 * abs(off) + 1e-5, \
+                        (q, a, A, u, off)
         for _ in range(3):
             u = rng.random_sample()
             quick = triple(1, q, a, A, u)
             assert quick < 0 or quick == triple(0, q, a, A, u), (q, a, A, u)
-    assert decided > 50000 and declined > 50000
+            loop = triple(2, q, a, A, u)
+            assert loop < 0 or loop == triple(0, q, a, A, u), (q, a, A, u)
+    assert decided > 50000 and declined > 50000 and decided32 > 30000
 
 
 # ------------------------------------------------------ pieces of the native step
