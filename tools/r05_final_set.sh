@@ -16,10 +16,12 @@ for c in c3 c3k c4 c5; do
     BNPC_TIMING=gibbs,params python3 bench.py --config $c --steps 20 --warmup 6 --cpu-steps 0 > /dev/null 2> $out/host_phase_trace_$c.log
 done
 uptime >> $out/box_load.log
-bash tools/r05_soaks.sh > $out.soaks.log 2>&1
-bash tools/r05_soaks_more.sh > $out.soaks_more.log 2>&1
-uptime >> $out/box_load.log
-tail -n 1 gpurun_out/r05soak/*.log gpurun_out/r05soak2/*.log | grep "first diverging"
+if [ "${SOAKS:-1}" != 0 ]; then     # (SOAKS=0: the measurements only)
+    bash tools/r05_soaks.sh > $out.soaks.log 2>&1
+    bash tools/r05_soaks_more.sh > $out.soaks_more.log 2>&1
+    uptime >> $out/box_load.log
+    tail -n 1 gpurun_out/r05soak/*.log gpurun_out/r05soak2/*.log | grep "first diverging"
+fi
 for f in $out/bench_final_?.json $out/bench_config?.json $out/bench_c3k.json $out/bench_k150.json $out/bench_threads1_?.json $out/bench_step_by_methods.json; do
     python3 -c "
 import json, sys
