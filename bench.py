@@ -590,6 +590,8 @@ def main():
             'sweep_hinted': stats['hint_used'],
             'sweep_pairs': stats['pair_used'],
             'sweep_triples': stats['triple_used'],
+            # ... of sweep_hinted, decided in the loop's lane for such cells
+            'sweep_lane': stats['lane_used'],
             # steps made as ONE native call (bnpc_chain_step) / split-merge
             # moves made as one native call (bnpc_sm_move)
             'native_steps': stats['native_steps'],

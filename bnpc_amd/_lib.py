@@ -71,7 +71,7 @@ class GibbsState(C.Structure):
         ('beta_q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
         ('FP', C.c_double), ('FN', C.c_double), ('gauss', C.c_void_p),
         ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64),
-        ('triple_used', _i64), ('hint_in_order', _i64)]
+        ('triple_used', _i64), ('hint_in_order', _i64), ('lane_used', _i64)]
 
 
 class MoveState(C.Structure):
@@ -149,7 +149,8 @@ class ChainState(C.Structure):
         ('rec_params_done', C.c_int32), ('pad_', C.c_int32),
         ('ML', C.c_double), ('lprior', C.c_double), ('swept', _i64),
         ('hint_used', _i64), ('pair_used', _i64), ('triple_used', _i64),
-        ('native_moves', _i64), ('steps', _i64), ('clock_ns', _i64 * 10),
+        ('native_moves', _i64), ('steps', _i64), ('lane_used', _i64),
+        ('clock_ns', _i64 * 10),
         ('clock_calls', _i64 * 10), ('work', C.c_void_p)]
 
 
@@ -163,7 +164,7 @@ STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
 
 # the version bnpc_abi_version() of a matching library reports (bumped with
 # every change of a structure or signature of include/bnpc_hip.h)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {

@@ -54,7 +54,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 10; }
+extern "C" int bnpc_abi_version(void) { return 11; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \

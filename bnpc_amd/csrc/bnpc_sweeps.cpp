@@ -118,6 +118,24 @@ static bool loop_shortcuts()
     return !(e && e[0] == '0');
 }
 
+// BNPC_SWEEP_LANE (tests; read per call): "0" = no lane for the cells decided
+// from their records (sweep_window's general iteration for every cell: the
+// old-vs-new comparison); a number x in (0, 0.5) = the lane hands every cell
+// whose uniform lies within x of 0 or 1 over to the general iteration WITH
+// that uniform - what it does for the 1e-11 slivers at either end, made
+// frequent enough to test.  Returns the distance, < 0 for "no lane".
+static double sweep_lane_sliver()
+{
+    // (1e-11: with at most 4096 live clusters the floor entries below the
+    // winner end under 4.1e-12 and the ones above it start beyond 1 - 4.1e-12
+    // - the rule sweep_window's dominated pick has for 512 and 1e-12)
+    const char *e = getenv("BNPC_SWEEP_LANE");
+    if (!e || !e[0]) return 1e-11;
+    const double x = strtod(e, nullptr);
+    if (!(x > 0.0)) return -1.0;
+    return x < 0.5 ? (x > 1e-11 ? x : 1e-11) : 1e-11;
+}
+
 // ---------------------------------------------------------------------------
 // Gibbs sweep
 // ---------------------------------------------------------------------------
@@ -622,6 +640,212 @@ extern "C" int bnpc_two_way_pick(int quick, double p0, double p1, double u,
 // (the checker hooks bnpc_pair_pick / bnpc_triple_pick take the same range)
 static const int64_t QUICK_PICK_MAX = 4096;
 
+// The LANE of the cells a hint record decides, in a whole-matrix sweep: in a
+// converged chain nearly every cell is decided by its record - two in three
+// (config 3) or 98 in 100 (configs 4, 5) by its first column beyond doubt, the
+// rest picked between its two or among its three best columns - and what
+// sweep_window's general iteration spends on them (10.9 ns per dominated cell,
+// 40-50 per pick, measured on the GPU box's EPYC: tools/hinted_loop_bench.py)
+// is its own generality: a hundred and sixty instructions per cell, half of
+// its variables on the stack.  Here the same steps for exactly those cases,
+// in the same order with the same arithmetic: the cell leaves its cluster
+// (sizes, prior, drift), the dominance test of its record under the drift,
+// else the pair test, else the triple test, the cell's uniform, the pick, the
+// move - 7.2 ns per dominated cell, 33 / 40 per pick.  The lane stops in front
+// of anything else - a cell whose cluster would die, odd input, the end of
+// the window: nothing done, `removed` = false - or in the middle of a cell it
+// cannot decide: the cell has left its cluster (`removed`) and the general
+// iteration goes on from there, with the cell's uniform if that has been drawn
+// (`have_u`: a dominated pick in the 1e-11 slivers at either end, a pick
+// within the band of an interval end).  No cluster is born or dies in here,
+// so the live list, its positions and the dominance margin are constants of
+// a run of the lane.
+struct RecordLane {
+    // constants of a run
+    const int64_t *perm;
+    const bnpc_top2 *hint;      // narrow records
+    bool in_order;              // hint[p] is the cell at position p
+    const double *post_new, *crp_prior, *cpr0;
+    int64_t hint_cols, N, n_cols, A, pos_end;
+    double margin;              // dom_bound[A]
+    double sliver;              // 1e-11 (sweep_lane_sliver)
+    double band;                // 1e-6: of the two- / three-candidate picks
+    const int64_t *pos64;       // position of a column in the live list, or
+    const int32_t *pos32;       // the same as 32-bit entries (one is NULL)
+    int64_t *assignment;
+    const int64_t *col_of_id, *col_id, *order;
+    int64_t *col_size;
+    double *cpr;
+    bool weights;               // the prior table is log(size) + const: the
+                                // two- and three-candidate picks as well
+    // state
+    int64_t pos;
+    double drift;
+    int64_t decided;            // cells the lane has moved ...
+    int64_t pairs, triples;     // ... of them between two / among three
+    // the cell it stopped in
+    bool removed, have_u;
+    int64_t cell;
+    double u;
+};
+
+static void record_lane(RecordLane &L, bnpc_mt19937 *rng)
+{
+    const int64_t *__restrict__ perm = L.perm;
+    const bnpc_top2 *__restrict__ hint = L.hint;
+    const double *__restrict__ post_new = L.post_new;
+    const double *__restrict__ crp_prior = L.crp_prior;
+    const double *__restrict__ cpr0 = L.cpr0;
+    int64_t *assignment = L.assignment;
+    const int64_t *col_of_id = L.col_of_id, *col_id = L.col_id;
+    const int64_t *order = L.order;
+    int64_t *col_size = L.col_size;
+    double *cpr = L.cpr;
+    const int64_t hint_cols = L.hint_cols, N = L.N, n_cols = L.n_cols;
+    const int64_t pos_end = L.pos_end;
+    const double margin = L.margin, sliver = L.sliver, band = L.band;
+    const bool in_order = L.in_order;
+    const int64_t A = L.A;
+    const bool weights = L.weights;
+    int64_t pos = L.pos, decided = 0, pairs = 0, triples = 0;
+    double drift = L.drift;
+    L.removed = L.have_u = false;
+    auto pos_of = [&](int64_t c) -> int64_t {
+        return L.pos64 ? L.pos64[c] : (int64_t)L.pos32[c];
+    };
+    while (pos < pos_end) {
+        const int64_t cell = perm[pos];
+        if (pos + 16 < pos_end) {
+            const uint64_t ahead = (uint64_t)perm[pos + 16];
+            if (ahead < (uint64_t)N) {
+                if (!in_order) __builtin_prefetch(&hint[ahead], 0, 1);
+                __builtin_prefetch(&assignment[ahead], 1, 1);
+                __builtin_prefetch(&post_new[ahead], 0, 1);
+            }
+        }
+        if ((uint64_t)cell >= (uint64_t)N) break;
+        const int64_t old_id = assignment[cell];
+        if ((uint64_t)old_id >= (uint64_t)N) break;
+        const int64_t old_col = col_of_id[old_id];
+        if ((uint64_t)old_col >= (uint64_t)n_cols) break;
+        const int64_t old_size = col_size[old_col];
+        if (old_size < 2) break;        // its cluster dies (or odd input)
+        // the cell leaves its cluster (libs/CRP.py:262-266)
+        col_size[old_col] = old_size - 1;
+        const double left = crp_prior[old_size - 1];
+        cpr[old_col] = left;
+        if (old_col < hint_cols) {
+            const double d = fabs(left - cpr0[old_col]);
+            if (d > drift) drift = d;
+        }
+        // its record's first column against everything else, widened by how
+        // far the priors have moved since the launch
+        const bnpc_top2 &h = hint[in_order ? pos : cell];
+        const int64_t hc = h.col;
+        int64_t at = -1;
+        if ((uint64_t)hc < (uint64_t)hint_cols && col_size[hc] > 0)
+            at = pos_of(hc);
+        double other = h.second + drift;
+        const double pn = post_new[cell];
+        if (pn > other) other = pn;
+        int64_t pick = -1;
+        bool drawn = false;
+        double u = 0.0;
+        if (at >= 0 && other - (h.best - drift) < margin) {
+            u = mt_double(rng);
+            drawn = true;
+            if (u > sliver && u < 1.0 - sliver) pick = at;
+        } else if (weights && at >= 0) {
+            // Not dominated: torn between its record's two best columns,
+            // re-scored under the current priors, everything else more than
+            // 61 below the lower one (sweep_window's pair test), ...
+            const int64_t c2 = h.col2, c3 = h.col3;
+            int64_t a2 = -1, a3 = -1;
+            if ((uint64_t)c2 < (uint64_t)hint_cols && c2 != hc
+                && col_size[c2] > 0)
+                a2 = pos_of(c2);
+            if (a2 >= 0) {
+                const double q1 = h.ll_best + cpr[hc];
+                const double q2 = h.ll_second + cpr[c2];
+                double rest = (double)h.third + drift;
+                if (pn > rest) rest = pn;
+                const double low = q1 < q2 ? q1 : q2;
+                if (q1 > -INFINITY && q1 < INFINITY && q2 > -INFINITY
+                    && q2 < INFINITY && rest < low - 61.0) {
+                    if (h.e2 < 1e30f) {
+                        const bool first = q1 > q2 || (q1 == q2 && at < a2);
+                        const int64_t top = first ? at : a2;
+                        const double gap = first ? q2 - q1 : q1 - q2;
+                        u = mt_double(rng);
+                        drawn = true;
+                        if (gap < margin) {
+                            // (the runner-up beyond the dominance margin)
+                            if (u > sliver && u < 1.0 - sliver) pick = top;
+                        } else {
+                            pick = pair_pick_weights((double)col_size[hc],
+                                (double)h.e2 * (double)col_size[c2], at, a2, A,
+                                u, band);
+                        }
+                        if (pick >= 0) pairs++;
+                    }
+                } else if (A >= 2 && (uint64_t)c3 < (uint64_t)hint_cols
+                           && c3 != hc && c3 != c2 && col_size[c3] > 0
+                           && (a3 = pos_of(c3)) >= 0) {
+                    // ... or among its three best, everything else more than
+                    // 61 below the middle one (the triple test)
+                    const double q3 = h.ll_third + cpr[c3];
+                    double rest4 = (double)h.fourth + drift;
+                    if (pn > rest4) rest4 = pn;
+                    const double hi3 = q1 > q2 ? (q1 > q3 ? q1 : q3)
+                                               : (q2 > q3 ? q2 : q3);
+                    const double lo3 = q1 < q2 ? (q1 < q3 ? q1 : q3)
+                                               : (q2 < q3 ? q2 : q3);
+                    const double mid3 = q1 + q2 + q3 - hi3 - lo3;
+                    if (lo3 > -INFINITY && hi3 < INFINITY
+                        && rest4 < mid3 - 61.0 && h.e2 < 1e30f
+                        && h.e3 < 1e30f) {
+                        const double w[3] = {(double)col_size[hc],
+                            (double)h.e2 * (double)col_size[c2],
+                            (double)h.e3 * (double)col_size[c3]};
+                        const int64_t a[3] = {at, a2, a3};
+                        u = mt_double(rng);
+                        drawn = true;
+                        pick = triple_pick_weights(w, a, A, u, band);
+                        if (pick >= 0) triples++;
+                    }
+                }
+            }
+        }
+        if (pick < 0) {
+            // not for this lane: the general iteration goes on with the cell
+            // (and with its uniform, if that has been drawn)
+            L.removed = true;
+            L.have_u = drawn;
+            L.cell = cell;
+            L.u = u;
+            break;
+        }
+        // it joins (or stays in) the cluster picked
+        const int64_t c = order[pick];
+        assignment[cell] = col_id[c];
+        const int64_t grown = col_size[c] + 1;
+        col_size[c] = grown;
+        const double now = crp_prior[grown];
+        cpr[c] = now;
+        if (c < hint_cols) {
+            const double d = fabs(now - cpr0[c]);
+            if (d > drift) drift = d;
+        }
+        pos++;
+        decided++;
+    }
+    L.pos = pos;
+    L.drift = drift;
+    L.decided = decided;
+    L.pairs = pairs;
+    L.triples = triples;
+}
+
 static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                         const int64_t *perm, const double *ll,
                         const double *post_new, const double *crp_prior,
@@ -795,7 +1019,63 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
     }
 
     int64_t free_hint = 0;      // no id below it is free (native births)
+    // the lane of the dominated cells (record_lane): whole-matrix hints,
+    // the shortcuts on; entered whenever no column has been born since the
+    // launch, the live list has its position table and at most 4096 entries
+    // (the quick picks' range; sweep_lane_sliver for the dominated pick)
+    RecordLane lane;
+    const double lane_sliver = sweep_lane_sliver();
+    const bool lane_usable = narrow && shortcuts && lane_sliver > 0.0;
+    if (lane_usable) {
+        lane.perm = perm;
+        lane.hint = hint;
+        lane.in_order = in_order;
+        lane.post_new = post_new;
+        lane.crp_prior = crp_prior;
+        lane.cpr0 = cpr0;
+        lane.hint_cols = hint_cols;
+        lane.N = N;
+        lane.pos_end = st->pos_end;
+        lane.assignment = assignment;
+        lane.col_of_id = col_of_id;
+        lane.col_id = col_id;
+        lane.order = order;
+        lane.col_size = col_size;
+        lane.cpr = cpr;
+        lane.weights = size_weights;
+        lane.sliver = lane_sliver;
+        // (the test switch widens the band of the picks as well)
+        lane.band = lane_sliver > 1e-6 ? lane_sliver : 1e-6;
+    }
     while (st->pos < st->pos_end) {
+        bool lane_removed = false, lane_have_u = false;
+        double lane_u = 0.0;
+        if (lane_usable && st->n_active >= 1
+            && st->n_active <= QUICK_PICK_MAX
+            && order[st->n_active - 1] < hint_cols
+            && (pos_table || big_valid)) {
+            lane.n_cols = st->n_cols;
+            lane.A = st->n_active;
+            lane.margin = dom_bound[st->n_active];
+            lane.pos64 = pos_table ? pos_of_col : nullptr;
+            lane.pos32 = pos_table ? nullptr : pos_big.data();
+            lane.pos = st->pos;
+            lane.drift = drift;
+            record_lane(lane, rng);
+            st->pos = lane.pos;
+            drift = lane.drift;
+            st->hint_used += lane.decided;
+            st->lane_used += lane.decided;
+            st->pair_used += lane.pairs;
+            st->triple_used += lane.triples;
+            if (!lane.removed) {
+                if (st->pos >= st->pos_end) break;
+            } else {
+                lane_removed = true;
+                lane_have_u = lane.have_u;
+                lane_u = lane.u;
+            }
+        }
         const int64_t cell = perm[st->pos];
         // rows are visited in permutation order: pull the row (and the
         // per-cell scalars) of a cell a few positions ahead into the cache
@@ -826,16 +1106,22 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             bnpc_set_error("perm[%lld] out of range", (long long)st->pos);
             return 2;
         }
-        // remove the cell from its cluster (CRP.py:262-266)
+        // remove the cell from its cluster (CRP.py:262-266) - unless the
+        // lane has (it stopped at this cell because it is not dominated)
         const int64_t old_id = assignment[cell];
         const int64_t old_col = (old_id >= 0 && old_id < N) ?
             col_of_id[old_id] : -1;
-        if (old_col < 0 || old_col >= st->n_cols || col_size[old_col] < 1) {
+        if (lane_removed) {
+            // (the cell has left its cluster: nothing to do here)
+        } else if (old_col < 0 || old_col >= st->n_cols
+                   || col_size[old_col] < 1) {
             bnpc_set_error("cell %lld sits in unknown cluster %lld",
                            (long long)cell, (long long)old_id);
             return 3;
         }
-        if (col_size[old_col] == 1) {
+        if (lane_removed) {
+            // (sizes, prior and drift are the lane's)
+        } else if (col_size[old_col] == 1) {
             // the live list is ascending in column index (columns are handed
             // out in increasing order and deletions keep the order): bisect,
             // and fall back to a walk should that ever not hold
@@ -980,9 +1266,11 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         // drawn now; if it is clear of the interval ends the three entries
         // imply, the pick is known, else the cell is scanned with that same
         // uniform.
-        bool triple = false, have_u = false;
+        // (have_u: the lane has drawn this cell's uniform already - one of
+        // the 1e-11 slivers at either end, for the dominated pick below)
+        bool triple = false, have_u = lane_have_u;
         int64_t triple_pick = 0;
-        double u_saved = 0.0;
+        double u_saved = lane_u;
         if (narrow && !hinted && !pair && A <= QUICK_PICK_MAX && A >= 2
             && shortcuts) {
             const bnpc_top2 &h = hint[hrow];
@@ -1014,7 +1302,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
                 // below is 61 against the scan's 60)
                 if (lo3 > -INFINITY && hi3 < INFINITY
                     && other < mid3 - 61.0) {
-                    u_saved = mt_double(rng);
+                    if (!have_u) u_saved = mt_double(rng);
                     have_u = true;
                     if (size_weights && h.e2 < 1e30f && h.e3 < 1e30f) {
                         const double w[3] = {(double)col_size[c[0]],

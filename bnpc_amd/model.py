@@ -1170,6 +1170,7 @@ class CRP:
         self._pair_used = getattr(self, '_pair_used', 0) + int(st.pair_used)
         self._triple_used = getattr(self, '_triple_used', 0) \
             + int(st.triple_used)
+        self._lane_used = getattr(self, '_lane_used', 0) + int(st.lane_used)
         self._swept = getattr(self, '_swept', 0) + (pos_end - pos)
         if tile_timing:
             print(f'[bnpc]   tile [{pos},{pos_end}) cols={cols.size} '
@@ -1388,17 +1389,19 @@ class CRP:
     def host_stats(self):
         """Counters of the sweeps and moves made so far (bench.py): cells
         swept / decided from the device's hint / between two / among three
-        columns, moves made natively, steps made natively."""
+        columns / in the loop's lane (bnpc_gibbs_state.lane_used), moves made
+        natively, steps made natively."""
         out = {'swept': getattr(self, '_swept', 0),
             'hint_used': getattr(self, '_hint_used', 0),
             'pair_used': getattr(self, '_pair_used', 0),
             'triple_used': getattr(self, '_triple_used', 0),
+            'lane_used': getattr(self, '_lane_used', 0),
             'native_moves': getattr(self, '_native_moves', 0),
             'native_steps': getattr(self, '_native_steps', 0)}
         nat = getattr(self, '_nat', None)
         if nat is not None:
             for key in ('swept', 'hint_used', 'pair_used', 'triple_used',
-                    'native_moves'):
+                    'lane_used', 'native_moves'):
                 out[key] += getattr(nat.st, key)
         return out
 

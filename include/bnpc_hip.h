@@ -694,6 +694,14 @@ typedef struct bnpc_gibbs_state {
      * perm (bnpc_hints_in_order_issue), not to cell p; the rows of ll stay
      * indexed by cell */
     int64_t hint_in_order;
+    /* out: of hint_used, the cells decided in the loop's LANE (accumulated):
+     * a compact second loop inside bnpc_gibbs_sweep for the cells a record
+     * decides - dominated, or picked between two / among three candidates -
+     * while no column has been born since the launch; it stops in front of
+     * everything else and the general iteration takes over (same steps, same
+     * arithmetic, same stream: the result does not depend on it;
+     * BNPC_SWEEP_LANE=0 switches it off). */
+    int64_t lane_used;
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
@@ -866,6 +874,7 @@ typedef struct bnpc_chain {
     double ML, lprior;
     /* ---- running statistics ---- */
     int64_t swept, hint_used, pair_used, triple_used, native_moves, steps;
+    int64_t lane_used;          /* of hint_used: bnpc_gibbs_state.lane_used */
     /* wall time by part of the step, ns / calls: 0 Gibbs, 1 split accepted,
      * 2 split rejected, 3 merge accepted, 4 merge rejected, 5 DP alpha,
      * 6 parameters, 7 error rates, 8 record, 9 of 0: the sweep waiting for

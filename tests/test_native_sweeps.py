@@ -105,7 +105,7 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns,
     if used is not None:
         used.append(int(st.hint_used))
         native_gibbs.last = (int(st.hint_used), int(st.pair_used),
-            int(st.triple_used))
+            int(st.triple_used), int(st.lane_used))
     live = order[:st.n_active]
     return assignment, {int(col_id[c]): int(col_size[c]) for c in live}, n_new
 
@@ -641,7 +641,7 @@ def test_native_beta_theta_and_this_numpy():
     assert np.random.get_state()[2] == pos      # nothing was drawn
 
 
-def test_sweep_hints_fuzz():
+def test_sweep_hints_fuzz(monkeypatch):
     """The per-cell hint (three largest entries, the two best columns and
     their log-likelihoods) against the plain scan on 200 random sweeps whose
     matrices hold what a running chain holds: clear winners, cells torn
@@ -650,6 +650,7 @@ def test_sweep_hints_fuzz():
     born under the hint.  Same assignments, cluster tables, births, stream;
     most cells are decided without a scan."""
     decided = cells = pairs = triples = 0
+    in_lane = {}
     for seed in range(200):
         rng = np.random.RandomState(7000 + seed)
         N = int(rng.choice([30, 90, 200]))
@@ -689,28 +690,45 @@ def test_sweep_hints_fuzz():
         hint = _lib.hints_from_matrix(ll, col_prior)
         outs, used = [], []
         # (no hints / records by cell / records in visiting order)
-        for h, in_order in ((None, False), ((hint, col_prior), False),
-                ((hint, col_prior), True)):
+        for h, in_order, lane in ((None, False, None),
+                ((hint, col_prior), False, None),
+                ((hint, col_prior), True, None),
+                ((hint, col_prior), True, '0'),
+                ((hint, col_prior), seed % 2 == 0, '0.05'),
+                ((hint, col_prior), seed % 2 == 1, '0.3')):
+            # (lane: BNPC_SWEEP_LANE - the lane of the cells decided from
+            # their records switched off, or handing a share of its cells
+            # over to the general iteration with their uniforms drawn)
+            if lane is None:
+                monkeypatch.delenv('BNPC_SWEEP_LANE', raising=False)
+            else:
+                monkeypatch.setenv('BNPC_SWEEP_LANE', lane)
             np.random.seed(seed)
             got = native_gibbs(ll, post_new, crp_prior, assignment, sizes,
                 new_columns, hint=h, used=used, in_order=in_order)
             outs.append((got[0], list(got[1].items()), got[2],
                 np.random.random(2)))
+            if h is not None:
+                in_lane[lane] = in_lane.get(lane, 0) + native_gibbs.last[3]
         for other in outs[1:]:
             assert np.array_equal(outs[0][0], other[0]), seed
             assert outs[0][1] == other[1] and outs[0][2] == other[2], seed
             assert np.array_equal(outs[0][3], other[3]), seed
-        assert used[1] == used[2], seed
+        assert used[1] == used[2] == used[3] == used[4] == used[5], seed
         decided += used[1]
         pairs += native_gibbs.last[1]
         triples += native_gibbs.last[2]
         cells += N
     assert decided > 0.7 * cells, (decided, cells)
     assert pairs > 0.1 * cells and triples > 0.05 * cells, (pairs, triples)
+    # the lane took its share (both record layouts: twice the cells), less
+    # when it hands cells over, nothing when it is switched off
+    assert in_lane[None] > 0.25 * 2 * cells, (in_lane, cells)
+    assert in_lane['0'] == 0 and 0 < in_lane['0.3'] < in_lane[None], in_lane
 
 
 @pytest.mark.parametrize('K', [65, 150, 400, 1500])
-def test_sweep_hints_with_hundreds_of_columns(K):
+def test_sweep_hints_with_hundreds_of_columns(K, monkeypatch):
     """The same comparison for sweeps of MORE than 64 columns (a running
     chain with hundreds of clusters; the first sweep of a data set whose
     matrix fits the host budget): the hint's columns are found in the live
@@ -719,6 +737,7 @@ def test_sweep_hints_with_hundreds_of_columns(K):
     winners, torn cells) and first-sweep ones (every column near every other
     one - all cells scanned - until clusters are born that dominate)."""
     decided = cells = pairs = triples = 0
+    in_lane = {}
     for seed in range(12):
         rng = np.random.RandomState(9000 + 31 * K + seed)
         N = int(rng.choice([2 * K, 3 * K + 7, 4 * K]))
@@ -779,18 +798,31 @@ def test_sweep_hints_with_hundreds_of_columns(K):
             crp_prior[np.fromiter(sizes.values(), dtype=np.int64)])
         hint = _lib.hints_from_matrix(ll, col_prior)
         outs, used = [], []
-        for h, in_order in ((None, False), ((hint, col_prior), False),
-                ((hint, col_prior), True)):
+        for h, in_order, lane in ((None, False, None),
+                ((hint, col_prior), False, None),
+                ((hint, col_prior), True, None),
+                ((hint, col_prior), True, '0'),
+                ((hint, col_prior), seed % 2 == 0, '0.05'),
+                ((hint, col_prior), seed % 2 == 1, '0.3')):
+            # (lane: BNPC_SWEEP_LANE - the lane of the cells decided from
+            # their records switched off, or handing a share of its cells
+            # over to the general iteration with their uniforms drawn)
+            if lane is None:
+                monkeypatch.delenv('BNPC_SWEEP_LANE', raising=False)
+            else:
+                monkeypatch.setenv('BNPC_SWEEP_LANE', lane)
             np.random.seed(seed)
             got = native_gibbs(ll, post_new, crp_prior, assignment, sizes,
                 new_columns, hint=h, used=used, in_order=in_order)
             outs.append((got[0], list(got[1].items()), got[2],
                 np.random.random(2)))
+            if h is not None:
+                in_lane[lane] = in_lane.get(lane, 0) + native_gibbs.last[3]
         for other in outs[1:]:
             assert np.array_equal(outs[0][0], other[0]), seed
             assert outs[0][1] == other[1] and outs[0][2] == other[2], seed
             assert np.array_equal(outs[0][3], other[3]), seed
-        assert used[1] == used[2], seed
+        assert used[1] == used[2] == used[3] == used[4] == used[5], seed
         if not first_sweep:
             decided += used[1]
             pairs += native_gibbs.last[1]
@@ -801,6 +833,7 @@ def test_sweep_hints_with_hundreds_of_columns(K):
     # (a cell whose favourite cluster has died since the launch is scanned)
     assert decided > 0.7 * cells, (decided, cells)
     assert pairs > 0.1 * cells and triples > 0.05 * cells, (pairs, triples)
+    assert in_lane['0'] == 0 and 0 < in_lane['0.3'] < in_lane[None], in_lane
 
 
 # ------------------------------------------------ native split / merge moves
