@@ -1110,6 +1110,10 @@ def test_chain_with_hundreds_of_clusters_matches_oracle(monkeypatch):
     # from the second sweep on nearly every cell is decided from its record
     assert nat[1]['hint_used'] > 0.8 * nat[1]['swept'], nat[1]
     assert ref[1]['hint_used'] > 0.8 * ref[1]['swept'], ref[1]
+    # ... most of them in the loop's lane for such cells (native step and
+    # method-by-method walk alike: the same loop)
+    assert nat[1]['lane_used'] > 0.7 * nat[1]['swept'], nat[1]
+    assert ref[1]['lane_used'] == nat[1]['lane_used'], (ref[1], nat[1])
     for i, (a, b) in enumerate(zip(nat[0], ref[0])):
         for x, y in zip(a, b):
             if isinstance(x, np.ndarray):
