@@ -4,6 +4,7 @@ configuration (config 3: synthetic 5,000 cells x 1,000 mutations, 20 % missing,
 learned error rates), one independent chain per GPU.
 
     python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus N ...        (spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -214,10 +215,7 @@ class Ranks:
         # ranks bound to the same NUMA node divide its CPUs (as the chains of
         # a multi-chain run do, bnpc_amd.mcmc._bind_worker_to_gpu)
         local = int(os.environ.get('LOCAL_WORLD_SIZE', self.world))
-        share = _lib.host_share(local, n_dev)
-        if share > 1:
-            os.environ.setdefault('BNPC_HOST_SHARE', str(share))
-            os.environ.setdefault('BNPC_HOST_SPIN_US', '5')
+        self.host_settings = _lib.host_settings(local, n_dev, keep_env=True)
         return self
 
     def barrier_sync(self):
@@ -390,6 +388,61 @@ def ll_roofline(ctx, rng, N, M, K, reps, traffic=None, traffic_src=None):
     }, evals
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: N rank processes of this very
+    command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run
+    sets them), started BEFORE anything in this process has touched a GPU -
+    the parent never does.  Rank 0 prints the line on the stdout it inherits;
+    the parent waits, ends the others if one fails, and returns the first
+    non-zero exit code (libs/MCMC.py:100-120: the reference's pool of
+    chains)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r),
+            WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+            MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + list(argv),
+            env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:          # the others wait in a barrier
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(ranks, args):
+    """--dry: the rank harness alone (rendezvous, barriers, max over ranks,
+    the gathered identities) around steps that only sleep - no chain, no
+    device.  What the CPU tests run as a COMMAND."""
+    if args.dry_fail_rank == ranks.rank:
+        os._exit(7)             # (the test of the spawner's failure path)
+    elapsed = timed_steps(ranks, lambda i: time.sleep(0.002), 1, args.steps)
+    devices, distinct = devices_of(ranks, args.steps)
+    if ranks.rank == 0:
+        print(json.dumps({'dry': True, 'ranks': ranks.world,
+            'gpus_asked': args.gpus,
+            'n_gpus': distinct if distinct is not None else ranks.world,
+            'steps': args.steps,
+            'value': round(ranks.world * args.steps / elapsed, 3),
+            'devices': devices, 'host_settings': ranks.host_settings}))
+    ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -404,11 +457,34 @@ def main():
             'least one step is made: a warm-up of 0 puts the first sweep, '
             'minutes on the CPU, into the leg)')
     ap.add_argument('--kernel-reps', type=int, default=5)
+    ap.add_argument('--sustained-steps', type=int, default=200,
+        help='steps run AFTER the timed window for the line\'s `sustained` '
+            'rate (0 = skip); the window itself is untouched')
+    ap.add_argument('--device-steps', type=int, default=50,
+        help='steps run after those with per-launch device timers on, for '
+            '`window.device_ms_per_step` (0 = skip)')
+    ap.add_argument('--dry', action='store_true',
+        help='the rank harness only: no chain, no device (CPU tests)')
+    ap.add_argument('--dry-fail-rank', type=int, default=-1,
+        help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # --gpus N means N ranks.  Under a launcher (WORLD_SIZE set) the two must
+    # agree; without one this process starts the ranks itself, before any GPU
+    # call, and only relays their exit code.
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: the '
+            'launcher\'s rank count and --gpus must agree', file=sys.stderr)
+        sys.exit(2)
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     ranks = Ranks().init()
     rank, world = ranks.rank, ranks.world
     os.environ['BNPC_DEVICE'] = str(ranks.device)
+    if args.dry:
+        return dry_run(ranks, args)
 
     import libs.CRP as dev_fixed
     import libs.CRP_learning_errors as dev_learn
@@ -452,6 +528,9 @@ def main():
     gc.collect()
     clock = MoveClock(model)
     clock.on = True
+    # (the host.* counters of the line are the WINDOW's: deltas against this)
+    stats0 = dict(model.host_stats())
+    screen0 = model._dev().mh_screen_stats()
     cpu0 = time.process_time()      # all threads of this process
     elapsed = timed_steps(ranks, lambda i: step(chain, i, burn),
         args.warmup + 1, total)
@@ -459,7 +538,48 @@ def main():
     clock.on = False
     K_end = len(model.cells_per_cluster)
     ml_end = float(chain.results['ML'][total])
+    stats1 = dict(model.host_stats())
+    screen1 = model._dev().mh_screen_stats()
     devices, distinct_gpus = devices_of(ranks, args.steps)   # (collective)
+
+    # ---- after the window: what the chain sustains, and its device time ---
+    # The driver's window may be short (20 steps: 8 ms at config 3) and its
+    # rate moves with the moves it happened to draw; the reference's own
+    # metric is a whole-run average (libs/dpmmIO.py:310-315).  The chain walks
+    # on: `sustained` = the same timing over --sustained-steps more steps.
+    sustained = device_time = None
+    at = total
+    if args.sustained_steps > 0:
+        chain.add_slots(args.sustained_steps + args.device_steps + 1)
+        own_window = ranks.own_s
+        s_el = timed_steps(ranks, lambda i: step(chain, i, False), at + 1,
+            at + args.sustained_steps)
+        ranks.own_s = own_window
+        at += args.sustained_steps
+        sustained = {'steps': args.sustained_steps,
+            'steps_s': round(world * args.sustained_steps / s_el, 3),
+            'ms_per_step': round(1e3 * s_el / args.sustained_steps, 4),
+            'K_end': len(model.cells_per_cluster)}
+    if rank == 0 and args.device_steps > 0:
+        # per-launch timers (the start / stop timestamps of every kernel
+        # dispatch, as rocprofv3's kernel trace reads them): their sum over
+        # these steps is the device's busy time
+        if args.sustained_steps <= 0:
+            chain.add_slots(args.device_steps + 1)
+        dctx = model._dev()
+        dctx.launch_timers(True)
+        t0 = time.perf_counter()
+        for i in range(at + 1, at + args.device_steps + 1):
+            step(chain, i, False)
+        dctx.sync()
+        wall = time.perf_counter() - t0
+        dev_ms, launches = dctx.launch_timers(False)
+        at += args.device_steps
+        device_time = {'steps': args.device_steps,
+            'device_ms_per_step': round(dev_ms / args.device_steps, 4),
+            'launches_per_step': round(launches / args.device_steps, 2),
+            'ms_per_step_with_timers': round(1e3 * wall / args.device_steps,
+                4)}
 
     # ---- roofline of the dominant kernel, measured live -------------------
     roofline = roofline_converged = None
@@ -564,8 +684,8 @@ def main():
 
     if rank == 0:
         from bnpc_amd import _lib, model as pmodel
-        seen, kept = model._dev().mh_screen_stats()
-        stats = model.host_stats()
+        seen, kept = screen1[0] - screen0[0], screen1[1] - screen0[1]
+        stats = {key: stats1[key] - stats0.get(key, 0) for key in stats1}
         host_info = {
             'threads': _lib.host_threads(),
             'threads_wide_batches': _lib.threads_for(K_end * M),
@@ -582,10 +702,9 @@ def main():
             # costs the host it shares with the other chains of a node
             'cpu_ms_per_step': round(1e3 * proc_cpu_s / args.steps, 3),
             'cpu_busy_threads': round(proc_cpu_s / elapsed, 2),
-            # parameter-batch entries screened on the device / share of them
-            # the host still had to evaluate (accepted or in doubt)
-            # cells of all sweeps so far / decided from the device's hint
-            # without a scan / of those, between the row's two best columns
+            # (counters of the TIMED WINDOW: deltas over its steps)
+            # cells of its sweeps / decided from the device's hint without a
+            # scan / of those, between the row's two best columns
             'sweep_cells': stats['swept'],
             'sweep_hinted': stats['hint_used'],
             'sweep_pairs': stats['pair_used'],
@@ -596,10 +715,21 @@ def main():
             # moves made as one native call (bnpc_sm_move)
             'native_steps': stats['native_steps'],
             'native_moves': stats['native_moves'],
+            # parameter-batch entries screened on the device / share of them
+            # the host still had to evaluate (accepted or in doubt)
             'mh_screened': seen,
             'mh_left_to_host': round(kept / seen, 4) if seen else None,
         }
         value = world * args.steps / elapsed
+        window = clock.report(args.steps, elapsed)
+        if device_time is not None:
+            # device busy time per step (measured on the steps right after
+            # the sustained leg, timers on) and the share of a step it is
+            per = (sustained or {}).get('ms_per_step') \
+                or 1e3 * elapsed / args.steps
+            window.update(device_time)
+            window['device_busy_frac'] = round(
+                device_time['device_ms_per_step'] / per, 4)
         line = {
             'metric': ('MCMC steps/s, 5k cells x 1k muts' if args.config == 'c3'
                 else f'MCMC steps/s, {N} cells x {M} muts')
@@ -632,7 +762,8 @@ def main():
                 else round(first_step_s, 4),
             # what the timed window was made of (rank 0): a window's value
             # depends on its move mix - split/merge steps cost ~3x a Gibbs step
-            'window': clock.report(args.steps, elapsed),
+            'window': window,
+            'sustained': sustained,
             'ML_end': ml_end,
             'roofline': roofline,
             'roofline_converged': roofline_converged,

@@ -164,7 +164,7 @@ STEP_CLOCKS = ('gibbs', 'split_accepted', 'split_rejected', 'merge_accepted',
 
 # the version bnpc_abi_version() of a matching library reports (bumped with
 # every change of a structure or signature of include/bnpc_hip.h)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # name -> (restype, argtypes); must list every symbol of include/bnpc_hip.h
 SIGNATURES = {
@@ -227,6 +227,8 @@ SIGNATURES = {
     'bnpc_ll_total_wait': (C.c_int, [_ctx, _pd]),
     'bnpc_bench_ll': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
     'bnpc_bench_ll_full': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
+    'bnpc_launch_timers': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_double),
+        C.POINTER(C.c_int64)]),
     'bnpc_last_launch': (C.c_int, [_ctx, C.c_char_p, C.c_int,
         C.POINTER(_i64), C.POINTER(C.c_int)]),
     'bnpc_timer_start': (C.c_int, [_ctx]),
@@ -442,6 +444,52 @@ def host_share(n_chains, n_devices, nodes=None):
     nodes = nodes or numa_node_count()
     groups = max(1, min(int(nodes), int(n_devices), int(n_chains)))
     return max(1, -(-int(n_chains) // groups))
+
+
+# logical CPUs of its NUMA node a chain must have to itself to keep the
+# settings of a chain alone (team spinning 300 us between the batches of a
+# step, a rank per 2 blocks for the small batches: 3.4 busy threads); with
+# fewer it gives idle ranks back after 5 us and wakes a rank per 12 blocks
+# (1.4 busy threads).  Round 5 keyed this on "shares a node" - on the target
+# (8 GPUs, 2 x 64 cores: 4 chains per node, 32 logical CPUs each) every chain
+# then ran the frugal settings with 28 CPUs idle.
+GREEDY_MIN_CPUS = 8
+
+
+def node_cpus(nodes=None):
+    """Logical CPUs of one NUMA node as this process may use them: the
+    online CPUs divided by the nodes, capped by the affinity mask (a process
+    already bound to a node, a cgroup)."""
+    nodes = nodes or numa_node_count()
+    total = os.cpu_count() or 1
+    return max(1, min(_host_cores(), max(1, total // max(1, int(nodes)))))
+
+
+def host_settings(n_chains, n_devices, nodes=None, apply=True,
+            keep_env=False):
+    """The host side of one of `n_chains` concurrent chains on `n_devices`
+    GPUs (bnpc_amd.mcmc's workers, bench.py's ranks): how many chains share
+    the CPUs of its NUMA node, how many logical CPUs that leaves it, and
+    whether it keeps the settings of a chain alone (`greedy`).  apply=True
+    exports them: BNPC_HOST_SHARE always (the default team size goes by it),
+    BNPC_HOST_SPIN_US=5 for a frugal chain unless the user set one.
+    keep_env: a BNPC_HOST_SHARE the user exported is taken as it is."""
+    share = host_share(n_chains, n_devices, nodes)
+    if keep_env and env('BNPC_HOST_SHARE'):
+        try:
+            share = max(1, int(env('BNPC_HOST_SHARE')))
+        except ValueError:
+            pass
+    per_chain = node_cpus(nodes) // share
+    greedy = share == 1 or per_chain >= GREEDY_MIN_CPUS
+    out = {'share': share, 'cpus_per_chain': per_chain, 'greedy': greedy}
+    if apply:
+        os.environ['BNPC_HOST_SHARE'] = str(share)
+        if not greedy:
+            os.environ.setdefault('BNPC_HOST_SPIN_US', '5')
+    out['spin_us'] = int(os.environ.get('BNPC_HOST_SPIN_US') or 300) \
+        if apply else (300 if greedy else 5)
+    return out
 
 
 _affinity = {'pid': None, 'original': None, 'bound': 0}
@@ -1719,6 +1767,14 @@ class Context:
         check(self._lib.bnpc_bench_ll_full(self._h, reps, C.byref(ms)),
             'bench_ll_full')
         return ms.value
+
+    def launch_timers(self, on):
+        """Per-launch device timers (bnpc_launch_timers).  on=True: start;
+        on=False: stop, returns (sum of kernel durations in ms, launches)."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self._lib.bnpc_launch_timers(self._h, 1 if on else 0,
+            C.byref(ms), C.byref(n)), 'launch_timers')
+        return None if on else (ms.value, n.value)
 
     def last_launch(self):
         """(kernel name(s), clusters, mutation chunks) of the last ll call."""

@@ -68,6 +68,10 @@ public:
         const char *e = getenv("BNPC_HOST_SPIN_US");
         spin_ns_ = (e ? atol(e) : 300) * 1000L;
     }
+    // a chain whose driver gave it the short spin (it has fewer than a
+    // handful of CPUs to itself) is frugal with ranks as well: every rank it
+    // wakes is taken from a neighbour
+    bool frugal() const { return spin_ns_ < 50000; }
     int size() const { return ranks_.load(std::memory_order_acquire); }
     pid_t pid() const { return pid_; }
 
@@ -670,8 +674,9 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // scans of a move: half a dozen) take a rank per 2 blocks as well
         // when this chain has the host's cores to itself - with the team
         // spinning 300 us between jobs, i.e. across a whole converged step
-        // (Team::Team) - and a rank per 12 when chains share a NUMA node
-        // (BNPC_HOST_SHARE > 1: every woken rank is taken from a neighbour).
+        // (Team::Team) - and a rank per 12 when it has fewer than
+        // GREEDY_MIN_CPUS logical CPUs of its NUMA node to itself
+        // (bnpc_amd._lib.host_settings: the short spin, Team::frugal).
         // Round 5, config 3, five interleaved runs on one box: 2054-2147
         // steps/s (median 2140) with a rank per 12 blocks and 50 us of
         // spinning, 2107-2275 (median 2234) with a rank per 2 and 300 us, at
@@ -679,10 +684,9 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         // Three interleaved runs each on a loaded box (load average 34), new
         // against old: config 3 2145 / 2098, config 4 1518 / 1457, config 5
         // 314 / 299 (means).
-        static const int64_t per_small = [] {
-            const char *e = getenv("BNPC_HOST_SHARE");
-            return (e && atol(e) > 1) ? (int64_t)12 : (int64_t)2;
-        }();
+        // (read where the team reads its spin: once per process, again in a
+        // forked child - the drivers set both before the first batch)
+        const int64_t per_small = team_for(1)->frugal() ? 12 : 2;
         const int64_t per = blocks >= 32 ? 2 : (blocks >= 16 ? 4 : per_small);
         if (threads > (blocks + per - 1) / per)
             threads = (int)((blocks + per - 1) / per);

@@ -24,6 +24,7 @@
 // /root/reference).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <thread>
 #include <stdint.h>
@@ -54,7 +55,7 @@ void bnpc_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *bnpc_last_error(void) { return g_err; }
-extern "C" int bnpc_abi_version(void) { return 11; }
+extern "C" int bnpc_abi_version(void) { return 12; }
 
 #define HIPCHK(expr)                                                         \
     do {                                                                     \
@@ -72,6 +73,46 @@ extern "C" int bnpc_abi_version(void) { return 11; }
             bnpc_set_error("bad argument: %s", msg);                         \
             return 2;                                                        \
         }                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// per-launch device timers (bnpc_launch_timers: bench.py's
+// window.device_ms_per_step).  Off: a plain launch.  On: the launch carries a
+// start / stop event pair that takes the dispatch's own begin / end
+// timestamps (what rocprofv3's kernel trace reads), summed when the timers
+// are read.  One chain per process launches from one thread (the caller, or
+// rank 0 of a team job = the caller): no lock.
+// ---------------------------------------------------------------------------
+struct LaunchTimers {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    size_t used = 0;
+    hipEvent_t *next_pair()
+    {
+        if (used + 2 > ev.size()) {
+            const size_t old = ev.size();
+            ev.resize(old + 512, nullptr);
+            for (size_t i = old; i < ev.size(); i++)
+                if (hipEventCreate(&ev[i]) != hipSuccess) {
+                    ev.resize(i & ~(size_t)1);
+                    break;
+                }
+            if (used + 2 > ev.size()) return nullptr;
+        }
+        used += 2;
+        return &ev[used - 2];
+    }
+};
+static LaunchTimers g_timers;
+
+#define BNPC_LAUNCH(kern, grid, block, lds, stream, ...)                      \
+    do {                                                                      \
+        hipEvent_t *e_ = g_timers.on ? g_timers.next_pair() : nullptr;        \
+        if (e_)                                                               \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, e_[0],      \
+                                  e_[1], 0, __VA_ARGS__);                     \
+        else                                                                  \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);  \
     } while (0)
 
 // ---------------------------------------------------------------------------
@@ -2130,7 +2171,7 @@ static int build_view(bnpc_ctx *c, int view, const long long *d_cells,
     if (ensure(v.masks, ((size_t)v.nblk * c->Mpad + 8) * sizeof(ulonglong2)))
         return 1;
     dim3 grid((unsigned)v.nblk, (unsigned)((c->W + 3) / 4));
-    hipLaunchKernelGGL(k_gather_transpose, grid, dim3(256), 0, c->stream,
+    BNPC_LAUNCH(k_gather_transpose, grid, dim3(256), 0, c->stream,
                        c->rows, d_cells, (long long)n, c->W,
                        (ulonglong2 *)v.masks.p, c->Mpad);
     HIPCHK(hipGetLastError());
@@ -2572,7 +2613,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     const int64_t split1 = v.nblk * G * MSq;
     int planes = MS;
 #define LAUNCH_ASM(CB_, SPLIT_, GRID_)                                        \
-    hipLaunchKernelGGL((k_ll8_asm<CB_, SPLIT_>), dim3((unsigned)(GRID_)),     \
+    BNPC_LAUNCH((k_ll8_asm<CB_, SPLIT_>), dim3((unsigned)(GRID_)),     \
                        dim3(256), 0, c->stream,                              \
                        (const ulonglong2 *)v.masks.p, c->Mpad, c->Mt,        \
                        (long long)v.n, (long long)v.nblk,                    \
@@ -2604,7 +2645,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
             // x 31608 76 -> 78 at 1024 rows and 89 -> 81 at 2048+, x 1000
             // 93 -> 81, and 50000 x 5000 x 100 with its 1300 workgroups
             // 57 -> 48: tools/tile_shape_bench.py, profiles/r04)
-            hipLaunchKernelGGL((k_ll8_lds<2>), dim3((unsigned)wg2), dim3(256),
+            BNPC_LAUNCH((k_ll8_lds<2>), dim3((unsigned)wg2), dim3(256),
                                0, c->stream, (const ulonglong2 *)v.masks.p,
                                c->Mpad, c->Mt, (long long)v.n,
                                (long long)v.nblk, (const double *)c->tabs.p,
@@ -2633,7 +2674,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     else {
         snprintf(c->last_name, sizeof(c->last_name), "k_ll<%d>%s", KW,
                  MS > 1 ? " + k_ll_combine" : "");
-        hipLaunchKernelGGL(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
+        BNPC_LAUNCH(k_ll<KW>, dim3((unsigned)nwg), dim3(256), 0,
                            c->stream, (const ulonglong2 *)v.masks.p, c->Mpad,
                            c->Mt, (long long)v.n, (long long)v.nblk,
                            (const double *)c->tabs.p, (int)K, (long long)ldo,
@@ -2642,7 +2683,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     if (MS > 1 && planes > 1) {
         HIPCHK(hipGetLastError());
         const long long total = (long long)v.n * K;
-        hipLaunchKernelGGL(k_ll_combine, dim3((unsigned)((total + 255) / 256)),
+        BNPC_LAUNCH(k_ll_combine, dim3((unsigned)((total + 255) / 256)),
                            dim3(256), 0, c->stream, (const double *)c->part.p,
                            (long long)v.n, (int)K, planes, (long long)ldo,
                            d_out, sig);
@@ -2672,7 +2713,7 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     if (from_theta && G * KW * (int64_t)c->Mt
             <= TABLES_FLAT_MAX) {
         const int64_t threads = G * KW * (int64_t)c->Mt;
-        hipLaunchKernelGGL(k_tables_theta_flat<KW>,
+        BNPC_LAUNCH(k_tables_theta_flat<KW>,
                            dim3((unsigned)((threads + 255) / 256)), dim3(256),
                            0, c->stream,
                            c->use_rows ? (const float *)c->theta_store.p
@@ -2680,13 +2721,13 @@ static int launch_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                            c->use_rows, (int)K, (int)c->M, c->Mt, (int)G, FP,
                            FN, (double *)c->tabs.p);
     } else if (from_theta)
-        hipLaunchKernelGGL(k_tables_theta<KW>, tgrid_e, dim3(256), 0, c->stream,
+        BNPC_LAUNCH(k_tables_theta<KW>, tgrid_e, dim3(256), 0, c->stream,
                            c->use_rows ? (const float *)c->theta_store.p
                                        : c->theta_src,
                            c->use_rows, (int)K, (int)c->M, c->Mt, FP, FN,
                            (double *)c->tabs.p);
     else
-        hipLaunchKernelGGL(k_tables_relayout<KW>, tgrid, dim3(256), 0,
+        BNPC_LAUNCH(k_tables_relayout<KW>, tgrid, dim3(256), 0,
                            c->stream, c->tab_src,
                            c->tab_src + (size_t)K * c->M,
                            (int)K, (int)c->M, c->Mt, (double *)c->tabs.p);
@@ -2712,14 +2753,14 @@ static int issue_seqp(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         // staged in the pinned arena: every chain of the launch would pull
         // its table over the host link again - one copy kernel instead
         if (ensure(c->tab_in, 2 * n2 * sizeof(double))) return 1;
-        hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+        BNPC_LAUNCH(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
                            dim3(256), 0, c->stream, (const double2 *)tabs,
                            (double2 *)c->tab_in.p, (long long)n2);
         tabs = (const double *)c->tab_in.p;
     }
     dim3 grid((unsigned)v.nblk, (unsigned)K);
     snprintf(c->last_name, sizeof(c->last_name), "k_ll_seqp");
-    hipLaunchKernelGGL(k_ll_seqp, grid, dim3(256), SEQP_LDS, c->stream,
+    BNPC_LAUNCH(k_ll_seqp, grid, dim3(256), SEQP_LDS, c->stream,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.n, (long long)v.nblk, tabs,
                        tabs + (size_t)K * c->M, (int)K, (long long)ldo, d_out,
@@ -2940,12 +2981,12 @@ static int hint_launch(bnpc_ctx *c, const double *d_ll, int64_t n, int64_t K,
                        double *rows_dev, const long long *order)
 {
     if (K <= 64)
-        hipLaunchKernelGGL(k_row_top2, dim3((unsigned)((n + 255) / 256)),
+        BNPC_LAUNCH(k_row_top2, dim3((unsigned)((n + 255) / 256)),
                            dim3(256), 0, c->stream, d_ll, (long long)n,
                            (long long)ldo, (int)K, pr, (bnpc_top2 *)hint_dev,
                            rows_dev, order);
     else
-        hipLaunchKernelGGL(k_row_top4_wave, dim3((unsigned)((n + 3) / 4)),
+        BNPC_LAUNCH(k_row_top4_wave, dim3((unsigned)((n + 3) / 4)),
                            dim3(256), 0, c->stream, d_ll, (long long)n,
                            (long long)ldo, (int)K,
                            (const double *)c->hint_prior.p,
@@ -3050,7 +3091,7 @@ static int ll_top2_impl(bnpc_ctx *c, int view, const float *theta, int64_t K,
             HIPCHK(hipHostGetDevicePointer(&pp_dev, c->hint_prior_pin, 0));
             memcpy(c->hint_prior_pin, col_prior, pb);
             const long long n2 = (long long)(pb2 / 16);
-            hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+            BNPC_LAUNCH(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
                                dim3(256), 0, c->stream, (const double2 *)pp_dev,
                                (double2 *)c->hint_prior.p, n2);
             HIPCHK(hipGetLastError());
@@ -3185,7 +3226,7 @@ extern "C" int bnpc_hints_in_order_issue(bnpc_ctx *c, const int64_t *order,
     HIPCHK(hipHostGetDevicePointer(&op_dev, c->order_pin, 0));
     memcpy(c->order_pin, order, ob);
     const long long n2 = (long long)(ob2 / 16);
-    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+    BNPC_LAUNCH(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
                        dim3(256), 0, c->stream, (const double2 *)op_dev,
                        (double2 *)c->order_dev.p, n2);
     HIPCHK(hipGetLastError());
@@ -3358,7 +3399,7 @@ static int ll_rows_issue_impl(bnpc_ctx *c, int view, const int64_t *rows,
                               c->stream));
         void *hint_dev = nullptr;
         HIPCHK(hipHostGetDevicePointer(&hint_dev, c->tile_hint[slot], 0));
-        hipLaunchKernelGGL(k_row_top2_wide, dim3((unsigned)rows_n), dim3(256),
+        BNPC_LAUNCH(k_row_top2_wide, dim3((unsigned)rows_n), dim3(256),
                            0, c->stream, (const double *)c->tile_out[par].p,
                            (long long)ldo, (int)K,
                            (const double *)c->tile_prior_dev[par].p,
@@ -3486,7 +3527,7 @@ static int colcounts_device(bnpc_ctx *c, const int64_t *cells, int64_t n_cells,
     for (size_t off = 0; off < chunks.size(); off += maxy) {
         const size_t ny = std::min(maxy, chunks.size() - off);
         dim3 grid((unsigned)((c->M + 255) / 256), (unsigned)ny);
-        hipLaunchKernelGGL(k_colcounts, grid, dim3(256), 0, c->stream,
+        BNPC_LAUNCH(k_colcounts, grid, dim3(256), 0, c->stream,
                            c->rows, c->W, (int)c->M,
                            (const long long *)c->cells.p,
                            (const Chunk *)c->chunks.p + off, n1, n0);
@@ -3571,7 +3612,7 @@ static int counts_from_masks(bnpc_ctx *c, int view, LabelOf label_of,
     unsigned done_seq = 0;
     const DoneSignal sig = (zc_host && !defer) ? make_signal(c, 0, &done_seq)
                                                : DoneSignal{nullptr, nullptr, 0};
-    hipLaunchKernelGGL(k_counts_masks, grid, dim3(256), lds, c->stream,
+    BNPC_LAUNCH(k_counts_masks, grid, dim3(256), lds, c->stream,
                        (const ulonglong2 *)v.masks.p, c->Mpad, (int)c->M,
                        (long long)v.nblk, d_mem, (int)G, d1, d0, h1, h0, sig);
     HIPCHK(hipGetLastError());
@@ -3814,7 +3855,7 @@ static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
     k.tmax32 = (float)a->tmax;
     k.uniform_prior = a->uniform_prior;
     const long long GM = (long long)Gp * a->M;
-    hipLaunchKernelGGL(k_mh_screen, dim3((unsigned)((GM + 255) / 256)),
+    BNPC_LAUNCH(k_mh_screen, dim3((unsigned)((GM + 255) / 256)),
                        dim3(256), 0, c->stream, dev.theta + at, n1 + at,
                        n0 + at, dev.sd_idx + at, dev.U + at, dev.u + at, GM,
                        (int)a->M, sum_row, k, dev.flags + at,
@@ -4210,7 +4251,7 @@ extern "C" int bnpc_ll_total_issue(bnpc_ctx *c, const float *theta, int64_t K,
     }
     const int *n1 = (const int *)c->lab_cnt.p;
     const int *n0 = n1 + (size_t)K * c->M;
-    hipLaunchKernelGGL(k_ll_total, dim3(blocks), dim3(256), 0, c->stream,
+    BNPC_LAUNCH(k_ll_total, dim3(blocks), dim3(256), 0, c->stream,
                        d_theta, n1, n0, KM, E, fp[0], fn[0], fp[1], fn[1],
                        fp[2], fn[2], fp[3], fn[3], (double *)d_part,
                        in_place ? make_signal(c, 2, &c->total_seq)
@@ -4298,6 +4339,30 @@ extern "C" int bnpc_bench_ll_full(bnpc_ctx *c, int reps, float *ms_per_call)
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *ms_per_call = ms / reps;
+    return 0;
+}
+
+extern "C" int bnpc_launch_timers(bnpc_ctx *c, int on, double *device_ms,
+                                  int64_t *launches)
+{
+    ARGCHK(c, "NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (on) {
+        g_timers.used = 0;
+        g_timers.on = true;
+        return 0;
+    }
+    g_timers.on = false;
+    HIPCHK(hipDeviceSynchronize());
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < g_timers.used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, g_timers.ev[i], g_timers.ev[i + 1]));
+        sum += ms;
+    }
+    if (device_ms) *device_ms = sum;
+    if (launches) *launches = (int64_t)(g_timers.used / 2);
+    g_timers.used = 0;
     return 0;
 }
 

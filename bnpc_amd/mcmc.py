@@ -103,16 +103,16 @@ def _bind_worker_to_gpu(chain_index, n_devices=None, n_chains=1):
     environment does not pin every chain to one GPU.  BNPC_HOST_SHARE tells
     the worker how many chains end up on the CPUs of its NUMA node (each is
     bound to the node of its GPU): the default host thread team is a share of
-    that node (_lib.host_threads)."""
+    that node (_lib.host_threads), and whether the chain spins and wakes ranks
+    like a chain alone goes by the logical CPUs that leaves it
+    (_lib.host_settings)."""
     from bnpc_amd import _lib
     n_devices = n_devices or _visible_gpus()
     os.environ['BNPC_DEVICE'] = str(device_for_chain(chain_index, n_devices))
-    share = _lib.host_share(n_chains, n_devices)
-    os.environ['BNPC_HOST_SHARE'] = str(share)
-    if share > 1:
-        # idle ranks of a shared node give their CPU back quickly (8 chains x
-        # 4 ranks: 2990 steps/s spinning 50 us, 3170 spinning 5 us)
-        os.environ.setdefault('BNPC_HOST_SPIN_US', '5')
+    # (a chain left with fewer than _lib.GREEDY_MIN_CPUS logical CPUs gives
+    # idle ranks back quickly and wakes few: 8 chains x 4 ranks on one node's
+    # 16 CPUs each, round 3: 2990 steps/s spinning 50 us, 3170 spinning 5 us)
+    _lib.host_settings(n_chains, n_devices)
 
 
 # ------------------------------------------------------------------- traces
@@ -150,8 +150,8 @@ class TraceStore:
         d = self.data
         if with_params and 'params' in d:
             k_max = d['params'].shape[1]
-            d['params'] = np.append(d['params'],
-                np.zeros((extra, k_max, self.n_muts)), axis=0)
+            d['params'] = np.append(d['params'], np.zeros(
+                (extra, k_max, self.n_muts), dtype=d['params'].dtype), axis=0)
         for key in self.SCALARS:
             d[key] = np.append(d[key], np.zeros(extra))
         d['assignments'] = np.append(d['assignments'],

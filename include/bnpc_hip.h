@@ -331,6 +331,15 @@ int bnpc_bench_ll_full(bnpc_ctx *ctx, int reps, float *ms_per_call);
  * for how many clusters, in how many mutation chunks */
 int bnpc_last_launch(const bnpc_ctx *ctx, char *name, int len, int64_t *K,
                      int *mutation_chunks);
+/* Per-launch device timers.  on = 1: from now on every kernel this library
+ * launches (any context of the process) carries a start / stop event pair
+ * that takes the dispatch's own timestamps.  on = 0: timers off, the device
+ * synchronised, *device_ms = the sum of the kernel durations since they were
+ * switched on, *launches = their number (either may be NULL).  Measurement
+ * only (bench.py: window.device_ms_per_step, taken on steps AFTER the timed
+ * window - a pair of events costs the host ~2 us per launch). */
+int bnpc_launch_timers(bnpc_ctx *ctx, int on, double *device_ms,
+                       int64_t *launches);
 int bnpc_timer_start(bnpc_ctx *ctx);
 int bnpc_timer_stop(bnpc_ctx *ctx, float *ms);
 int bnpc_sync(bnpc_ctx *ctx);

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.load()
-    assert lib.bnpc_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.bnpc_abi_version() == _lib.ABI_VERSION == 12
     assert lib.bnpc_last_error() is not None
 
 

@@ -98,6 +98,55 @@ def test_bench_rank_harness_gloo_world2():
     assert got[0][1] == got[1][1]
 
 
+def _bench_cmd(args, env=None, timeout=180):
+    import subprocess
+    e = dict(os.environ)
+    for name in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE',
+            'MASTER_ADDR', 'MASTER_PORT', 'BNPC_HOST_SHARE',
+            'BNPC_HOST_SPIN_US'):
+        e.pop(name, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')]
+        + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_command_with_gpus_2():
+    """`bench.py --gpus N` as a COMMAND, no launcher around it,
+    runs N ranks (it starts them itself before any GPU call; --dry: the rank
+    harness alone, no chain, no device) and rank 0's line says so."""
+    import json
+    res = _bench_cmd(['--gpus', '2', '--steps', '5', '--dry'])
+    assert res.returncode == 0, res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['ranks'] == 2 and line['gpus_asked'] == 2
+    assert [d['rank'] for d in line['devices']] == [0, 1]
+    assert [d['local_rank'] for d in line['devices']] == [0, 1]
+    assert all(d['steps_s'] > 0 for d in line['devices'])
+    # exactly one line: the other rank prints nothing
+    assert len([ln for ln in res.stdout.splitlines() if ln.startswith('{')]) \
+        == 1
+    # one rank needs no launcher and no torch
+    res = _bench_cmd(['--gpus', '1', '--steps', '3', '--dry'])
+    assert res.returncode == 0, res.stderr
+    assert json.loads(res.stdout.strip().splitlines()[-1])['ranks'] == 1
+
+
+def test_bench_command_refuses_a_launcher_that_disagrees_with_gpus():
+    res = _bench_cmd(['--gpus', '2', '--dry'], env={'WORLD_SIZE': '3',
+        'RANK': '0', 'LOCAL_RANK': '0'})
+    assert res.returncode == 2
+    assert '--gpus 2 but WORLD_SIZE=3' in res.stderr and not res.stdout
+
+
+def test_bench_command_reports_a_rank_that_fails():
+    """A rank that dies takes the command down with its exit code instead of
+    leaving the others in a barrier."""
+    res = _bench_cmd(['--gpus', '2', '--steps', '2', '--dry',
+        '--dry-fail-rank', '1'], timeout=120)
+    assert res.returncode == 7
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+
+
 def test_lugsail_mode_extends_chains_until_psrf_cutoff(monkeypatch):
     """-ls: chains run max(10, 1/(c^2-1)) steps, then are extended by 200
     steps through the pool until the lugsail PSRF drops under the cutoff
@@ -359,20 +408,44 @@ def test_host_threads_are_divided_among_chains_sharing_a_gpu(monkeypatch):
     from bnpc_amd import mcmc
     monkeypatch.delenv('BNPC_HOST_THREADS', raising=False)
     monkeypatch.delenv('BNPC_HOST_SPIN_US', raising=False)
+    monkeypatch.delenv('BNPC_HOST_SHARE', raising=False)
     monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(128)))
+    monkeypatch.setattr(os, 'cpu_count', lambda: 256)
     monkeypatch.setattr(_lib, '_threads_memo', {})
     monkeypatch.setattr(_lib, 'numa_node_count', lambda: 2)
     # 8 GPUs on 2 nodes, 8 chains: 4 chains per node although 1 per GPU
     assert _lib.host_share(8, 8) == 4 and _lib.host_share(2, 8) == 1
     assert _lib.host_share(8, 1) == 8 and _lib.host_share(3, 8, nodes=1) == 3
+    # greedy or frugal goes by the logical CPUs a chain is left
+    # with on its node, not by "shares a node": the 8-GPU target (4 chains
+    # per 128-CPU node: 32 each) keeps the settings of a chain alone
+    got = _lib.host_settings(8, 8, apply=False)
+    assert got == {'share': 4, 'cpus_per_chain': 32, 'greedy': True,
+        'spin_us': 300}
+    assert _lib.host_settings(64, 8, apply=False)['greedy'] is False
+    assert _lib.host_settings(64, 8, apply=False)['cpus_per_chain'] == 4
+    assert 'BNPC_HOST_SHARE' not in os.environ
     for chain in range(8):
         mcmc._bind_worker_to_gpu(chain, n_devices=2, n_chains=8)
         assert os.environ['BNPC_HOST_SHARE'] == '4'
-        assert os.environ['BNPC_HOST_SPIN_US'] == '5'
+        assert 'BNPC_HOST_SPIN_US' not in os.environ
         assert os.environ['BNPC_DEVICE'] == str(chain % 2)
         assert _lib.host_threads() == 8
         assert _lib.threads_for(10 ** 6) == 8
+    # a small host: 8 chains on the 8 CPUs of one node give ranks back at once
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(8)))
+    monkeypatch.setattr(os, 'cpu_count', lambda: 8)
+    monkeypatch.setattr(_lib, 'numa_node_count', lambda: 1)
+    monkeypatch.setattr(_lib, '_threads_memo', {})
+    mcmc._bind_worker_to_gpu(3, n_devices=2, n_chains=8)
+    assert os.environ['BNPC_HOST_SHARE'] == '8'
+    assert os.environ['BNPC_HOST_SPIN_US'] == '5'
+    assert _lib.host_threads() == 1
     monkeypatch.delenv('BNPC_HOST_SPIN_US')
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(128)))
+    monkeypatch.setattr(os, 'cpu_count', lambda: 256)
+    monkeypatch.setattr(_lib, 'numa_node_count', lambda: 2)
+    monkeypatch.setattr(_lib, '_threads_memo', {})
     mcmc._bind_worker_to_gpu(0, n_devices=8, n_chains=2)
     assert os.environ['BNPC_HOST_SHARE'] == '1'
     assert 'BNPC_HOST_SPIN_US' not in os.environ
