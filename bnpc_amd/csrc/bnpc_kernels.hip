@@ -149,6 +149,14 @@ struct Tunables {
                                     // of split launches (tools/msplit_sweep.py)
     int screen_theta = 1;           // BNPC_MH_SCREEN = 2: verdicts only - not the
                                     // float32 bits of the proposals it accepts
+    size_t mh_pin_max = (size_t)512 << 20;  // pinned block of a screened
+                                    // parameter batch at most: twice
+                                    // BNPC_SWEEP_BYTES, the host budget of a
+                                    // sweep's matrix (default 256 MiB -> 512:
+                                    // 37 bytes per entry, 14.5 M entries -
+                                    // config 4's K0 x M batch fits, config 5's
+                                    // 158 M are screened in slices of rows
+                                    // that reuse the block)
 };
 
 #define MSPLIT_MAX 64               // chunks of a split launch at most
@@ -160,6 +168,9 @@ struct Tunables {
 #define MH_SCREEN_MIN 512           // batch entries from which the screen pays
 #define MH_THREADED_MIN 65536       // batch entries from which rank 0 issues
                                     // draws and launches ahead of the waits
+                                    // (the pinned block of a screened batch
+                                    // is at most Tunables::mh_pin_max bytes)
+#define MH_PIN_NO_MEMORY 77         // mh_pin_get: the host refused the block
 #define HINT_COLS_MAX 32767         // columns of a hinted sweep (int16 in the
                                     // record)
 #define HINT_THROUGH_MAX 1024       // ... up to which rows that will be scanned
@@ -185,6 +196,11 @@ static void read_tunables(Tunables &t)
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
     t.done_words = env_int("BNPC_DONE_WORDS", 1);
     t.screen_theta = t.mh_screen != 2;
+    {
+        const char *e = getenv("BNPC_SWEEP_BYTES");
+        const long long b = e ? atoll(e) : 0;
+        t.mh_pin_max = 2 * (size_t)(b > 0 ? b : (long long)256 << 20);
+    }
     t.msplit_chunks = t.msplit >= 2 ? t.msplit : 0;
 }
 
@@ -2112,7 +2128,13 @@ __global__ __launch_bounds__(256) void k_mh_screen(
                     // those below theta ~ 1e-4, where the spacing itself is
                     // 1e-12) stays with the host's arithmetic.  Flag 3: the
                     // host takes nw and evaluates its prior density only.
-                    if (flag == 2 && new_out) {
+                    // (only within four deviations of the old
+                    // value - the host evaluates the LEFT form, log_ndtr +
+                    // ndtri_exp, even where Phi is close to 1, and the 5e-17
+                    // its cancellation leaves in Phi is 5e-17 / pdf(x) in x:
+                    // beyond the guard from six deviations on.  Six in a
+                    // hundred thousand proposals lie further out than four.)
+                    if (flag == 2 && new_out && fabs(x) <= 4.0) {
                         const double up = (double)nextafterf(nw, INFINITY);
                         const double dn = (double)nextafterf(nw, -INFINITY);
                         const double sp = fmax(up - (double)nw, (double)nw - dn);
@@ -3218,18 +3240,33 @@ extern "C" int bnpc_hints_in_order_issue(bnpc_ctx *c, const int64_t *order,
     }
     const size_t ob = (size_t)n * sizeof(long long);
     const size_t ob2 = (ob + 15) & ~(size_t)15;
-    if (!c->order_pin)
-        HIPCHK(hipHostMalloc(&c->order_pin, ((size_t)c->N + 2) * 8,
-                             hipHostMallocDefault));
-    if (ensure(c->order_dev, ob2)) return 1;
+    // (the caller has drawn its permutation from the stream by now: a host
+    // that gives no mapped pinned memory must not fail the sweep here - the
+    // order then travels by a plain copy from the caller's array)
+    if (!c->order_pin
+        && hipHostMalloc(&c->order_pin, ((size_t)c->N + 2) * 8,
+                         hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->order_pin = nullptr;
+    }
     void *op_dev = nullptr;
-    HIPCHK(hipHostGetDevicePointer(&op_dev, c->order_pin, 0));
-    memcpy(c->order_pin, order, ob);
-    const long long n2 = (long long)(ob2 / 16);
-    BNPC_LAUNCH(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
-                       dim3(256), 0, c->stream, (const double2 *)op_dev,
-                       (double2 *)c->order_dev.p, n2);
-    HIPCHK(hipGetLastError());
+    if (c->order_pin
+        && hipHostGetDevicePointer(&op_dev, c->order_pin, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        op_dev = nullptr;
+    }
+    if (ensure(c->order_dev, ob2)) return 1;
+    if (op_dev) {
+        memcpy(c->order_pin, order, ob);
+        const long long n2 = (long long)(ob2 / 16);
+        BNPC_LAUNCH(k_stage_copy, dim3((unsigned)((n2 + 255) / 256)),
+                    dim3(256), 0, c->stream, (const double2 *)op_dev,
+                    (double2 *)c->order_dev.p, n2);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(c->order_dev.p, order, ob,
+                              hipMemcpyHostToDevice, c->stream));
+    }
     if (int rh = hint_launch(c, (const double *)c->out.p, n, c->hint_later.K,
                              c->hint_later.ldo, c->hint_later.prior,
                              c->hint_later.hint_dev, c->hint_later.rows_dev,
@@ -3794,8 +3831,20 @@ static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
         c->mh_pin = nullptr;
         c->mh_dev = nullptr;
         c->mh_cap = 0;
-        const size_t cap = need + need / 4 + 4096;
-        HIPCHK(hipHostMalloc(&c->mh_pin, cap, hipHostMallocDefault));
+        // (no head room for the largest blocks: a slice of a batch beyond the
+        // budget never grows)
+        const size_t cap = need + (need < c->tun.mh_pin_max ? need / 4 : 0) + 4096;
+        const hipError_t e = hipHostMalloc(&c->mh_pin, cap,
+                                           hipHostMallocDefault);
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+            // the caller evaluates the batch without the screen
+            (void)hipGetLastError();
+            c->mh_pin = nullptr;
+            bnpc_set_error("no pinned memory for the screen of a parameter "
+                           "batch (%zu bytes)", cap);
+            return MH_PIN_NO_MEMORY;
+        }
+        HIPCHK(e);
         void *d = nullptr;
         HIPCHK(hipHostGetDevicePointer(&d, c->mh_pin, 0));
         c->mh_dev = (char *)d;
@@ -3815,14 +3864,19 @@ static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
 // the last bnpc_colcounts_by_label (G rows), src 1 = the two segments of the
 // last bnpc_view_counts (rows 0, 1; a third row of the batch is their sum)
 static int mh_counts(bnpc_ctx *c, int src, int64_t G, const int **n1,
-                     const int **n0, int *sum_row)
+                     const int **n0, int *sum_row, int64_t row0 = 0,
+                     int64_t G_all = -1)
 {
     *sum_row = -1;
     if (src == 0) {
-        ARGCHK(c->lab_cnt.p && c->lab_K == G,
+        // (a slice of a batch beyond the pinned budget: rows row0 ... of the
+        // G_all resident ones)
+        if (G_all < 0) G_all = G;
+        ARGCHK(c->lab_cnt.p && c->lab_K == G_all && row0 >= 0
+               && row0 + G <= G_all,
                "the batch does not match the resident per-cluster counts");
-        *n1 = (const int *)c->lab_cnt.p;
-        *n0 = *n1 + (size_t)G * c->M;
+        *n1 = (const int *)c->lab_cnt.p + (size_t)row0 * c->M;
+        *n0 = *n1 + (size_t)G_all * c->M;
     } else {
         ARGCHK(c->cnt.p && c->cnt_rows == 2 && (G == 2 || G == 3),
                "the batch does not match the last view counts");
@@ -3836,11 +3890,13 @@ static int mh_counts(bnpc_ctx *c, int src, int64_t G, const int **n1,
 // rows [g0, g0 + Gp) of the batch
 static int mh_screen_launch(bnpc_ctx *c, int src, const bnpc_mh_args *a,
                             const MHPin &dev, int64_t g0 = 0, int64_t Gp = -1,
-                            DoneSignal sig = {nullptr, nullptr, 0})
+                            DoneSignal sig = {nullptr, nullptr, 0},
+                            int64_t row0 = 0, int64_t G_all = -1)
 {
     const int *n1, *n0;
     int sum_row;
-    if (int rc = mh_counts(c, src, a->G, &n1, &n0, &sum_row)) return rc;
+    if (int rc = mh_counts(c, src, a->G, &n1, &n0, &sum_row, row0, G_all))
+        return rc;
     if (Gp < 0) Gp = a->G;
     const size_t at = (size_t)g0 * a->M;
     ARGCHK(sum_row < 0 || (g0 == 0 && Gp == a->G),
@@ -3907,9 +3963,24 @@ static bool mh_screen_applies(const bnpc_ctx *c, const bnpc_mh_args *a)
              || a->G * a->M < MH_SCREEN_MIN);
 }
 
+// The counts a fused launch is still writing behind the stream, taken now
+// (a batch that will not wait for its first screen before the host reads them)
+static int mh_take_pending(bnpc_ctx *c, const bnpc_mh_args *a,
+                           const int **pending)
+{
+    if (!*pending) return 0;
+    const size_t E = (size_t)a->G * a->M;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy((void *)a->n1, *pending, E * sizeof(int32_t));
+    memcpy((void *)a->n0, *pending + E, E * sizeof(int32_t));
+    *pending = nullptr;
+    return 0;
+}
+
 static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
                              bnpc_mt19937 *rng, const bnpc_mh_args *a,
-                             int counts_src, int *status, const int *pending)
+                             int counts_src, int *status, const int *pending,
+                             int64_t row0 = 0, int64_t G_all = -1)
 {
     ARGCHK(c && a && status, "NULL argument");
     if (!mh_screen_applies(c, a)) {
@@ -3918,6 +3989,55 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     }
     if (int rc = mh_screen_argchk(c, a)) return rc;
     HIPCHK(hipSetDevice(c->device));
+    {
+        // The pinned block has a budget (a first step that is a
+        // move at config 5 brings a batch of K0 x M = 158 M entries - 5.7 GB
+        // pinned per chain without one).  A larger batch is screened in
+        // slices of whole rows that reuse the block: the draws are taken row
+        // by row in the reference's order either way, and nothing of a row
+        // depends on another.
+        size_t off[6];
+        const size_t per_row = mh_pin_offsets((size_t)a->M, off);
+        const int64_t rows_max = std::max<int64_t>(
+            1, (int64_t)(c->tun.mh_pin_max / per_row));
+        if (a->G > rows_max && counts_src == 0 && row0 == 0 && G_all < 0) {
+            if (int rc = mh_take_pending(c, a, &pending)) return rc;
+            *status = 0;
+            for (int64_t g0 = 0; g0 < a->G; g0 += rows_max) {
+                const int64_t Gs = std::min<int64_t>(rows_max, a->G - g0);
+                const size_t at = (size_t)g0 * a->M;
+                bnpc_mh_args b = *a;
+                b.G = Gs;
+                b.old_theta += at;
+                b.n1 += at;
+                b.n0 += at;
+                if (b.known_theta) {
+                    b.known_theta += at;
+                    b.known_prior += at;
+                }
+                b.sd_idx += at;
+                b.U += at;
+                b.u += at;
+                b.new_theta += at;
+                if (b.prior_out) b.prior_out += at;
+                b.A += at;
+                b.log_prob += g0;
+                b.declined += g0;
+                int st = 0;
+                if (int rc = mh_batch_dev_impl(c, k, rng, &b, 0, &st, nullptr,
+                                               g0, a->G))
+                    return rc;
+                // (an element left to SciPy: the caller puts the stream back
+                // and walks the whole batch by the binding - no point in
+                // going on)
+                if (st) {
+                    *status = 1;
+                    return 0;
+                }
+            }
+            return 0;
+        }
+    }
     static const bool trace = [] {      // BNPC_TIMING=mh
         const char *e = getenv("BNPC_TIMING");
         return e && strstr(e, "mh");
@@ -3927,7 +4047,13 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     const int64_t G = a->G, M = a->M;
     const size_t E = (size_t)G * M;
     MHPin h, d;
-    if (mh_pin_get(c, E, h, d)) return 1;
+    if (const int prc = mh_pin_get(c, E, h, d)) {
+        if (prc != MH_PIN_NO_MEMORY) return 1;
+        // no pinned block: the batch without its screen (the exact arithmetic
+        // of every entry on the team) instead of a failed step
+        if (int rc = mh_take_pending(c, a, &pending)) return rc;
+        return bnpc_mh_batch(k, rng, a, status);
+    }
     // Parts in a pipeline (batches of 4 rows and more): the draws of part
     // p + 1 are taken while the device screens part p, and the host evaluates
     // what a screen left while the next one runs.  Two halves for the batches
@@ -3979,7 +4105,8 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         memcpy(h.theta + at, a->old_theta + at, n * 4);
         // (one word for all parts: the launches of a stream finish in order)
         const DoneSignal sig = make_signal(c, threaded ? 0 : p, &done_seq[p]);
-        if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp, sig))
+        if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp, sig, row0,
+                                      G_all))
             return rc;
         if (!done_seq[p]) HIPCHK(hipEventRecord(c->mh_ev[p & 1], c->stream));
         return 0;

@@ -233,8 +233,17 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     // (births write their rows into `parameters` M floats apart)
     // (any number of clusters whose whole matrix fits the host budget: the
     // hint record holds its columns as 16-bit numbers)
+    // spare columns for the clusters opened during the sweep (running out
+    // means a copy of the whole matrix into a wider one): a few for a
+    // converged chain, an eighth of the columns when there are hundreds or
+    // thousands (a first sweep opens about as many clusters as the data hold)
+    const int64_t spare = K <= 64
+        ? std::max<int64_t>(4, std::min<int64_t>(16, K / 4))
+        : std::min<int64_t>(512, std::max<int64_t>(16, K / 8));
+    // (the budget is tested on the matrix as it is allocated, spare columns
+    // included - the same expression as CRP.update_assignments_Gibbs)
     if (K < 1 || K + 512 > 32767 || !ch->sweep_hint || ch->param_stride != M
-        || ch->sweep_bytes / (8 * (K + 16)) < N)
+        || ch->sweep_bytes / (8 * (K + spare)) < N)
         return 0;
     const double FP = ch->FP, FN = ch->FN;
     // get_lpost_single_new_cluster (libs/CRP.py:230-234): an m-sequential
@@ -259,13 +268,6 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     const double prior_new = ch->crp_prior[N + 1];
     for (int64_t i = 0; i < N; i++) w.post_new[i] = w.newcl[i] + prior_new;
 
-    // spare columns for the clusters opened during the sweep (running out
-    // means a copy of the whole matrix into a wider one): a few for a
-    // converged chain, an eighth of the columns when there are hundreds or
-    // thousands (a first sweep opens about as many clusters as the data hold)
-    const int64_t spare = K <= 64
-        ? std::max<int64_t>(4, std::min<int64_t>(16, K / 4))
-        : std::min<int64_t>(512, std::max<int64_t>(16, K / 8));
     int64_t ld = K + spare;
     w.col_prior.resize((size_t)K);
     for (int64_t g = 0; g < K; g++) {
@@ -637,6 +639,25 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     }
     ch->par_declined = declined;
     ch->par_accepted = (int64_t)E - declined;
+    // the batch of a first step (K0 rows: 50 bytes of scratch per entry, 8 GB
+    // at config 5) must not stay allocated for the chain's lifetime
+    if (w.U.capacity() > 4 * E && w.U.capacity() > ((size_t)1 << 22)) {
+        auto trim = [E](auto &v) {
+            v.resize(std::min(v.size(), E));
+            v.shrink_to_fit();
+        };
+        trim(w.n1);
+        trim(w.n0);
+        trim(w.fresh);
+        trim(w.sd_idx);
+        trim(w.U);
+        trim(w.u);
+        trim(w.A);
+        trim(w.prior_out);
+        trim(w.kt);
+        trim(w.kp);
+        trim(w.dens);
+    }
     if (trace_p) {
         auto us = [](Clock::time_point a, Clock::time_point b) {
             return std::chrono::duration_cast<std::chrono::nanoseconds>(

@@ -834,6 +834,10 @@ class CRP:
         proceeds.  Same decisions, same draws, same trajectory either way.
         """
         N = self.cells_total
+        # (checker hook: a sweep that ends after its first `_sweep_stop`
+        # cells - the state the CPU oracle reaches walking that many cells of
+        # config 5's first sweep, tests/golden/make_c5_first_cells.py)
+        stop = min(N, getattr(self, '_sweep_stop', None) or N)
         timing = _lib.env('BNPC_TIMING') in ('1', '2')
         if timing:
             import time
@@ -846,12 +850,14 @@ class CRP:
 
         budget = int(_lib.env('BNPC_SWEEP_BYTES', 256 << 20))
         ctx = self._dev()
-        if budget // (8 * (ids.size + 16)) >= N:
+        # a few spare columns for clusters opened during the sweep (the
+        # matrix is re-allocated with more if they run out); the budget is
+        # tested on the matrix as allocated (bnpc_step.cpp: gibbs_phase has
+        # the same expression)
+        spare = max(4, min(16, ids.size // 4)) if ids.size <= 64 \
+            else min(512, max(16, ids.size // 8))
+        if budget // (8 * (ids.size + spare)) >= N:
             # the whole matrix in one launch, rows = cell ids
-            # a few spare columns for clusters opened during the sweep (the
-            # matrix is re-allocated with more if they run out)
-            spare = max(4, min(16, ids.size // 4)) if ids.size <= 64 \
-                else min(512, max(16, ids.size // 8))
             # the device also reports, per cell, the four largest entries
             # under the priors at launch with the columns of three: the
             # native loop then decides most cells without scanning them
@@ -884,7 +890,7 @@ class CRP:
                 perm, assignment = self._sweep_order(N)
                 ll = ctx.ll_theta_pinned(VIEW_ALL, self.parameters[ids],
                     self.FP, self.FN, ids.size + spare)
-            ids, sizes, born = self._gibbs_window(perm, 0, N, VIEW_ALL, ll,
+            ids, sizes, born = self._gibbs_window(perm, 0, stop, VIEW_ALL, ll,
                 ids, ids, sizes, (), assignment, post_new, crp_prior,
                 hint=hint)
             opened, tiles = len(born), 1
@@ -921,7 +927,7 @@ class CRP:
                 if rows >= 512:
                     rows -= rows % 512
                 slot = number % _lib.TILE_SLOTS
-                tile = dict(pos=start, end=min(N, start + rows), slot=slot,
+                tile = dict(pos=start, end=min(stop, start + rows), slot=slot,
                     number=number, view=VIEW_SWEEP + slot, cols=ids.copy(),
                     ld=ids.size + _TILE_SPARE, born_mark=len(born_log))
                 if timing:
@@ -950,7 +956,7 @@ class CRP:
             spent = {'issue': 0.0, 'wait': 0.0}
 
             def fill():
-                while len(in_flight) < ahead_max and upcoming[0] < N:
+                while len(in_flight) < ahead_max and upcoming[0] < stop:
                     if timing:
                         t_0 = time.perf_counter()
                     tile = issue(upcoming[0], upcoming[1])

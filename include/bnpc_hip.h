@@ -817,10 +817,10 @@ int bnpc_np_sum(const double *a, int64_t n, double *out);
  * The model's state lives in the CALLER's arrays, updated in place:
  * assignment, parameters, the live clusters (ids / sizes, in the insertion
  * order of the reference's cells_per_cluster dict; capacity N), CRP_prior,
- * DP_a, FP, FN.  A phase the call does not make itself - a Gibbs sweep over
- * more than 64 clusters or one that does not fit `sweep_bytes` (first steps),
- * a parameter batch of more than 64 clusters, a move / batch / scalar the
- * kernel table leaves to SciPy - ends the call BEFORE that phase, with the
+ * DP_a, FP, FN.  A phase the call does not make itself - a Gibbs sweep whose
+ * matrix (N x (K + spare columns) doubles) does not fit `sweep_bytes` or has
+ * more than 32 767 columns (first steps: tiled by the binding), a move / batch
+ * / scalar the kernel table leaves to SciPy - ends the call BEFORE that phase, with the
  * stream where the reference would have it at that point: `need` names the
  * phase, the binding runs it through its own methods and calls again with
  * `phase` = the next one.  need == 0: the step is complete and recorded.

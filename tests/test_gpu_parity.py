@@ -556,14 +556,17 @@ def test_config2_chain_matches_oracle():
     np.testing.assert_allclose(rp['ML'], ro['ML'], rtol=1e-9)
 
 
-@pytest.mark.parametrize('cfg', ['c3', 'c4'])
+@pytest.mark.parametrize('cfg', ['c3', 'c4', 'c3k'])
 def test_full_size_trajectory_matches_oracle_fixture(cfg, golden_dir):
     """BASELINE configs 3 and 4 at FULL size (5000 x 1000 and 10000 x 2000,
     20 % missing, learned errors, CLI-default moves), 9 steps including the
     first sweep from K0 = 3152 / 6325 clusters (config 4: after four
     split/merge attempts at K0, each with a K0 x M proposal batch): the device
     chain walks the trajectory the CPU oracle produced
-    (tests/golden/make_c3_trajectory.py; 3 and 24 CPU-minutes)."""
+    (tests/golden/make_c3_trajectory.py; 3 and 24 CPU-minutes).  `c3k`
+    (more than 64 clusters at bench size under the driver's
+    eyes): config 3's shape with 200 true clusters - the chain runs at K ~ 200
+    from its second step on."""
     import bench
     import libs.CRP_learning_errors as dev
     from bnpc_amd.mcmc import MCMC
@@ -580,6 +583,40 @@ def test_full_size_trajectory_matches_oracle_fixture(cfg, golden_dir):
     assert np.array_equal(res['assignments'], t['assignments'])
     for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
         np.testing.assert_allclose(res[key], t[key], rtol=1e-9, err_msg=key)
+
+
+def test_k150_chain_matches_oracle_fixture(golden_dir):
+    """a chain with MORE THAN 64 CLUSTERS against the
+    oracle in the driver-run suite - bench.py's `k150` workload (2000 x 500,
+    150 true clusters), 20 steps from the initial state (K0 = 1268) stepped
+    as bench.py steps its chain; the oracle's walk is the fixture
+    (tests/golden/make_k150_trajectory.py).  Identical assignments after
+    every step, traces to 1e-9, every step ONE native call, and from the
+    second sweep on nearly every cell decided from its device record."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_k150',
+        os.path.join(golden_dir, 'make_k150_trajectory.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    import libs.CRP as dev_fixed
+    import libs.CRP_learning_errors as dev_learn
+    t = np.load(os.path.join(golden_dir, 'k150_trajectory.npz'))
+    model, res = mk.walk(dev_fixed, dev_learn)
+    assert np.array_equal(res['assignments'], t['assignments'])
+    for key in ('ML', 'MAP', 'DP_alpha', 'FN', 'FP'):
+        np.testing.assert_allclose(res[key], t[key], rtol=1e-9, err_msg=key)
+    K = [len(np.unique(a)) for a in res['assignments']]
+    assert K[0] > 1000 and min(K[1:]) > 64, K
+    stats = model.host_stats()
+    assert stats['native_steps'] == mk.STEPS, stats
+    # the first sweep (K0 random clusters: 2000 of the cells swept) scans many
+    # of its cells; of all the others more than 95 % come from their records
+    N = res['assignments'].shape[1]
+    assert stats['swept'] >= 5 * N, stats
+    later = stats['swept'] - N
+    assert stats['hint_used'] - N <= later
+    assert stats['hint_used'] > 0.95 * later, stats
+    model.close()
 
 
 # ------------------------------------------ full BASELINE size, properties
@@ -838,6 +875,29 @@ def test_first_sweep_at_config5_size_does_not_depend_on_the_tiling(
     assert int(first['seed']) == 42 and int(first['K0']) == K0
     assert first['cells'].size >= 64 and first['born'].sum() >= 8
     assert np.array_equal(a[0][first['cells']], first['drawn'])
+    # ... and the rest of that fixture: the device sweep STOPPED
+    # after those cells stands where the oracle stood - as many clusters, as
+    # many of them opened by these cells, the same next uniform on the stream
+    n_first = int(first['cells'].size)
+    monkeypatch.delenv('BNPC_TILE_BYTES', raising=False)
+    monkeypatch.delenv('BNPC_SWEEP_BYTES', raising=False)
+    np.random.seed(42)
+    m = bench.make_model(dev, dev, data, learned)
+    m.init()
+    m._sweep_stop = n_first
+    m.update_assignments_Gibbs()
+    peek = np.random.random()
+    assert np.array_equal(m.assignment[first['cells']], first['drawn'])
+    assert len(m.cells_per_cluster) == int(first['K_after'][-1])
+    assert sum(m.cells_per_cluster.values()) == N
+    untouched = np.setdiff1d(np.arange(N), first['cells'])
+    np.random.seed(42)
+    m0 = bench.make_model(dev, dev, data, learned)
+    m0.init()
+    assert np.array_equal(m.assignment[untouched], m0.assignment[untouched])
+    m0.close()
+    assert peek == float(first['peek'])
+    m.close()
 
 
 def test_pinned_result_buffer():
