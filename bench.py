@@ -715,6 +715,11 @@ def main():
             # moves made as one native call (bnpc_sm_move)
             'native_steps': stats['native_steps'],
             'native_moves': stats['native_moves'],
+            # parameter batches whose draws a walker on the aside thread took
+            # ahead on a copy of the stream: started / adopted by the batch
+            # (the live stream stood where the walker's did) / rows adopted
+            'mh_ahead': [stats.get('ahead_begun', 0),
+                stats.get('ahead_taken', 0), stats.get('ahead_rows', 0)],
             # parameter-batch entries screened on the device / share of them
             # the host still had to evaluate (accepted or in doubt)
             'mh_screened': seen,

@@ -229,6 +229,8 @@ SIGNATURES = {
     'bnpc_bench_ll_full': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
     'bnpc_launch_timers': (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_double),
         C.POINTER(C.c_int64)]),
+    'bnpc_mh_ahead_stats': (C.c_int, [_ctx, C.POINTER(C.c_int64),
+        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'bnpc_last_launch': (C.c_int, [_ctx, C.c_char_p, C.c_int,
         C.POINTER(_i64), C.POINTER(C.c_int)]),
     'bnpc_timer_start': (C.c_int, [_ctx]),
@@ -1767,6 +1769,15 @@ class Context:
         check(self._lib.bnpc_bench_ll_full(self._h, reps, C.byref(ms)),
             'bench_ll_full')
         return ms.value
+
+    def mh_ahead_stats(self):
+        """(walkers started, adopted by a batch, rows of draws adopted): the
+        parameter batches whose draws were taken ahead on a copy of the
+        stream (bnpc_mh_ahead_stats)."""
+        b, t, r = _i64(0), _i64(0), _i64(0)
+        check(self._lib.bnpc_mh_ahead_stats(self._h, C.byref(b), C.byref(t),
+            C.byref(r)), 'mh_ahead_stats')
+        return b.value, t.value, r.value
 
     def launch_timers(self, on):
         """Per-launch device timers (bnpc_launch_timers).  on=True: start;

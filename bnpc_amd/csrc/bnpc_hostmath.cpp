@@ -241,7 +241,122 @@ Team *team_for(int threads)
     return t;
 }
 
+// ---------------------------------------------------------------------------
+// the aside: ONE more persistent thread per process, for a job that runs NEXT
+// TO the calling thread instead of with it (bnpc_aside_start / _wait,
+// bnpc_internal.h): the draws of the next parameter batch taken ahead on a
+// copy of the stream while the caller waits for the sweep's kernel and walks
+// its loop.  Parks on a futex word after the team's spin; rebuilt after
+// fork() like the team.
+// ---------------------------------------------------------------------------
+class Aside {
+public:
+    Aside() : pid_(getpid())
+    {
+        const char *e = getenv("BNPC_HOST_SPIN_US");
+        spin_ns_ = (e ? atol(e) : 300) * 1000L;
+    }
+    pid_t pid() const { return pid_; }
+
+    // post fn (copied); false: no thread to be had - nothing was posted.
+    // One job at a time: the caller has waited for the previous one.
+    bool start(const std::function<void()> &fn)
+    {
+        wait();
+        if (!started_) {
+            try {
+                thread_ = std::thread([this] { loop(); });
+            } catch (const std::system_error &) {
+                return false;
+            }
+            started_ = true;
+        }
+        job_ = fn;
+        running_.store(1, std::memory_order_release);
+        word_.fetch_add(1, std::memory_order_seq_cst);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        if (sleeping_.load(std::memory_order_seq_cst) > 0)
+            syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAKE_PRIVATE, 1,
+                    nullptr, nullptr, 0);
+        return true;
+    }
+
+    void wait()
+    {
+        for (int spins = 0; running_.load(std::memory_order_acquire);
+             spins++) {
+            if (spins < 2048) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            } else {
+                std::this_thread::yield();
+            }
+        }
+    }
+
+private:
+    static long now_ns()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1000000000L + ts.tv_nsec;
+    }
+    void loop()
+    {
+        uint32_t seen = 0;
+        for (;;) {
+            uint32_t w;
+            const long t0 = now_ns();
+            int polls = 0;
+            while ((w = word_.load(std::memory_order_acquire)) == seen) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if ((++polls & 63) == 0 && now_ns() - t0 > spin_ns_) {
+                    sleeping_.fetch_add(1, std::memory_order_seq_cst);
+                    syscall(SYS_futex, (uint32_t *)&word_, FUTEX_WAIT_PRIVATE,
+                            seen, nullptr, nullptr, 0);
+                    sleeping_.fetch_sub(1, std::memory_order_acq_rel);
+                }
+            }
+            seen = w;
+            job_();
+            running_.store(0, std::memory_order_release);
+        }
+    }
+
+    pid_t pid_;
+    long spin_ns_ = 300000;
+    bool started_ = false;
+    std::thread thread_;
+    std::function<void()> job_;
+    std::atomic<uint32_t> word_{0};
+    std::atomic<int> running_{0}, sleeping_{0};
+};
+
+Aside *g_aside = nullptr;
+
+// (the calling thread of a chain only: no lock - and a forked child starts
+// its own, the parent's object is abandoned like its team)
+Aside *aside()
+{
+    if (g_aside && g_aside->pid() != getpid()) g_aside = nullptr;
+    if (!g_aside) g_aside = new Aside();
+    return g_aside;
+}
+
 }  // namespace
+
+bool bnpc_aside_start(const std::function<void()> &fn)
+{
+    return aside()->start(fn);
+}
+
+void bnpc_aside_wait()
+{
+    if (g_aside && g_aside->pid() == getpid()) g_aside->wait();
+}
 
 // ranks a team of `threads` will really have: the team is capped at 255 and
 // keeps what it has when the system refuses a thread (the team is grown here)

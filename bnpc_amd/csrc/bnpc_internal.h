@@ -18,6 +18,12 @@ void bnpc_set_error(const char *fmt, ...);
 // concurrent callers take turns (the team's job lock).
 int bnpc_team_ranks(int threads);
 int bnpc_team_run(int threads, const std::function<void(int)> &fn);
+// fn() on the process's one aside thread, NEXT TO the caller (it returns at
+// once; false: no thread to be had, nothing runs); bnpc_aside_wait returns
+// when that job is over.  One job at a time, posted and awaited by the thread
+// that drives the chain.
+bool bnpc_aside_start(const std::function<void()> &fn);
+void bnpc_aside_wait();
 #endif
 
 // bnpc_kernels.hip: the {ones, zeros} 64-bit words of one cell's row
@@ -52,6 +58,27 @@ double bnpc_legacy_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
 // and the screen launch of a later part of a large batch under the team's
 // work on this one); NULL: nothing.  Consumed by that call.
 void bnpc_mh_rank0_hook(const std::function<void()> *hook);
+#ifdef __cplusplus
+// bnpc_kernels.hip: the draws of the NEXT screened parameter batch on this
+// context taken ahead (MhAhead there): a walker on the aside thread takes a
+// copy of (rng, g), runs `prelude` on it - the draws the stream goes through
+// before the batch begins; false: it cannot tell - and then draws `rows` rows
+// of M into the batch's pinned block.  The batch adopts them iff the live
+// stream stands exactly where the walker's stood after the prelude.  *posted:
+// whether a walker was started (not for small batches, without the screen,
+// BNPC_MH_AHEAD=0 ...).  bnpc_mh_ahead_drop ends one that will not be used.
+int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
+                        const bnpc_legacy_gauss *g,
+                        const std::function<bool(bnpc_mt19937 *,
+                                                 bnpc_legacy_gauss *)> &prelude,
+                        int64_t rows, int64_t M, int64_t n_sd, bool *posted);
+void bnpc_mh_ahead_drop(bnpc_ctx *c);
+// bnpc_moves.cpp: called by the NEXT bnpc_sm_move of this thread right after
+// the move's last draw of variable length, with the number of uniforms that
+// still follow inside the move (its acceptance test: 0 or 1); consumed by
+// that call.  NULL: nothing.
+void bnpc_move_last_draw_hook(const std::function<void(int)> *hook);
+#endif
 // bnpc_ll_theta in two halves (bnpc_kernels.hip): the caller works between
 // them - bnpc_sm_move draws the third Beta row under the first scan's sums
 int bnpc_ll_theta_begin(bnpc_ctx *c, int view, const float *theta, int64_t K,

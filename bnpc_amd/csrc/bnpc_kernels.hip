@@ -149,6 +149,11 @@ struct Tunables {
                                     // of split launches (tools/msplit_sweep.py)
     int screen_theta = 1;           // BNPC_MH_SCREEN = 2: verdicts only - not the
                                     // float32 bits of the proposals it accepts
+    int mh_ahead = 1;               // BNPC_MH_AHEAD: the draws of the next
+                                    // parameter batch taken ahead on the aside
+                                    // thread (0: never; 2: for a batch of any
+                                    // size - tests; 3: taken and then thrown
+                                    // away - tests of the discard path)
     size_t mh_pin_max = (size_t)512 << 20;  // pinned block of a screened
                                     // parameter batch at most: twice
                                     // BNPC_SWEEP_BYTES, the host budget of a
@@ -171,6 +176,11 @@ struct Tunables {
                                     // (the pinned block of a screened batch
                                     // is at most Tunables::mh_pin_max bytes)
 #define MH_PIN_NO_MEMORY 77         // mh_pin_get: the host refused the block
+#define MH_AHEAD_MIN 16384          // batch entries from which its draws are
+                                    // taken ahead (config 3's 10-14 thousand
+                                    // cost less than the hand-over)
+#define MH_AHEAD_MAX_ROWS 1024      // ... and rows up to which (a stream state
+                                    // is kept per row: 2.5 KB)
 #define HINT_COLS_MAX 32767         // columns of a hinted sweep (int16 in the
                                     // record)
 #define HINT_THROUGH_MAX 1024       // ... up to which rows that will be scanned
@@ -196,6 +206,7 @@ static void read_tunables(Tunables &t)
     t.mh_screen = env_int("BNPC_MH_SCREEN", 1);
     t.done_words = env_int("BNPC_DONE_WORDS", 1);
     t.screen_theta = t.mh_screen != 2;
+    t.mh_ahead = env_int("BNPC_MH_AHEAD", 1);
     {
         const char *e = getenv("BNPC_SWEEP_BYTES");
         const long long b = e ? atoll(e) : 0;
@@ -287,6 +298,9 @@ struct bnpc_ctx {
     void *mh_pin = nullptr;
     char *mh_dev = nullptr;
     size_t mh_cap = 0;
+    size_t mh_capE = 0;             // entries the block is laid out for
+    struct MhAhead *ahead = nullptr;    // draws taken ahead (bnpc_mh_ahead_*)
+    int64_t ahead_begun = 0, ahead_taken = 0, ahead_rows_taken = 0;
     hipEvent_t mh_ev[2] = {};
     int64_t screened = 0, screen_kept = 0;  // elements seen / left to the host
     size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
@@ -368,6 +382,8 @@ struct bnpc_ctx {
     double last_FP = 0.0, last_FN = 0.0;
     char last_name[96] = "";
 };
+
+static void mh_ahead_destroy(bnpc_ctx *c);      // (with MhAhead, below)
 
 static int ensure(DevBuf &b, size_t bytes)
 {
@@ -2359,6 +2375,7 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->hint_pin) (void)hipHostFree(c->hint_pin);
     if (c->hint_prior_pin) (void)hipHostFree(c->hint_prior_pin);
     if (c->order_pin) (void)hipHostFree(c->order_pin);
+    mh_ahead_destroy(c);
     if (c->mh_pin) (void)hipHostFree(c->mh_pin);
     for (int p = 0; p < 2; p++)
         if (c->mh_ev[p]) (void)hipEventDestroy(c->mh_ev[p]);
@@ -3820,11 +3837,81 @@ static size_t mh_pin_offsets(size_t E, size_t off[6])
     return off[5] + Ea;
 }
 
-static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
+// ---- draws taken AHEAD ------------------------------
+// The draws of a parameter batch - choice(sd, M), M uniforms, M uniforms per
+// cluster, cluster by cluster (libs/CRP.py:328-335) - depend on nothing but
+// the position of the stream, and rank 0's walk through them paces a large
+// batch (0.5 ms of config 5's 0.9 ms parameter phase) while the same thread
+// idles 0.9 ms in front of the sweep's kernel.  So the step posts a WALKER on
+// the aside thread as soon as the stream's way to the batch is known (after a
+// sweep's permutation: one uniform per cell, the alpha test; in a move: after
+// its last variable draw): on a private COPY of the stream it goes that way
+// (`prelude`), notes the state it arrives with (`start`) and draws rows
+// straight into the pinned block, publishing row after row.  The batch adopts
+// them iff the live stream stands exactly at `start` when it begins - any
+// birth, any other draw, any difference makes the two states differ, and the
+// walker's work is dropped (the live stream was never touched).  Same bits
+// by construction: the same generator from the same state.  A batch with
+// more rows than the walker took draws the rest itself, one with fewer
+// continues from the state kept after its last row.
+struct MhAhead {
+    // set by the thread that posts the walker
+    bnpc_mt19937 rng;               // the walker's private stream
+    bnpc_legacy_gauss gauss;
+    std::function<bool(bnpc_mt19937 *, bnpc_legacy_gauss *)> prelude;
+    int64_t rows = 0, M = 0, n_sd = 0;
+    MHPin h;
+    bool active = false;            // posted and not yet taken or dropped
+    // written by the walker
+    std::atomic<int> start_known{0};    // 1: `start` holds; -1: no way known
+    bnpc_mt19937 start;
+    std::atomic<int64_t> rows_ready{0};
+    std::vector<bnpc_mt19937> after_row;
+    std::atomic<int> cancel{0};
+};
+
+static inline void mt_canonical(bnpc_mt19937 &s)
 {
+    if (s.pos >= 624) mt_refill(&s);
+}
+
+static bool mt_same_position(const bnpc_mt19937 &a, const bnpc_mt19937 &b)
+{
+    bnpc_mt19937 x = a, y = b;
+    mt_canonical(x);
+    mt_canonical(y);
+    return x.pos == y.pos && memcmp(x.key, y.key, sizeof x.key) == 0;
+}
+
+// the walker is stopped and forgotten (its draws were not wanted)
+static void mh_ahead_drop(bnpc_ctx *c)
+{
+    MhAhead *ah = c->ahead;
+    if (!ah || !ah->active) return;
+    ah->cancel.store(1, std::memory_order_release);
+    bnpc_aside_wait();
+    ah->active = false;
+}
+
+static void mh_ahead_destroy(bnpc_ctx *c)
+{
+    mh_ahead_drop(c);
+    delete c->ahead;
+    c->ahead = nullptr;
+}
+
+static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev,
+                      bool keep_ahead = false)
+{
+    // (whoever else wants the block ends a walker that writes into it)
+    if (!keep_ahead) mh_ahead_drop(c);
     size_t off[6];
-    const size_t need = mh_pin_offsets(E, off);
-    if (need > c->mh_cap) {
+    // the block is laid out for its CAPACITY in entries, not for this batch:
+    // rows the walker drew for K + 1 clusters lie where a batch of K finds them
+    size_t need = mh_pin_offsets(E, off);
+    if (E <= c->mh_capE) need = mh_pin_offsets(c->mh_capE, off);
+    if (need > c->mh_cap || E > c->mh_capE) {
+        mh_ahead_drop(c);
         // the screen of a batch in flight reads this block: nothing is in
         // flight here (every screened call ends with a synchronisation)
         if (c->mh_pin) HIPCHK(hipHostFree(c->mh_pin));
@@ -3833,7 +3920,9 @@ static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
         c->mh_cap = 0;
         // (no head room for the largest blocks: a slice of a batch beyond the
         // budget never grows)
-        const size_t cap = need + (need < c->tun.mh_pin_max ? need / 4 : 0) + 4096;
+        const size_t capE = E + (need < c->tun.mh_pin_max ? E / 4 : 0) + 64;
+        const size_t cap = mh_pin_offsets(capE, off) + 4096;
+        c->mh_capE = 0;
         const hipError_t e = hipHostMalloc(&c->mh_pin, cap,
                                            hipHostMallocDefault);
         if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
@@ -3849,6 +3938,7 @@ static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
         HIPCHK(hipHostGetDevicePointer(&d, c->mh_pin, 0));
         c->mh_dev = (char *)d;
         c->mh_cap = cap;
+        c->mh_capE = capE;
     }
     char *h = (char *)c->mh_pin, *d = c->mh_dev;
     host = {(double *)(h + off[0]), (double *)(h + off[1]),
@@ -3857,6 +3947,86 @@ static int mh_pin_get(bnpc_ctx *c, size_t E, MHPin &host, MHPin &dev)
     dev = {(double *)(d + off[0]), (double *)(d + off[1]),
            (int32_t *)(d + off[2]), (float *)(d + off[3]),
            (float *)(d + off[4]), (uint8_t *)(d + off[5])};
+    return 0;
+}
+
+// Post the walker (bnpc_internal.h).  Returns 0 whether or not one was posted
+// (*posted says): no walker is never an error.
+int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
+                        const bnpc_legacy_gauss *g,
+                        const std::function<bool(bnpc_mt19937 *,
+                                                 bnpc_legacy_gauss *)> &prelude,
+                        int64_t rows, int64_t M, int64_t n_sd, bool *posted)
+{
+    if (posted) *posted = false;
+    if (!c || !rng || !g || rows < 1 || M != c->M || n_sd < 1 || n_sd > 8)
+        return 0;
+    const int mode = c->tun.mh_ahead;
+    const int64_t E = rows * M;
+    size_t off[6];
+    if (mode == 0 || !c->tun.mh_screen || rows > MH_AHEAD_MAX_ROWS
+        || E < (mode >= 2 ? MH_SCREEN_MIN : MH_AHEAD_MIN)
+        || mh_pin_offsets((size_t)E, off) > c->tun.mh_pin_max
+        || c->any_tile_pending())
+        return 0;
+    if (hipSetDevice(c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (!c->ahead) c->ahead = new MhAhead();
+    MHPin h, d;
+    if (mh_pin_get(c, (size_t)E, h, d)) return 0;   // (drops a walker at work)
+    MhAhead *ah = c->ahead;
+    ah->rng = *rng;
+    ah->gauss = *g;
+    ah->prelude = prelude;
+    ah->rows = rows;
+    ah->M = M;
+    ah->n_sd = n_sd;
+    ah->h = h;
+    ah->start_known.store(0, std::memory_order_relaxed);
+    ah->rows_ready.store(0, std::memory_order_relaxed);
+    ah->cancel.store(0, std::memory_order_relaxed);
+    ah->after_row.resize((size_t)rows);
+    const bool ok = bnpc_aside_start([ah]() {
+        if (ah->prelude && !ah->prelude(&ah->rng, &ah->gauss)) {
+            ah->start_known.store(-1, std::memory_order_release);
+            return;
+        }
+        mt_canonical(ah->rng);
+        ah->start = ah->rng;
+        ah->start_known.store(1, std::memory_order_release);
+        const int64_t M = ah->M;
+        for (int64_t r = 0; r < ah->rows; r++) {
+            if (ah->cancel.load(std::memory_order_acquire)) break;
+            // (non-temporal stores, fenced before the row is published)
+            if (bnpc_mt_mh_draws_to(&ah->rng, 1, M, ah->n_sd,
+                                    ah->h.sd_idx + r * M, ah->h.U + r * M,
+                                    ah->h.u + r * M, true))
+                break;
+            ah->after_row[(size_t)r] = ah->rng;
+            ah->rows_ready.store(r + 1, std::memory_order_release);
+        }
+    });
+    if (!ok) return 0;
+    ah->active = true;
+    c->ahead_begun++;
+    if (posted) *posted = true;
+    return 0;
+}
+
+void bnpc_mh_ahead_drop(bnpc_ctx *c)
+{
+    if (c) mh_ahead_drop(c);
+}
+
+extern "C" int bnpc_mh_ahead_stats(bnpc_ctx *c, int64_t *begun, int64_t *taken,
+                                   int64_t *rows)
+{
+    ARGCHK(c && begun && taken && rows, "NULL argument");
+    *begun = c->ahead_begun;
+    *taken = c->ahead_taken;
+    *rows = c->ahead_rows_taken;
     return 0;
 }
 
@@ -3985,6 +4155,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     ARGCHK(c && a && status, "NULL argument");
     if (!mh_screen_applies(c, a)) {
         ARGCHK(!pending, "counts still pending");
+        mh_ahead_drop(c);
         return bnpc_mh_batch(k, rng, a, status);
     }
     if (int rc = mh_screen_argchk(c, a)) return rc;
@@ -4047,7 +4218,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     const int64_t G = a->G, M = a->M;
     const size_t E = (size_t)G * M;
     MHPin h, d;
-    if (const int prc = mh_pin_get(c, E, h, d)) {
+    if (const int prc = mh_pin_get(c, E, h, d, true)) {
         if (prc != MH_PIN_NO_MEMORY) return 1;
         // no pinned block: the batch without its screen (the exact arithmetic
         // of every entry on the team) instead of a failed step
@@ -4066,6 +4237,37 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     // std::thread did the issuing earlier in round 4: a thread started per
     // batch on whatever core is free took 80-120 us for the draws of a part
     // that this thread, warm, takes in 27 - tools/draws_bench.py.)
+    // Draws taken ahead (MhAhead above): adopted iff the live stream stands
+    // where the walker's stood when it began to draw.
+    MhAhead *ah = c->ahead;
+    int64_t ahead_rows = 0;
+    if (ah && ah->active) {
+        bool ok = rng && row0 == 0 && G_all < 0 && counts_src == 0
+            && ah->M == M && ah->n_sd == a->n_sd && c->tun.mh_ahead != 3;
+        if (ok) {
+            int known;
+            while ((known = ah->start_known.load(std::memory_order_acquire))
+                   == 0)
+                __builtin_ia32_pause();
+            ok = known == 1 && mt_same_position(ah->start, *rng);
+        }
+        if (!ok) {
+            mh_ahead_drop(c);
+        } else {
+            ahead_rows = std::min<int64_t>(ah->rows, G);
+            c->ahead_taken++;
+            c->ahead_rows_taken += ahead_rows;
+        }
+    }
+    // the walker's part of the batch is over: the live stream continues from
+    // the state kept after the last row taken from it
+    auto ahead_close = [&]() {
+        if (!ahead_rows || !ah->active) return;
+        while (ah->rows_ready.load(std::memory_order_acquire) < ahead_rows)
+            __builtin_ia32_pause();
+        *rng = ah->after_row[(size_t)(ahead_rows - 1)];
+        mh_ahead_drop(c);
+    };
     const bool threaded = rng && c->tun.done_words && G >= 4 && counts_src == 0
         && E >= MH_THREADED_MIN;     // "pipelined on rank 0"
     int parts = (G >= 4 && counts_src == 0) ? 2 : 1;
@@ -4088,10 +4290,22 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         timespec tq0, tq1;
         if (trace) clock_gettime(CLOCK_MONOTONIC, &tq0);
         if (rng) {
-            if (int rc = bnpc_mt_mh_draws_to(rng, Gp, M, a->n_sd,
-                                             h.sd_idx + at, h.U + at,
-                                             h.u + at, threaded))
-                return rc;
+            int64_t lo = g0;
+            const int64_t hi = g0 + Gp;
+            if (lo < ahead_rows) {      // rows the walker took (or is taking)
+                const int64_t upto = std::min(hi, ahead_rows);
+                while (ah->rows_ready.load(std::memory_order_acquire) < upto)
+                    __builtin_ia32_pause();
+                lo = upto;
+            }
+            if (lo < hi) {              // rows this thread draws
+                ahead_close();
+                const size_t lat = (size_t)lo * M;
+                if (int rc = bnpc_mt_mh_draws_to(rng, hi - lo, M, a->n_sd,
+                                                 h.sd_idx + lat, h.U + lat,
+                                                 h.u + lat, threaded))
+                    return rc;
+            }
             if (trace) {
                 clock_gettime(CLOCK_MONOTONIC, &tq1);
                 t_draws_us[p] = (tq1.tv_sec - tq0.tv_sec) * 1e6
@@ -4120,7 +4334,13 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     };
     int next_issue = 0;
     {
-        const int up_front = threaded ? std::min(2, parts) : parts;
+        // (parts whose draws are there cost this thread a copy and a launch:
+        // all of them up front)
+        int up_front = threaded ? std::min(2, parts) : parts;
+        while (up_front < parts && ahead_rows >= cut[up_front + 1]
+               && ah->rows_ready.load(std::memory_order_acquire)
+                   >= cut[up_front + 1])
+            up_front++;
         for (; next_issue < up_front; next_issue++)
             if (int rc = issue_timed(next_issue)) return rc;
     }
@@ -4190,6 +4410,7 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
             + 0.5 * (double)counts[2]) / (double)Gp;
         if (trace) clock_gettime(CLOCK_MONOTONIC, &t_hosted[p]);
     }
+    ahead_close();
     c->screened += (int64_t)E;
     c->screen_kept += kept;
     if (trace) {

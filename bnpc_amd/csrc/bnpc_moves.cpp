@@ -232,6 +232,15 @@ extern "C" int bnpc_move_propose(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     return 0;
 }
 
+// What the NEXT bnpc_sm_move of this thread calls right after its last draw
+// of variable length (bnpc_internal.h); consumed by that call.
+static thread_local const std::function<void(int)> *g_last_draw_hook = nullptr;
+
+void bnpc_move_last_draw_hook(const std::function<void(int)> *hook)
+{
+    g_last_draw_hook = hook;
+}
+
 extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
                             bnpc_mt19937 *rng, bnpc_move_state *st,
                             int *status)
@@ -245,6 +254,8 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     }
     *status = 1;
     st->accepted = 0;
+    const std::function<void(int)> *last_draw = g_last_draw_hook;
+    g_last_draw_hook = nullptr;
     bnpc_legacy_gauss *gauss = (bnpc_legacy_gauss *)st->gauss;
     Restore restore(rng, gauss);    // undone below when the move completes
     static thread_local Scratch s;
@@ -462,6 +473,12 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         // np.random.choice(sd, size=M); the reverse move's parameter
         // proposal: the merged launch row -> the cluster's own row
         mt_fill_interval32(rng, (uint32_t)(st->n_sd - 1), s.sd_idx.data(), M);
+        // (all that the stream still gives inside this move: the uniform of
+        // its acceptance test, unless the scan left a side empty)
+        if (last_draw) {
+            const int64_t ones_now = rg_ones();
+            (*last_draw)(ones_now != 0 && ones_now != S ? 1 : 0);
+        }
         s.std2.resize((size_t)2 * M);
         for (int64_t m = 0; m < M; m++) s.std2[m] = st->sd[s.sd_idx[m]];
         const int64_t cl = st->ids[pos_i];
@@ -593,6 +610,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         // _rg_get_split_prob (libs/CRP.py:777-820)
         mt_fill_interval32(rng, (uint32_t)(st->n_sd - 1), s.sd_idx.data(),
                            2 * M);
+        if (last_draw) (*last_draw)(1);     // (the acceptance test's uniform)
         s.std2.resize((size_t)2 * M);
         for (int64_t m = 0; m < 2 * M; m++) s.std2[m] = st->sd[s.sd_idx[m]];
         memcpy(s.gather.data(), st->parameters + cl_i * st->param_stride,

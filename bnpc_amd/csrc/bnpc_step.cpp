@@ -221,6 +221,69 @@ bool error_prior(const bnpc_host_kernels *k, const bnpc_chain *ch, Work &w,
     return true;
 }
 
+// the draws of CRP.update_DP_alpha (libs/CRP.py:386-410) and the value they
+// give - a function of the stream and of (DP_a, N, K, the prior) alone: the
+// walker that takes a parameter batch's draws ahead goes through them on its
+// copy of the stream
+struct AlphaArgs {
+    double DP_a, shape, rate;
+    int64_t N, K;
+};
+
+int alpha_draws(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
+                bnpc_legacy_gauss *g, const AlphaArgs &p, double *alpha)
+{
+    const double kk = (double)p.K;
+    double eta = 0.0;
+    const double a = p.DP_a + 1, b = (double)p.N;
+    int rc = bnpc_mt_beta(rng, g, 1, &a, &b, &eta);
+    if (rc) return rc;
+    const double rate = p.rate - np_log1(k, eta);
+    const double wgt = (p.shape + kk - 1) / ((double)p.N * rate);
+    const double pi_eta = wgt / (1 + wgt);
+    if (mt_double(rng) < pi_eta)
+        *alpha = bnpc_legacy_gamma(rng, g, p.shape + kk, rate);
+    else
+        *alpha = bnpc_legacy_gamma(rng, g, p.shape + kk - 1, rate);
+    return 0;
+}
+
+// The draws of this step's parameter batch taken ahead (bnpc_mh_ahead_begin):
+// from a point of the step after which the stream's way to the batch is known
+// - `doubles` uniforms (a sweep's picks, one per cell, if no cluster is born;
+// a move's acceptance test), the alpha test and, if it fires, update_DP_alpha
+// with the clusters there are now - a walker goes that way on a copy of the
+// stream and draws the rows of K + 1 clusters.  Whatever else happens (a
+// birth, a move that changes K before an alpha update) leaves the live stream
+// somewhere else, and the batch draws for itself.
+void params_ahead(bnpc_ctx *ctx, const bnpc_host_kernels *k,
+                  const bnpc_mt19937 *rng, const bnpc_chain *ch,
+                  int64_t doubles)
+{
+    if (ch->fix_assign) return;
+    const double dpa_prob = ch->dpa_prob;
+    const AlphaArgs args = {ch->DP_a, ch->dpa_shape, ch->dpa_rate, ch->N,
+                            ch->K};
+    const auto way = [k, doubles, dpa_prob, args](bnpc_mt19937 *r,
+                                                  bnpc_legacy_gauss *g) {
+        // (2 words per uniform: whole state blocks are skipped untempered)
+        for (int64_t left = 2 * doubles; left > 0;) {
+            if (r->pos >= 624) mt_refill(r);
+            const int64_t take = std::min<int64_t>(624 - r->pos, left);
+            r->pos += (int32_t)take;
+            left -= take;
+        }
+        if (mt_double(r) < dpa_prob) {
+            double alpha;
+            if (alpha_draws(k, r, g, args, &alpha)) return false;
+        }
+        return true;
+    };
+    bool posted = false;
+    (void)bnpc_mh_ahead_begin(ctx, rng, (const bnpc_legacy_gauss *)ch->gauss,
+                              way, ch->K + 1, ch->M, ch->n_sd, &posted);
+}
+
 // ---------------------------------------------------------------- the phases
 // CRP.update_assignments_Gibbs (bnpc_amd/model.py; libs/CRP.py:254-288) for a
 // sweep whose whole matrix is one hinted launch.  *done = false: not this
@@ -298,6 +361,9 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     mt_fill_permutation(rng, N, w.perm.data());
     rc = bnpc_hints_in_order_issue(ctx, w.perm.data(), &top2);
     if (rc) return rc;
+    // from here to the parameter batch the stream gives one uniform per cell
+    // (and whatever a birth draws: then the walker's work is dropped)
+    if (ch->phase == BNPC_PHASE_ASSIGN) params_ahead(ctx, k, rng, ch, N);
     // under the launches: the sweep's private state
     w.assign.assign(ch->assignment, ch->assignment + N);
     w.col_of_id.assign((size_t)N, -1);
@@ -474,7 +540,16 @@ int move_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     st.fill = ch->mix0;
     st.gauss = ch->gauss;
     int sub = 1;
+    // (after the move's last draw of variable length: its acceptance test,
+    // then the way to the parameter batch as after a sweep)
+    const std::function<void(int)> last_draw = [&](int uniforms_left) {
+        if (ch->phase == BNPC_PHASE_ASSIGN)
+            params_ahead(ctx, k, rng, ch, uniforms_left);
+    };
+    bnpc_move_last_draw_hook(&last_draw);
     const int rc = bnpc_sm_move(ctx, k, rng, &st, &sub);
+    bnpc_move_last_draw_hook(nullptr);
+    if (rc || sub) bnpc_mh_ahead_drop(ctx);
     if (rc) return rc;
     if (sub) return 0;
     *done = true;
@@ -515,19 +590,10 @@ int alpha_phase(const bnpc_host_kernels *k, bnpc_mt19937 *rng, bnpc_chain *ch,
 {
     bnpc_legacy_gauss *g = (bnpc_legacy_gauss *)ch->gauss;
     const int64_t N = ch->N;
-    const double kk = (double)ch->K;
-    double eta = 0.0;
-    const double a = ch->DP_a + 1, b = (double)N;
-    int rc = bnpc_mt_beta(rng, g, 1, &a, &b, &eta);
-    if (rc) return rc;
-    const double rate = ch->dpa_rate - np_log1(k, eta);
-    const double wgt = (ch->dpa_shape + kk - 1) / ((double)N * rate);
-    const double pi_eta = wgt / (1 + wgt);
     double alpha;
-    if (mt_double(rng) < pi_eta)
-        alpha = bnpc_legacy_gamma(rng, g, ch->dpa_shape + kk, rate);
-    else
-        alpha = bnpc_legacy_gamma(rng, g, ch->dpa_shape + kk - 1, rate);
+    const AlphaArgs args = {ch->DP_a, ch->dpa_shape, ch->dpa_rate, N, ch->K};
+    int rc = alpha_draws(k, rng, g, args, &alpha);
+    if (rc) return rc;
     ch->DP_a = (1 + EPSILON) < alpha ? alpha : (1 + EPSILON);
     // CRP_prior = [0, log(1..N, DP_a) - log(N - 1 + DP_a)]: NumPy's log loop
     // over the same N + 1 element vector the reference hands it

@@ -1409,6 +1409,11 @@ class CRP:
             for key in ('swept', 'hint_used', 'pair_used', 'triple_used',
                     'lane_used', 'native_moves'):
                 out[key] += getattr(nat.st, key)
+        # parameter batches whose draws a walker took ahead of them
+        ctx = getattr(self, '_ctx', None)
+        ahead = getattr(ctx, 'mh_ahead_stats', None)
+        out['ahead_begun'], out['ahead_taken'], out['ahead_rows'] = \
+            ahead() if ahead is not None else (0, 0, 0)
         return out
 
     # ------------------------------------------------- cluster parameters

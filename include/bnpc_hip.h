@@ -331,6 +331,11 @@ int bnpc_bench_ll_full(bnpc_ctx *ctx, int reps, float *ms_per_call);
  * for how many clusters, in how many mutation chunks */
 int bnpc_last_launch(const bnpc_ctx *ctx, char *name, int len, int64_t *K,
                      int *mutation_chunks);
+/* Parameter batches whose draws were taken ahead of the batch on a copy of
+ * the stream (bnpc_chain_step): walkers started / adopted
+ * by a batch / rows of draws adopted, since the context was created. */
+int bnpc_mh_ahead_stats(bnpc_ctx *ctx, int64_t *begun, int64_t *taken,
+                        int64_t *rows);
 /* Per-launch device timers.  on = 1: from now on every kernel this library
  * launches (any context of the process) carries a start / stop event pair
  * that takes the dispatch's own timestamps.  on = 0: timers off, the device

@@ -1525,6 +1525,58 @@ def test_native_steps_change_nothing(kind, pb, knobs, monkeypatch):
         np.testing.assert_allclose(a[7], c[7], rtol=1e-9)
 
 
+@pytest.mark.parametrize('mode,kind,pb,knobs', [
+    ('2', 'learn', (.25, .25), None),
+    ('2', 'learn', (.75, 2.), dict(sm_prob=.6, sm_steps=2, dpa_prob=.6,
+        error_prob=.7, sm_ratios=[.4, .6])),
+    ('3', 'learn', (.25, .25), None),
+    ('0', 'fixed', (1, 1), None),
+])
+def test_draws_taken_ahead_change_nothing(mode, kind, pb, knobs, monkeypatch):
+    """the draws of a step's parameter batch taken AHEAD
+    by a walker on the aside thread - on a copy of the stream, under the
+    sweep's kernel and loop / under the tail of a move - and adopted by the
+    batch iff the live stream stands exactly where the walker's stood
+    (bnpc_mh_ahead_begin, MhAhead in bnpc_kernels.hip).  BNPC_MH_AHEAD=2 takes
+    them for a batch of ANY size (the default starts at 16 384 entries), 3
+    takes and then throws them away (the discard path at every step), 0 never
+    takes any: after EVERY one of 120 steps the chain is the chain walked
+    method by method without a walker - labels, cluster table, parameter
+    rows, alpha, error rates, recorded traces, the position of the stream -
+    from the first sweeps (hundreds of clusters, births: walkers dropped)
+    into the converged regime, moves accepted and rejected included."""
+    data = H.synth(33, 900, 220, 7, 0.15)
+    steps = 120
+    monkeypatch.setenv('BNPC_MH_AHEAD', mode)
+    nat = _chain_by_steps(P, kind, data, steps, 77, pb, '1', monkeypatch, knobs)
+    monkeypatch.delenv('BNPC_MH_AHEAD')
+    ref = _chain_by_steps(P, kind, data, steps, 77, pb, '0', monkeypatch, knobs)
+    assert nat[1]['native_steps'] >= steps - 5, nat[1]
+    begun, taken = nat[1]['ahead_begun'], nat[1]['ahead_taken']
+    assert ref[1]['ahead_begun'] == 0
+    if mode == '2':
+        # a walker per native sweep / move; most are adopted (not: a sweep
+        # with a birth, an alpha update after a move that changed K, a move
+        # handed back)
+        assert begun >= 0.8 * steps, nat[1]
+        assert taken >= 0.6 * begun, nat[1]
+        assert nat[1]['ahead_rows'] >= 5 * taken
+    elif mode == '3':
+        assert begun >= 0.8 * steps and taken == 0, nat[1]
+    else:
+        assert begun == 0 and taken == 0, nat[1]
+    for i, (a, b) in enumerate(zip(nat[0], ref[0])):
+        for x, y in zip(a, b):
+            if isinstance(x, np.ndarray):
+                assert x.dtype == y.dtype and np.array_equal(x, y), i
+            else:
+                assert x == y, (i, x, y)
+    for key in nat[2]:
+        assert np.array_equal(nat[2][key], ref[2][key]), key
+    for name in nat[3]:
+        assert np.array_equal(nat[3][name], ref[3][name]), name
+
+
 def test_native_step_hands_phases_back_and_resumes(monkeypatch):
     """Phases the library hands back to the binding (ch->need) and resumes
     after: without the sweep's hints, or with a sweep budget too small for one
