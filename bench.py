@@ -540,6 +540,7 @@ def main():
     ml_end = float(chain.results['ML'][total])
     stats1 = dict(model.host_stats())
     screen1 = model._dev().mh_screen_stats()
+    window = clock.report(args.steps, elapsed)      # (this rank's phases)
     devices, distinct_gpus = devices_of(ranks, args.steps)   # (collective)
 
     # ---- after the window: what the chain sustains, and its device time ---
@@ -726,7 +727,6 @@ def main():
             'mh_left_to_host': round(kept / seen, 4) if seen else None,
         }
         value = world * args.steps / elapsed
-        window = clock.report(args.steps, elapsed)
         if device_time is not None:
             # device busy time per step (measured on the steps right after
             # the sustained leg, timers on) and the share of a step it is
