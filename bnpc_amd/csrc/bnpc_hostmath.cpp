@@ -661,6 +661,16 @@ void bnpc_mh_rank0_hook(const std::function<void()> *hook)
     g_rank0_hook = hook;
 }
 
+// What every rank of the NEXT screened bnpc_mh_batch of this thread calls
+// before it touches a row (bnpc_internal.h): it returns when the row's flags
+// are there.  false: give the batch up.  Consumed by that call.
+static thread_local const std::function<bool(int64_t)> *g_row_gate = nullptr;
+
+void bnpc_mh_row_gate(const std::function<bool(int64_t)> *gate)
+{
+    g_row_gate = gate;
+}
+
 static int check_kernels(const bnpc_host_kernels *k)
 {
     if (!k || !k->ndtr || !k->log_ndtr || !k->ndtri_exp || !k->sc_log1p
@@ -809,6 +819,8 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         if (threads < 1) threads = 1;
         std::atomic<int64_t> next(0), n_todo(0), n_sure(0), n_miss(0),
             n_given(0);
+        const std::function<bool(int64_t)> *gate = g_row_gate;
+        g_row_gate = nullptr;
         auto work = [&](int) {
             int32_t todo[SEG], sure[SEG], given[SEG];
             const bool take_given = a->screen_theta != nullptr;
@@ -819,6 +831,12 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 const int64_t g = t / segs, m0 = (t - g * segs) * SEG;
                 const int64_t m1 = std::min(M, m0 + SEG);
                 const size_t row = (size_t)g * M;
+                // (a batch whose parts are still being screened: the row's
+                // verdicts may not be there yet)
+                if (gate && !(*gate)(g)) {
+                    bail.store(1, std::memory_order_relaxed);
+                    continue;
+                }
                 const uint8_t *sc = a->screen + row;
                 const float *old = a->old_theta + row;
                 float *out = a->new_theta + row;

@@ -58,6 +58,11 @@ double bnpc_legacy_gamma(bnpc_mt19937 *rng, bnpc_legacy_gauss *g, double shape,
 // and the screen launch of a later part of a large batch under the team's
 // work on this one); NULL: nothing.  Consumed by that call.
 void bnpc_mh_rank0_hook(const std::function<void()> *hook);
+// ... and every rank of it calls (*gate)(row) before it touches a row of the
+// batch: the call returns when that row's verdicts are there (a batch that is
+// evaluated as ONE team job while its later parts are still being screened);
+// false gives the batch up.  NULL: nothing.  Consumed by that call.
+void bnpc_mh_row_gate(const std::function<bool(int64_t)> *gate);
 #ifdef __cplusplus
 // bnpc_kernels.hip: the draws of the NEXT screened parameter batch on this
 // context taken ahead (MhAhead there): a walker on the aside thread takes a

@@ -301,6 +301,8 @@ struct bnpc_ctx {
     size_t mh_capE = 0;             // entries the block is laid out for
     struct MhAhead *ahead = nullptr;    // draws taken ahead (bnpc_mh_ahead_*)
     int64_t ahead_begun = 0, ahead_taken = 0, ahead_rows_taken = 0;
+    double mh_flagged_share = 0.25; // host work the last screened batch left,
+                                    // per entry (sizes the next one's team)
     hipEvent_t mh_ev[2] = {};
     int64_t screened = 0, screen_kept = 0;  // elements seen / left to the host
     size_t pin_lazy_bytes = 0;      // sweep matrix still on the device (c->out)
@@ -4276,6 +4278,9 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
             std::min<int64_t>(8, G), (int64_t)(E / (MH_THREADED_MIN / 2))));
     int64_t cut[9];
     for (int p = 0; p <= parts; p++) cut[p] = G * p / parts;
+    // ONE team job for the whole batch (round 6; below): its ranks wait for a
+    // part's verdicts at the first row of it they touch
+    const bool one_job = c->tun.done_words && parts >= 2;
     for (int p = 0; p < 2; p++)
         if (!c->mh_ev[p])
             HIPCHK(hipEventCreateWithFlags(&c->mh_ev[p],
@@ -4318,7 +4323,8 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         }
         memcpy(h.theta + at, a->old_theta + at, n * 4);
         // (one word for all parts: the launches of a stream finish in order)
-        const DoneSignal sig = make_signal(c, threaded ? 0 : p, &done_seq[p]);
+        const DoneSignal sig = make_signal(c, threaded || one_job ? 0 : p,
+                                           &done_seq[p]);
         if (int rc = mh_screen_launch(c, counts_src, a, d, g0, Gp, sig, row0,
                                       G_all))
             return rc;
@@ -4348,6 +4354,100 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     int64_t kept = 0;
     double weighted_per_row = 0.0;      // flagged entries of the parts so far
     *status = 0;
+    bool all_signalled = one_job;
+    for (int p = 0; p < next_issue; p++)
+        all_signalled = all_signalled && done_seq[p] != 0;
+    if (all_signalled) {
+        // ---- the batch as ONE team job ---------------------------------
+        // Round 5 evaluated part after part: a team job per part, its rank 0
+        // issuing the next part but one before it joined - seven wake-ups,
+        // seven barriers and seven tails per config-5 batch, 60-70 us a part
+        // even with the draws taken ahead.  Now the team is started once:
+        // rank 0 (this thread) first issues what is left to issue - a copy
+        // and a launch per part when a walker took the draws, else the draws
+        // too -, copies the counts a fused launch wrote, and joins; every
+        // rank, before it touches a row, waits until the part the row lies
+        // in has been launched and the device's completion word has reached
+        // that launch's number (the parts finish in order on one stream).
+        std::atomic<int> issued(next_issue), ready(0), failed(0);
+        const volatile unsigned *word = c->done_pin;    // slot 0
+        const std::function<bool(int64_t)> gate = [&](int64_t g) -> bool {
+            int p = 0;
+            while (p + 1 < parts && g >= cut[p + 1]) p++;
+            if (ready.load(std::memory_order_acquire) > p) return true;
+            for (long spins = 0;; spins++) {
+                if (failed.load(std::memory_order_relaxed)) return false;
+                if (issued.load(std::memory_order_acquire) > p
+                    && (int)(*word - done_seq[p]) >= 0)
+                    break;
+                if (spins < 4000) __builtin_ia32_pause();
+                else std::this_thread::yield();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            int seen = ready.load(std::memory_order_relaxed);
+            while (seen < p + 1
+                   && !ready.compare_exchange_weak(seen, p + 1,
+                                                   std::memory_order_release))
+            {}
+            return true;
+        };
+        int hook_rc = 0;
+        const int *counts_dev = pending;
+        const std::function<void()> hook = [&]() {
+            while (next_issue < parts && !hook_rc) {
+                hook_rc = issue_timed(next_issue);
+                if (!hook_rc && !done_seq[next_issue]) hook_rc = 1;
+                next_issue++;
+                issued.store(next_issue, std::memory_order_release);
+            }
+            if (hook_rc) {
+                failed.store(1, std::memory_order_relaxed);
+                return;
+            }
+            if (counts_dev) {   // behind the first screen: the counts are there
+                if (!gate(0)) return;
+                memcpy((void *)a->n1, counts_dev, E * sizeof(int32_t));
+                memcpy((void *)a->n0, counts_dev + E, E * sizeof(int32_t));
+            }
+        };
+        bnpc_mh_args b = *a;
+        b.sd_idx = h.sd_idx;
+        b.U = h.U;
+        b.u = h.u;
+        b.screen = h.flags;
+        b.screen_theta = h.new32;
+        if (pending) {          // the evaluation reads them where they are
+            b.n1 = pending;
+            b.n0 = pending + E;
+        }
+        int64_t counts[3] = {0, 0, 0};
+        b.flag_counts = counts;
+        b.flagged_estimate = std::max<int64_t>(
+            1, (int64_t)(c->mh_flagged_share * (double)E));
+        int st = 0;
+        bnpc_mh_rank0_hook(&hook);
+        bnpc_mh_row_gate(&gate);
+        int rc = bnpc_mh_batch(k, nullptr, &b, &st);
+        bnpc_mh_rank0_hook(nullptr);
+        bnpc_mh_row_gate(nullptr);
+        pending = nullptr;
+        if (rc == 0 && hook_rc) {
+            bnpc_set_error("a part of a screened parameter batch could not "
+                           "be issued");
+            rc = hook_rc == 2 ? 2 : 1;
+        }
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+        if (st) *status = 1;
+        kept = counts[0] + counts[1] + counts[2];
+        c->mh_flagged_share = ((double)(counts[0] + counts[1])
+            + 0.5 * (double)counts[2]) / (double)E;
+        if (trace)
+            for (int p = 0; p < parts; p++) t_got[p] = t_waited[p] =
+                t_hosted[p] = t_issued[p];
+    } else
     for (int p = 0; p < parts; p++) {
         const int64_t g0 = cut[p], Gp = cut[p + 1] - cut[p];
         const size_t at = (size_t)g0 * M;
