@@ -104,7 +104,7 @@ class MHArgs(C.Structure):
         ('log_prob', C.c_void_p), ('declined', C.c_void_p),
         ('threads', C.c_int), ('screen', C.c_void_p),
         ('screen_theta', C.c_void_p), ('flagged_estimate', _i64),
-        ('flag_counts', C.c_void_p)]
+        ('flag_counts', C.c_void_p), ('prior_seq_sum', C.c_void_p)]
 
 
 class LogAArgs(C.Structure):

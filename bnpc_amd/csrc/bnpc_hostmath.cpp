@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <system_error>
@@ -821,7 +822,57 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
             n_given(0);
         const std::function<bool(int64_t)> *gate = g_row_gate;
         g_row_gate = nullptr;
-        auto work = [&](int) {
+        // the sum of the batch's prior densities in index order
+        // (bnpc_mh_args.prior_seq_sum): segments still missing per row; the
+        // LAST rank adds a row up as soon as it and all rows before it are
+        // complete - one chain of dependent adds that trails the team instead
+        // of following it
+        const bool want_sum = a->prior_seq_sum && a->prior_out;
+        std::unique_ptr<std::atomic<int>[]> row_left;
+        if (want_sum) {
+            row_left.reset(new std::atomic<int>[(size_t)G]);
+            for (int64_t g = 0; g < G; g++)
+                row_left[(size_t)g].store((int)segs, std::memory_order_relaxed);
+        }
+        double seq_sum = want_sum ? *a->prior_seq_sum : 0.0;
+        bool seq_started = want_sum && seq_sum == seq_sum;
+        int64_t seq_next = 0;           // (restartable: rows [0, seq_next) are in)
+        auto add_rows_up = [&]() {
+            // (uniform prior: prior_out holds zeros - the sum of zeros)
+            for (int64_t g = seq_next; g < G; g++) {
+                for (long spins = 0; row_left[(size_t)g].load(
+                         std::memory_order_acquire) != 0; spins++) {
+                    if (bail.load(std::memory_order_relaxed)) return;
+                    if (spins < 2000) {
+#if defined(__x86_64__)
+                        __builtin_ia32_pause();
+#endif
+                    } else {
+                        std::this_thread::yield();
+                    }
+                }
+                const double *d = a->prior_out + (size_t)g * M;
+                int64_t m = 0;
+                if (!seq_started) {
+                    seq_sum = d[0];
+                    seq_started = true;
+                    m = 1;
+                }
+                double sacc = seq_sum;
+                for (; m < M; m++) sacc += d[m];
+                seq_sum = sacc;
+                seq_next = g + 1;
+            }
+        };
+        // (the ranks there really are: the team keeps what it has when the
+        // system refuses a thread)
+        if (want_sum && threads > 2) threads = bnpc_team_ranks(threads);
+        const int sum_rank = want_sum && threads > 2 ? threads - 1 : -1;
+        auto work = [&](int rank) {
+            if (rank == sum_rank) {
+                add_rows_up();
+                return;
+            }
             int32_t todo[SEG], sure[SEG], given[SEG];
             const bool take_given = a->screen_theta != nullptr;
             for (;;) {
@@ -837,6 +888,13 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                     bail.store(1, std::memory_order_relaxed);
                     continue;
                 }
+                struct RowDone {        // this segment of row g is complete
+                    std::atomic<int> *left;
+                    ~RowDone()
+                    {
+                        if (left) left->fetch_sub(1, std::memory_order_release);
+                    }
+                } row_done = {want_sum ? &row_left[(size_t)g] : nullptr};
                 const uint8_t *sc = a->screen + row;
                 const float *old = a->old_theta + row;
                 float *out = a->new_theta + row;
@@ -945,6 +1003,12 @@ extern "C" int bnpc_mh_batch(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         } else {
             if (first) (*first)();
             work(0);
+        }
+        if (want_sum && !bail.load()) {
+            // (a team of one or two - or a sum rank that never came: after
+            // the work, by the caller)
+            add_rows_up();
+            *a->prior_seq_sum = seq_sum;
         }
         if (trace)
             fprintf(stderr, "[mh_batch] G=%lld M=%lld screened: %lld in doubt, "

@@ -54,6 +54,8 @@ struct Work {
     std::vector<double> pc_prior, kp, prior_out, dens;
     bool pc_set = false;
     bool pc_is_rows = false;    // ... and they are w.rows as gathered now
+    double pc_sum = 0.0;        // their sum in index order, from the batch
+    bool pc_sum_set = false;
     // batch scratch
     std::vector<int32_t> sd_idx;
     std::vector<double> U, u, A, log_prob, cdf;
@@ -669,6 +671,11 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     a.log_prob = w.log_prob.data();
     a.declined = w.declined.data();
     a.threads = team_for(ch, (int64_t)E);
+    // (the densities' sum in index order - what recording the step needs of
+    // them - is made by a rank of the batch's team behind the others)
+    double prior_sum = NAN;
+    a.prior_seq_sum = want_prior ? &prior_sum : nullptr;
+    w.pc_sum_set = false;
     const Snapshot before(rng, (bnpc_legacy_gauss *)ch->gauss);
     const Clock::time_point tp3 = Clock::now();
     int sub = 0, rc;
@@ -700,6 +707,8 @@ int params_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         w.pc_prior.swap(w.prior_out);
         w.pc_set = true;
         w.pc_is_rows = true;        // until the rows are gathered afresh
+        w.pc_sum = prior_sum;
+        w.pc_sum_set = prior_sum == prior_sum;
     } else if (want_prior) {
         w.pc_set = false;
     }
@@ -821,9 +830,13 @@ int record_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_chain *ch,
             // produced, with their densities: the sum in index order is all
             // that is left (a compare and a copy per element otherwise: the
             // largest part of recording a config-5 step)
-            const double *d = w.pc_prior.data();
-            seq = d[0];
-            for (int64_t i = 1; i < K * M; i++) seq += d[i];
+            if (w.pc_sum_set) {
+                seq = w.pc_sum;
+            } else {
+                const double *d = w.pc_prior.data();
+                seq = d[0];
+                for (int64_t i = 1; i < K * M; i++) seq += d[i];
+            }
         } else {
             const float *kt;
             const double *kp;
