@@ -712,6 +712,9 @@ def main():
             'sweep_triples': stats['triple_used'],
             # ... of sweep_hinted, decided in the loop's lane for such cells
             'sweep_lane': stats['lane_used'],
+            # ... of sweep_lane, taken whole runs at a time (cells that stay in
+            # the cluster that dominates them: the lane's stride)
+            'sweep_stride': stats.get('stride_used', 0),
             # steps made as ONE native call (bnpc_chain_step) / split-merge
             # moves made as one native call (bnpc_sm_move)
             'native_steps': stats['native_steps'],

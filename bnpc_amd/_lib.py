@@ -71,7 +71,8 @@ class GibbsState(C.Structure):
         ('beta_q', C.c_double), ('tmin', C.c_double), ('tmax', C.c_double),
         ('FP', C.c_double), ('FN', C.c_double), ('gauss', C.c_void_p),
         ('born', C.c_void_p), ('born_cap', _i64), ('n_born', _i64),
-        ('triple_used', _i64), ('hint_in_order', _i64), ('lane_used', _i64)]
+        ('triple_used', _i64), ('hint_in_order', _i64), ('lane_used', _i64),
+        ('stride_used', _i64)]
 
 
 class MoveState(C.Structure):
@@ -150,7 +151,7 @@ class ChainState(C.Structure):
         ('ML', C.c_double), ('lprior', C.c_double), ('swept', _i64),
         ('hint_used', _i64), ('pair_used', _i64), ('triple_used', _i64),
         ('native_moves', _i64), ('steps', _i64), ('lane_used', _i64),
-        ('clock_ns', _i64 * 10),
+        ('stride_used', _i64), ('clock_ns', _i64 * 10),
         ('clock_calls', _i64 * 10), ('work', C.c_void_p)]
 
 

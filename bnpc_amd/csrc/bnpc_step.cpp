@@ -502,6 +502,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     ch->pair_used += st.pair_used;
     ch->triple_used += st.triple_used;
     ch->lane_used += st.lane_used;
+    ch->stride_used += st.stride_used;
     std::vector<double>().swap(w.heap_ll);
     *done = true;
     return 0;

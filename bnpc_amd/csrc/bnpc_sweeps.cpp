@@ -124,13 +124,21 @@ static bool loop_shortcuts()
 // whose uniform lies within x of 0 or 1 over to the general iteration WITH
 // that uniform - what it does for the 1e-11 slivers at either end, made
 // frequent enough to test.  Returns the distance, < 0 for "no lane".
+// BNPC_SWEEP_LANE=nostride: the lane without its stride (every cell by the
+// lane's own steps: the A/B and the old-vs-new comparison of the stride)
+static bool sweep_lane_stride()
+{
+    const char *e = getenv("BNPC_SWEEP_LANE");
+    return !(e && strcmp(e, "nostride") == 0);
+}
+
 static double sweep_lane_sliver()
 {
     // (1e-11: with at most 4096 live clusters the floor entries below the
     // winner end under 4.1e-12 and the ones above it start beyond 1 - 4.1e-12
     // - the rule sweep_window's dominated pick has for 512 and 1e-12)
     const char *e = getenv("BNPC_SWEEP_LANE");
-    if (!e || !e[0]) return 1e-11;
+    if (!e || !e[0] || strcmp(e, "nostride") == 0) return 1e-11;
     const double x = strtod(e, nullptr);
     if (!(x > 0.0)) return -1.0;
     return x < 0.5 ? (x > 1e-11 ? x : 1e-11) : 1e-11;
@@ -678,10 +686,15 @@ struct RecordLane {
     double *cpr;
     bool weights;               // the prior table is log(size) + const: the
                                 // two- and three-candidate picks as well
+    // the stride (below): folded[c] != 0 - column c's prior at its current
+    // size and at one cell less is in `drift` already
+    uint8_t *folded;
+    bool stride;
     // state
     int64_t pos;
     double drift;
     int64_t decided;            // cells the lane has moved ...
+    int64_t strided;            // ... of them whole runs at a time (the stride)
     int64_t pairs, triples;     // ... of them between two / among three
     // the cell it stopped in
     bool removed, have_u;
@@ -713,7 +726,119 @@ static void record_lane(RecordLane &L, bnpc_mt19937 *rng)
     auto pos_of = [&](int64_t c) -> int64_t {
         return L.pos64 ? L.pos64[c] : (int64_t)L.pos32[c];
     };
+    // THE STRIDE (round 6).  Nearly every cell of a converged sweep is
+    // dominated by the cluster it sits in: it leaves, its record's first
+    // column - its own - beats everything else by more than the dominance
+    // margin under any drift, its uniform lies clear of 0 and 1, it rejoins.
+    // Nothing of that depends on the cell before it, so a RUN of such cells
+    // is taken at once: per cell two gathers (label -> column, the
+    // new-cluster term), three compares against ONE threshold that holds for
+    // every drift the run can see, its uniform peeked - tempered straight
+    // out of the state block, not yet consumed - and compared with the
+    // slivers; the run ends in front of the first cell that fails anything,
+    // and that cell takes the lane's own steps below with nothing drawn.
+    //   The threshold: the lane accepts when second + d - (best - d) < margin
+    // and post_new - (best - d) < margin, d = the drift when the cell has
+    // left.  While every cell of a run stays, sizes are what they are, so d
+    // never exceeds D = max(drift, over the live hint columns c:
+    // |prior[size_c] - prior0_c|, |prior[size_c - 1] - prior0_c|); best -
+    // second > 2 D - margin and best - post_new > 2 D - margin (+ 1e-6: the
+    // two forms round differently) imply both for any d <= D.  `dmax` keeps D
+    // from above (it only grows while the lane runs: conservative).
+    //   What a staying cell leaves behind - the two priors of its column
+    // folded into the drift - is folded once per column and size (`folded`).
+    // 7.2 -> ~2 ns per dominated cell (tools/hinted_loop_bench.py).
+    double dmax = drift;
+    const bool stride = L.stride && L.folded;
+    uint8_t *folded = L.folded;
+    if (stride) {
+        // (the general iteration may have changed any size since the lane
+        // last ran: nothing counts as folded)
+        memset(folded, 0, (size_t)hint_cols);
+        for (int64_t a = 0; a < A; a++) {
+            const int64_t c = order[a];
+            if (c >= hint_cols) continue;
+            const int64_t sz = col_size[c];
+            double d = fabs(crp_prior[sz] - cpr0[c]);
+            if (d > dmax) dmax = d;
+            if (sz >= 1) {
+                d = fabs(crp_prior[sz - 1] - cpr0[c]);
+                if (d > dmax) dmax = d;
+            }
+        }
+    }
+    int64_t strided = 0;
+    constexpr int STRIDE = 32;
+    // (a column whose size has changed: its priors are folded again)
+#define LANE_RESIZED(c_)                                                      \
+    if (stride && (c_) < hint_cols) {                                         \
+        folded[c_] = 0;                                                       \
+        const int64_t sz_ = col_size[c_];                                     \
+        double d_ = fabs(crp_prior[sz_] - cpr0[c_]);                          \
+        if (d_ > dmax) dmax = d_;                                             \
+        if (sz_ >= 1) {                                                       \
+            d_ = fabs(crp_prior[sz_ - 1] - cpr0[c_]);                         \
+            if (d_ > dmax) dmax = d_;                                         \
+        }                                                                     \
+    }
     while (pos < pos_end) {
+        if (stride) {
+            if (rng->pos >= 624) mt_refill(rng);
+            int64_t B = pos_end - pos;
+            if (B > STRIDE) B = STRIDE;
+            if (B > (624 - rng->pos) / 2) B = (624 - rng->pos) / 2;
+            if (drift > dmax) dmax = drift;
+            const double thr = 2.0 * dmax - margin + 1e-6;
+            int32_t cols[STRIDE];
+            int64_t n_ok = 0;
+            for (; n_ok < B; n_ok++) {
+                const int64_t p = pos + n_ok;
+                const uint64_t cell = (uint64_t)perm[p];
+                if (cell >= (uint64_t)N) break;
+                const uint64_t id = (uint64_t)assignment[cell];
+                if (id >= (uint64_t)N) break;
+                const int64_t c = col_of_id[id];
+                if ((uint64_t)c >= (uint64_t)hint_cols) break;
+                const bnpc_top2 &h = hint[in_order ? p : (int64_t)cell];
+                if ((int64_t)h.col != c || col_size[c] < 2
+                    || !(h.best - h.second > thr)
+                    || !(h.best - post_new[cell] > thr))
+                    break;
+                // its uniform, as mt_double will form it
+                const uint32_t *k = rng->key + rng->pos + 2 * n_ok;
+                uint32_t y0 = k[0], y1 = k[1];
+                y0 ^= (y0 >> 11);
+                y0 ^= (y0 << 7) & 0x9d2c5680u;
+                y0 ^= (y0 << 15) & 0xefc60000u;
+                y0 ^= (y0 >> 18);
+                y1 ^= (y1 >> 11);
+                y1 ^= (y1 << 7) & 0x9d2c5680u;
+                y1 ^= (y1 << 15) & 0xefc60000u;
+                y1 ^= (y1 >> 18);
+                const double u = ((int32_t)(y0 >> 5) * 67108864.0
+                                  + (int32_t)(y1 >> 6)) / 9007199254740992.0;
+                if (!(u > sliver && u < 1.0 - sliver)) break;
+                cols[n_ok] = (int32_t)c;
+            }
+            if (n_ok > 0) {
+                rng->pos += (int32_t)(2 * n_ok);
+                for (int64_t i = 0; i < n_ok; i++) {
+                    const int64_t c = cols[i];
+                    if (folded[c]) continue;
+                    folded[c] = 1;
+                    const int64_t sz = col_size[c];
+                    double d = fabs(crp_prior[sz - 1] - cpr0[c]);
+                    if (d > drift) drift = d;
+                    d = fabs(crp_prior[sz] - cpr0[c]);
+                    if (d > drift) drift = d;
+                }
+                pos += n_ok;
+                decided += n_ok;
+                strided += n_ok;
+                if (n_ok == B) continue;    // (else: the cell that ended the run)
+                if (pos >= pos_end) break;
+            }
+        }
         const int64_t cell = perm[pos];
         if (pos + 16 < pos_end) {
             const uint64_t ahead = (uint64_t)perm[pos + 16];
@@ -836,12 +961,18 @@ static void record_lane(RecordLane &L, bnpc_mt19937 *rng)
             const double d = fabs(now - cpr0[c]);
             if (d > drift) drift = d;
         }
+        if (c != old_col) {         // two columns have another size now
+            LANE_RESIZED(old_col)
+            LANE_RESIZED(c)
+        }
         pos++;
         decided++;
     }
+#undef LANE_RESIZED
     L.pos = pos;
     L.drift = drift;
     L.decided = decided;
+    L.strided = strided;
     L.pairs = pairs;
     L.triples = triples;
 }
@@ -1046,6 +1177,10 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
         lane.sliver = lane_sliver;
         // (the test switch widens the band of the picks as well)
         lane.band = lane_sliver > 1e-6 ? lane_sliver : 1e-6;
+        static thread_local std::vector<uint8_t> folded;
+        folded.assign((size_t)hint_cols + 1, 0);
+        lane.folded = folded.data();
+        lane.stride = sweep_lane_stride();
     }
     while (st->pos < st->pos_end) {
         bool lane_removed = false, lane_have_u = false;
@@ -1066,6 +1201,7 @@ static int sweep_window(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
             drift = lane.drift;
             st->hint_used += lane.decided;
             st->lane_used += lane.decided;
+            st->stride_used += lane.strided;
             st->pair_used += lane.pairs;
             st->triple_used += lane.triples;
             if (!lane.removed) {

@@ -1177,6 +1177,8 @@ class CRP:
         self._triple_used = getattr(self, '_triple_used', 0) \
             + int(st.triple_used)
         self._lane_used = getattr(self, '_lane_used', 0) + int(st.lane_used)
+        self._stride_used = getattr(self, '_stride_used', 0) \
+            + int(st.stride_used)
         self._swept = getattr(self, '_swept', 0) + (pos_end - pos)
         if tile_timing:
             print(f'[bnpc]   tile [{pos},{pos_end}) cols={cols.size} '
@@ -1402,12 +1404,13 @@ class CRP:
             'pair_used': getattr(self, '_pair_used', 0),
             'triple_used': getattr(self, '_triple_used', 0),
             'lane_used': getattr(self, '_lane_used', 0),
+            'stride_used': getattr(self, '_stride_used', 0),
             'native_moves': getattr(self, '_native_moves', 0),
             'native_steps': getattr(self, '_native_steps', 0)}
         nat = getattr(self, '_nat', None)
         if nat is not None:
             for key in ('swept', 'hint_used', 'pair_used', 'triple_used',
-                    'lane_used', 'native_moves'):
+                    'lane_used', 'stride_used', 'native_moves'):
                 out[key] += getattr(nat.st, key)
         # parameter batches whose draws a walker took ahead of them
         ctx = getattr(self, '_ctx', None)

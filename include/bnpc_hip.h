@@ -726,6 +726,12 @@ typedef struct bnpc_gibbs_state {
      * arithmetic, same stream: the result does not depend on it;
      * BNPC_SWEEP_LANE=0 switches it off). */
     int64_t lane_used;
+    /* out: of lane_used, the cells taken whole runs at a time (accumulated):
+     * cells dominated by the cluster they sit in, their uniforms peeked out
+     * of the state block and found clear of 0 and 1 - the lane's STRIDE
+     * (bnpc_sweeps.cpp: record_lane; off with the lane, or alone with
+     * BNPC_SWEEP_LANE=nostride). */
+    int64_t stride_used;
 } bnpc_gibbs_state;
 
 int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
@@ -899,6 +905,7 @@ typedef struct bnpc_chain {
     /* ---- running statistics ---- */
     int64_t swept, hint_used, pair_used, triple_used, native_moves, steps;
     int64_t lane_used;          /* of hint_used: bnpc_gibbs_state.lane_used */
+    int64_t stride_used;        /* of lane_used: bnpc_gibbs_state.stride_used */
     /* wall time by part of the step, ns / calls: 0 Gibbs, 1 split accepted,
      * 2 split rejected, 3 merge accepted, 4 merge rejected, 5 DP alpha,
      * 6 parameters, 7 error rates, 8 record, 9 of 0: the sweep waiting for

@@ -840,7 +840,7 @@ def test_screened_parameter_batch_equals_the_plain_batch():
             screen[declined & (rng.uniform(size=(G, M)) < frac)] = 0
             # ... and "accepted for certain" for some of the accepted ones
             screen[~declined & (rng.uniform(size=(G, M)) < frac)] = 2
-            for threads in (1, 3):
+            for threads in (1, 3, 8):
                 a = _lib.MHArgs()
                 new = np.empty((G, M), np.float32)
                 prior = np.empty((G, M))
@@ -861,14 +861,27 @@ def test_screened_parameter_batch_equals_the_plain_batch():
                 a.log_prob, a.declined = lp.ctypes.data, dec.ctypes.data
                 a.threads = threads
                 a.screen = screen.ctypes.data
-                status = C.c_int(0)
-                _lib.check(_lib.load().bnpc_mh_batch(C.addressof(table), None,
-                    C.byref(a), C.byref(status)), 'mh_batch')
-                assert status.value == 0
-                assert np.array_equal(new, plain[1])
-                assert np.array_equal(dec, plain[3])
-                if not uniform:
-                    assert np.array_equal(prior, plain[4])
+                # the densities' sum in index order, made by the team's last
+                # rank behind the others (bnpc_mh_args.prior_seq_sum): from
+                # the first entry (NaN on entry) or continued from a value
+                for start in (np.nan, -12.5):
+                    seq = np.array([start])
+                    a.prior_seq_sum = seq.ctypes.data
+                    status = C.c_int(0)
+                    _lib.check(_lib.load().bnpc_mh_batch(C.addressof(table),
+                        None, C.byref(a), C.byref(status)), 'mh_batch')
+                    assert status.value == 0
+                    assert np.array_equal(new, plain[1])
+                    assert np.array_equal(dec, plain[3])
+                    if not uniform:
+                        assert np.array_equal(prior, plain[4])
+                        flat = plain[4].ravel()
+                        want = flat[0] if np.isnan(start) else start + flat[0]
+                        for v in flat[1:]:
+                            want = want + v     # one accumulator, index order
+                        assert seq[0] == want, (threads, start)
+                    else:
+                        assert np.isnan(seq[0]) or seq[0] == start
     # a screened batch cannot take draws itself, nor be scored
     a.trans_prob = 0
     st, _ = _lib.rng_export()

@@ -105,7 +105,7 @@ def native_gibbs(ll0, post_new, crp_prior, assignment, sizes, new_columns,
     if used is not None:
         used.append(int(st.hint_used))
         native_gibbs.last = (int(st.hint_used), int(st.pair_used),
-            int(st.triple_used), int(st.lane_used))
+            int(st.triple_used), int(st.lane_used), int(st.stride_used))
     live = order[:st.n_active]
     return assignment, {int(col_id[c]): int(col_size[c]) for c in live}, n_new
 
@@ -650,7 +650,7 @@ def test_sweep_hints_fuzz(monkeypatch):
     born under the hint.  Same assignments, cluster tables, births, stream;
     most cells are decided without a scan."""
     decided = cells = pairs = triples = 0
-    in_lane = {}
+    in_lane, in_stride = {}, {}
     for seed in range(200):
         rng = np.random.RandomState(7000 + seed)
         N = int(rng.choice([30, 90, 200]))
@@ -679,6 +679,13 @@ def test_sweep_hints_fuzz(monkeypatch):
         crp_prior = np.append(0, O.CRP.log_CRP_prior(
             np.append(np.arange(1, N + 1), alpha), N, alpha))
         labels = rng.randint(0, K, N)
+        if seed % 3 == 0:
+            # a settled chain: nine cells in ten sit in the cluster that
+            # dominates them (what the lane's stride takes in runs) - with
+            # winners far enough above the rest for the dominance margin
+            labels = np.where(rng.random_sample(N) < 0.9, a, labels)
+            clear = ~two & ~three
+            ll[clear, a[clear]] += 40
         labels[:K] = np.arange(K)
         ids = rng.permutation(N)[:K]
         assignment = ids[labels]
@@ -695,7 +702,8 @@ def test_sweep_hints_fuzz(monkeypatch):
                 ((hint, col_prior), True, None),
                 ((hint, col_prior), True, '0'),
                 ((hint, col_prior), seed % 2 == 0, '0.05'),
-                ((hint, col_prior), seed % 2 == 1, '0.3')):
+                ((hint, col_prior), seed % 2 == 1, '0.3'),
+                ((hint, col_prior), seed % 2 == 0, 'nostride')):
             # (lane: BNPC_SWEEP_LANE - the lane of the cells decided from
             # their records switched off, or handing a share of its cells
             # over to the general iteration with their uniforms drawn)
@@ -710,11 +718,14 @@ def test_sweep_hints_fuzz(monkeypatch):
                 np.random.random(2)))
             if h is not None:
                 in_lane[lane] = in_lane.get(lane, 0) + native_gibbs.last[3]
+                in_stride[lane] = in_stride.get(lane, 0) \
+                    + native_gibbs.last[4]
         for other in outs[1:]:
             assert np.array_equal(outs[0][0], other[0]), seed
             assert outs[0][1] == other[1] and outs[0][2] == other[2], seed
             assert np.array_equal(outs[0][3], other[3]), seed
-        assert used[1] == used[2] == used[3] == used[4] == used[5], seed
+        assert used[1] == used[2] == used[3] == used[4] == used[5] \
+            == used[6], seed
         decided += used[1]
         pairs += native_gibbs.last[1]
         triples += native_gibbs.last[2]
@@ -725,6 +736,15 @@ def test_sweep_hints_fuzz(monkeypatch):
     # when it hands cells over, nothing when it is switched off
     assert in_lane[None] > 0.25 * 2 * cells, (in_lane, cells)
     assert in_lane['0'] == 0 and 0 < in_lane['0.3'] < in_lane[None], in_lane
+    # ... and the lane's stride (runs of cells that stay where they are): a
+    # good share of the lane's cells in the settled sweeps, fewer when every
+    # third uniform ends a run, none when it is switched off - the lane then
+    # takes the same cells one by one
+    assert in_stride[None] > 0.1 * in_lane[None], (in_stride, in_lane)
+    assert 0 < in_stride['0.3'] < in_stride[None] / 2, in_stride
+    assert in_stride['nostride'] == 0 and in_stride['0'] == 0, in_stride
+    assert in_lane['nostride'] * 2 == in_lane[None] \
+        or in_lane['nostride'] > 0.45 * in_lane[None], in_lane
 
 
 @pytest.mark.parametrize('K', [65, 150, 400, 1500])

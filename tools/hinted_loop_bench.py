@@ -78,5 +78,5 @@ print(f'N={N} K={K} pairs={pairs} triples={triples}: min '
     f'{1e9 * times[0] / N:.1f} median {1e9 * times[reps // 2] / N:.1f} '
     f'ns/cell ({1e6 * times[reps // 2]:.1f} us/sweep); from the records '
     f'{st.hint_used}, between two {st.pair_used}, among three '
-    f'{st.triple_used}, in the lane {st.lane_used}, moved '
+    f'{st.triple_used}, in the lane {st.lane_used} (in runs {st.stride_used}), moved '
     f'{int((assignment != truth).sum())}')
