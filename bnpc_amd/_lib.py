@@ -455,8 +455,12 @@ def host_share(n_chains, n_devices, nodes=None):
 # fewer it gives idle ranks back after 5 us and wakes a rank per 12 blocks
 # (1.4 busy threads).  Round 5 keyed this on "shares a node" - on the target
 # (8 GPUs, 2 x 64 cores: 4 chains per node, 32 logical CPUs each) every chain
-# then ran the frugal settings with 28 CPUs idle.
-GREEDY_MIN_CPUS = 8
+# then ran the frugal settings with 28 CPUs idle.  Round 6, ranks of bench.py
+# sharing the one GPU and one node of a box (profiles/r06/
+# bench_ranks_sharing_one_gpu.jsonl; rule against frugal forced): 2 ranks (64
+# CPUs each) 4167 / 4171 steps/s, 4 ranks (32 each: the target's share) 8267 /
+# 8172, 8 ranks (16 each) 8789 / 10 967 - the line lies between 16 and 32.
+GREEDY_MIN_CPUS = 24
 
 
 def node_cpus(nodes=None):

@@ -4157,7 +4157,10 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
     ARGCHK(c && a && status, "NULL argument");
     if (!mh_screen_applies(c, a)) {
         ARGCHK(!pending, "counts still pending");
-        mh_ahead_drop(c);
+        // (the step's parameter batch without its screen: a walker's draws
+        // are not wanted - the scored batch of a move, counts_src 1, runs
+        // WHILE one walks and leaves it alone)
+        if (counts_src == 0) mh_ahead_drop(c);
         return bnpc_mh_batch(k, rng, a, status);
     }
     if (int rc = mh_screen_argchk(c, a)) return rc;

@@ -28,14 +28,14 @@ unset BNPC_HOST_SPIN_US
 cat $out/bench_ranks_sharing_one_gpu.jsonl
 # device or host?  one rank traced alone ...
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/trace_alone -o alone -- python3 $GRAFT_REPO_ROOT/bench.py $args > $GRAFT_REPO_ROOT/$out/bench_traced_alone.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$out/trace_alone -o alone -- python3 $GRAFT_REPO_ROOT/bench.py $args > $GRAFT_REPO_ROOT/$out/bench_traced_alone.json 2> /dev/null
 # ... and next to 7 untraced ranks' worth of load (7 independent chains on the
 # same GPU, started first; the traced one runs while they do)
 for r in 1 2 3 4 5 6 7; do
-  (cd $GRAFT_REPO_ROOT && BNPC_HOST_SHARE=8 python3 bench.py --cpu-steps 0 --sustained-steps 0 --device-steps 0 --steps 6000 > /dev/null 2>&1) &
+  (cd $GRAFT_REPO_ROOT && BNPC_HOST_SHARE=8 BNPC_HOST_SPIN_US=5 python3 bench.py --cpu-steps 0 --sustained-steps 0 --device-steps 0 --steps 6000 > /dev/null 2>&1) &
 done
 sleep 4
-BNPC_HOST_SHARE=8 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$out/trace_with7 -o with7 -- python3 $GRAFT_REPO_ROOT/bench.py $args > $GRAFT_REPO_ROOT/$out/bench_traced_with7.json 2> /dev/null
+BNPC_HOST_SHARE=8 BNPC_HOST_SPIN_US=5 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$out/trace_with7 -o with7 -- python3 $GRAFT_REPO_ROOT/bench.py $args > $GRAFT_REPO_ROOT/$out/bench_traced_with7.json 2> /dev/null
 wait
 cd $GRAFT_REPO_ROOT
 python3 tools/queueing_from_trace.py $out/trace_alone $out/trace_with7 > $out/queueing.txt 2>&1
