@@ -78,25 +78,11 @@ int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
                                                  bnpc_legacy_gauss *)> &prelude,
                         int64_t rows, int64_t M, int64_t n_sd, bool *posted);
 void bnpc_mh_ahead_drop(bnpc_ctx *c);
-// What the stream still goes through inside a split / merge move from the
-// point where the rest of its way is known (bnpc_moves.cpp): `doubles_first`
-// uniforms (the scored scan's picks, one per cell), `rows` times [choice(sd,
-// M): M masked-rejection draws, 2 M uniforms] (the scored parameter batch),
-// `choice_n` more masked-rejection draws (the reverse proposal's widths), then
-// `uniforms_after` uniforms (the acceptance test: 1 - assumed when the scan's
-// outcome is not known yet).  A walker goes through them on a copy of the
-// stream (bnpc_step.cpp: params_ahead).
-struct bnpc_move_tail {
-    int64_t doubles_first, rows, choice_n, uniforms_after;
-};
-// bnpc_moves.cpp: called by the NEXT bnpc_sm_move of this thread at that
-// point - for a split right after the scored scan's permutation, for a merge
-// after its last intermediate scan; consumed by that call.  NULL: nothing.
-void bnpc_move_tail_hook(const std::function<void(const bnpc_move_tail &)> *hook);
-// bnpc_sweeps.cpp: called by the NEXT unscored-or-scored bnpc_rg_scan (mode 0)
-// of this thread right after it has drawn its visiting order; consumed by
+// bnpc_moves.cpp: called by the NEXT bnpc_sm_move of this thread right after
+// the move's last draw of variable length, with the number of uniforms that
+// still follow inside the move (its acceptance test: 0 or 1); consumed by
 // that call.  NULL: nothing.
-void bnpc_rg_scan_order_hook(const std::function<void()> *hook);
+void bnpc_move_last_draw_hook(const std::function<void(int)> *hook);
 #endif
 // bnpc_ll_theta in two halves (bnpc_kernels.hip): the caller works between
 // them - bnpc_sm_move draws the third Beta row under the first scan's sums

@@ -21,7 +21,6 @@
 #include <time.h>
 #include <algorithm>
 #include <cstring>
-#include <functional>
 #include <vector>
 
 #include "bnpc_internal.h"
@@ -233,15 +232,13 @@ extern "C" int bnpc_move_propose(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     return 0;
 }
 
-// What the NEXT bnpc_sm_move of this thread calls at the point from which the
-// rest of the stream's way through the move is known (bnpc_internal.h);
-// consumed by that call.
-static thread_local const std::function<void(const bnpc_move_tail &)>
-    *g_tail_hook = nullptr;
+// What the NEXT bnpc_sm_move of this thread calls right after its last draw
+// of variable length (bnpc_internal.h); consumed by that call.
+static thread_local const std::function<void(int)> *g_last_draw_hook = nullptr;
 
-void bnpc_move_tail_hook(const std::function<void(const bnpc_move_tail &)> *hook)
+void bnpc_move_last_draw_hook(const std::function<void(int)> *hook)
 {
-    g_tail_hook = hook;
+    g_last_draw_hook = hook;
 }
 
 extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
@@ -257,8 +254,8 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     }
     *status = 1;
     st->accepted = 0;
-    const std::function<void(const bnpc_move_tail &)> *tail_hook = g_tail_hook;
-    g_tail_hook = nullptr;
+    const std::function<void(int)> *last_draw = g_last_draw_hook;
+    g_last_draw_hook = nullptr;
     bnpc_legacy_gauss *gauss = (bnpc_legacy_gauss *)st->gauss;
     Restore restore(rng, gauss);    // undone below when the move completes
     static thread_local Scratch s;
@@ -463,22 +460,9 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         mh.new_theta = fresh;
         // (the merged cluster's row is not part of the scored scan)
         memcpy(fresh + 2 * M, rows + 2 * M, (size_t)M * sizeof(float));
-        // Once the scored scan has drawn its visiting order, the stream's way
-        // through the rest of the move is known but for one thing: S picks,
-        // the scored batch of the two rows, the widths of the reverse
-        // proposal, and the acceptance test's uniform - not drawn when the
-        // scan leaves a side empty, which a walker started here cannot know
-        // (it assumes the uniform; a batch that finds the stream elsewhere
-        // draws for itself).
-        const std::function<void()> at_order = [&]() {
-            const bnpc_move_tail tail = {S, 2, M, 1};
-            (*tail_hook)(tail);
-        };
-        if (tail_hook) bnpc_rg_scan_order_hook(&at_order);
         rc = bnpc_rg_scan_step_with(ctx, k, rng, st->view, n, s.rg.data(),
                                     st->DP_a, &mh, n1, n0, &scan_prob, &sub,
                                     ll_first);
-        bnpc_rg_scan_order_hook(nullptr);
         ll_first = nullptr;
         if (rc) return rc;
         if (sub) return 0;
@@ -489,6 +473,12 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         // np.random.choice(sd, size=M); the reverse move's parameter
         // proposal: the merged launch row -> the cluster's own row
         mt_fill_interval32(rng, (uint32_t)(st->n_sd - 1), s.sd_idx.data(), M);
+        // (all that the stream still gives inside this move: the uniform of
+        // its acceptance test, unless the scan left a side empty)
+        if (last_draw) {
+            const int64_t ones_now = rg_ones();
+            (*last_draw)(ones_now != 0 && ones_now != S ? 1 : 0);
+        }
         s.std2.resize((size_t)2 * M);
         for (int64_t m = 0; m < M; m++) s.std2[m] = st->sd[s.sd_idx[m]];
         const int64_t cl = st->ids[pos_i];
@@ -602,13 +592,6 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         // the scored update of the merged launch row (libs/CRP.py:581-587)
         const int64_t cl_i = st->ids[pos_i], cl_j = st->ids[pos_j];
         double gs_merge = 0.0;
-        // (the rest of the stream's way through the move: the scored update
-        // of the merged row, the widths of the reverse proposal's two rows,
-        // the acceptance test's uniform)
-        if (tail_hook) {
-            const bnpc_move_tail tail = {0, 1, 2 * M, 1};
-            (*tail_hook)(tail);
-        }
         {
             bnpc_mh_args one = mh;
             one.G = 1;
@@ -627,6 +610,7 @@ extern "C" int bnpc_sm_move(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         // _rg_get_split_prob (libs/CRP.py:777-820)
         mt_fill_interval32(rng, (uint32_t)(st->n_sd - 1), s.sd_idx.data(),
                            2 * M);
+        if (last_draw) (*last_draw)(1);     // (the acceptance test's uniform)
         s.std2.resize((size_t)2 * M);
         for (int64_t m = 0; m < 2 * M; m++) s.std2[m] = st->sd[s.sd_idx[m]];
         memcpy(s.gather.data(), st->parameters + cl_i * st->param_stride,

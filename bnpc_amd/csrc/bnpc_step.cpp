@@ -260,39 +260,21 @@ int alpha_draws(const bnpc_host_kernels *k, bnpc_mt19937 *rng,
 // somewhere else, and the batch draws for itself.
 void params_ahead(bnpc_ctx *ctx, const bnpc_host_kernels *k,
                   const bnpc_mt19937 *rng, const bnpc_chain *ch,
-                  const bnpc_move_tail &tail)
+                  int64_t doubles)
 {
     if (ch->fix_assign) return;
     const double dpa_prob = ch->dpa_prob;
     const AlphaArgs args = {ch->DP_a, ch->dpa_shape, ch->dpa_rate, ch->N,
                             ch->K};
-    const int64_t M = ch->M;
-    const uint32_t sd_max = (uint32_t)(ch->n_sd - 1);
-    const auto way = [k, tail, M, sd_max, dpa_prob, args](
-                         bnpc_mt19937 *r, bnpc_legacy_gauss *g) {
+    const auto way = [k, doubles, dpa_prob, args](bnpc_mt19937 *r,
+                                                  bnpc_legacy_gauss *g) {
         // (2 words per uniform: whole state blocks are skipped untempered)
-        auto skip_doubles = [r](int64_t n) {
-            for (int64_t left = 2 * n; left > 0;) {
-                if (r->pos >= 624) mt_refill(r);
-                const int64_t take = std::min<int64_t>(624 - r->pos, left);
-                r->pos += (int32_t)take;
-                left -= take;
-            }
-        };
-        // (masked-rejection draws take as many words as they take: drawn)
-        std::vector<int32_t> sink;
-        auto choices = [r, sd_max, &sink](int64_t n) {
-            if (n <= 0) return;
-            sink.resize((size_t)n);
-            mt_fill_interval32(r, sd_max, sink.data(), n);
-        };
-        skip_doubles(tail.doubles_first);
-        for (int64_t row = 0; row < tail.rows; row++) {
-            choices(M);
-            skip_doubles(2 * M);
+        for (int64_t left = 2 * doubles; left > 0;) {
+            if (r->pos >= 624) mt_refill(r);
+            const int64_t take = std::min<int64_t>(624 - r->pos, left);
+            r->pos += (int32_t)take;
+            left -= take;
         }
-        choices(tail.choice_n);
-        skip_doubles(tail.uniforms_after);
         if (mt_double(r) < dpa_prob) {
             double alpha;
             if (alpha_draws(k, r, g, args, &alpha)) return false;
@@ -312,6 +294,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
                 bnpc_chain *ch, Work &w, bool *done)
 {
     *done = false;
+    const Clock::time_point tg_in = Clock::now();
     const int64_t N = ch->N, M = ch->M, K = ch->K;
     // (births write their rows into `parameters` M floats apart)
     // (any number of clusters whose whole matrix fits the host budget: the
@@ -383,10 +366,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     if (rc) return rc;
     // from here to the parameter batch the stream gives one uniform per cell
     // (and whatever a birth draws: then the walker's work is dropped)
-    if (ch->phase == BNPC_PHASE_ASSIGN) {
-        const bnpc_move_tail picks = {N, 0, 0, 0};
-        params_ahead(ctx, k, rng, ch, picks);
-    }
+    if (ch->phase == BNPC_PHASE_ASSIGN) params_ahead(ctx, k, rng, ch, N);
     // under the launches: the sweep's private state
     w.assign.assign(ch->assignment, ch->assignment + N);
     w.col_of_id.assign((size_t)N, -1);
@@ -495,17 +475,7 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
         w.rows_current = false;
         st.new_cell = -1;
     }
-    if (trace_g) {
-        auto us = [](Clock::time_point a, Clock::time_point b) {
-            return std::chrono::duration_cast<std::chrono::nanoseconds>(
-                b - a).count() / 1e3;
-        };
-        fprintf(stderr, "[gibbs] N=%lld K=%lld: rows "
-                "%.1f, issue %.1f, order + hints issue + state %.1f, wait "
-                "%.1f, loop %.1f us\n", (long long)N, (long long)K,
-                us(tg0, tg1), us(tg1, tg2), us(tg2, tg3), us(tg3, tg4),
-                us(tg4, Clock::now()));
-    }
+    const Clock::time_point tg5 = Clock::now();
     // commit: the live clusters in dict order, the new labels
     for (int64_t a = 0; a < st.n_active; a++) {
         const int64_t col = w.order[a];
@@ -525,6 +495,18 @@ int gibbs_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     ch->lane_used += st.lane_used;
     ch->stride_used += st.stride_used;
     std::vector<double>().swap(w.heap_ll);
+    if (trace_g) {
+        auto us = [](Clock::time_point a, Clock::time_point b) {
+            return std::chrono::duration_cast<std::chrono::nanoseconds>(
+                b - a).count() / 1e3;
+        };
+        fprintf(stderr, "[gibbs] N=%lld K=%lld: new-cluster term + priors "
+                "%.1f, rows %.1f, issue %.1f, order + hints issue + state "
+                "%.1f, wait %.1f, loop %.1f, commit %.1f us\n", (long long)N,
+                (long long)K, us(tg_in, tg0), us(tg0, tg1), us(tg1, tg2),
+                us(tg2, tg3), us(tg3, tg4), us(tg4, tg5),
+                us(tg5, Clock::now()));
+    }
     *done = true;
     return 0;
 }
@@ -564,16 +546,15 @@ int move_phase(bnpc_ctx *ctx, const bnpc_host_kernels *k, bnpc_mt19937 *rng,
     st.fill = ch->mix0;
     st.gauss = ch->gauss;
     int sub = 1;
-    // (from the point where the rest of the stream's way through the move is
-    // known, then on to the parameter batch as after a sweep)
-    const std::function<void(const bnpc_move_tail &)> tail_known =
-        [&](const bnpc_move_tail &tail) {
-            if (ch->phase == BNPC_PHASE_ASSIGN)
-                params_ahead(ctx, k, rng, ch, tail);
-        };
-    bnpc_move_tail_hook(&tail_known);
+    // (after the move's last draw of variable length: its acceptance test,
+    // then the way to the parameter batch as after a sweep)
+    const std::function<void(int)> last_draw = [&](int uniforms_left) {
+        if (ch->phase == BNPC_PHASE_ASSIGN)
+            params_ahead(ctx, k, rng, ch, uniforms_left);
+    };
+    bnpc_move_last_draw_hook(&last_draw);
     const int rc = bnpc_sm_move(ctx, k, rng, &st, &sub);
-    bnpc_move_tail_hook(nullptr);
+    bnpc_move_last_draw_hook(nullptr);
     if (rc || sub) bnpc_mh_ahead_drop(ctx);
     if (rc) return rc;
     if (sub) return 0;

@@ -32,7 +32,6 @@
 #include <vector>
 
 #include "bnpc_hip.h"
-#include <functional>
 #include "bnpc_internal.h"
 
 extern "C" double bnpc_mt_random_sample(bnpc_mt19937 *rng)
@@ -1724,15 +1723,6 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 // ---------------------------------------------------------------------------
 // restricted Gibbs 2-way scans (CRP.py:609-632 and :800-820)
 // ---------------------------------------------------------------------------
-// What the NEXT bnpc_rg_scan (mode 0) of this thread calls right after its
-// visiting order is drawn (bnpc_internal.h); consumed by that call.
-static thread_local const std::function<void()> *g_scan_order_hook = nullptr;
-
-void bnpc_rg_scan_order_hook(const std::function<void()> *hook)
-{
-    g_scan_order_hook = hook;
-}
-
 extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
                             const double *ll, double DP_a,
                             int64_t *rg_assignment, const int64_t *target,
@@ -1749,10 +1739,6 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
     std::vector<double> prob(S, 0.0);
     if (mode == 0) {
         bnpc_mt_permutation(rng, S, perm.data());
-        // (from here the scan takes exactly one uniform per cell)
-        const std::function<void()> *hook = g_scan_order_hook;
-        g_scan_order_hook = nullptr;
-        if (hook) (*hook)();
     } else {
         for (int64_t s = 0; s < S; s++) perm[s] = s;
     }
