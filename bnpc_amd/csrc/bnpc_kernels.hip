@@ -137,7 +137,6 @@ struct View {
 struct Tunables {
     int msplit = 1;                 // BNPC_MSPLIT: mutation-split small launches
     int force_kw = 0;               // BNPC_KW: force the cluster tile (tests)
-    int narrow_any = 0;             // BNPC_KW = 16: see read_tunables
     int zero_copy = 1;              // BNPC_ZERO_COPY: small payloads are read /
                                     // written in place in pinned host memory
     int mask_counts_max = 64;       // BNPC_MASK_COUNTS_MAX: segments for the
@@ -186,10 +185,6 @@ struct Tunables {
                                     // record)
 #define HINT_THROUGH_MAX 1024       // ... up to which rows that will be scanned
                                     // are written through to the host
-#define NARROW_MIN_WORK 2e9         // cells x clusters x mutations from which a
-                                    // split launch gives its last 1 ... 4
-                                    // columns to the narrow kernel on a second
-                                    // stream (two events, ~10 us of host time)
 #define LDS_TABLE_MIN_M 3072        // k_ll8_lds: mutations (padded) from which,
 #define LDS_TABLE_MIN_WGS 4096      // ... and workgroups from which it wins
 
@@ -203,10 +198,6 @@ static void read_tunables(Tunables &t)
 {
     t.msplit = env_int("BNPC_MSPLIT", 1);
     t.force_kw = env_int("BNPC_KW", 0);
-    // (16: the default tiles, and the narrow last group at ANY launch size -
-    // tests; by default only where the launch is long enough to pay for the
-    // second stream: NARROW_MIN_WORK)
-    t.narrow_any = t.force_kw == 16;
     if (t.force_kw != 1 && t.force_kw != 2 && t.force_kw != 4
         && t.force_kw != 8)
         t.force_kw = 0;
@@ -271,10 +262,6 @@ struct bnpc_ctx {
     // issued tile occupies the main stream - they must not queue behind it
     hipStream_t side_stream = nullptr;
     DevBuf side_theta, side_tabs, side_out, side_part;
-    // the narrow last cluster group of a long split launch runs beside the
-    // groups of 8 on a stream of its own (issue_ll)
-    hipStream_t narrow_stream = nullptr;
-    hipEvent_t narrow_ev[2] = {};
     // pinned staging arena for small host <-> device payloads (parameter
     // rows, cell lists, counts): a copy from/to pinned memory is a plain DMA
     // enqueue, a copy from/to pageable memory is staged by the runtime at
@@ -1080,56 +1067,6 @@ __device__ __forceinline__ void ll_step8(double (&a)[8],
           "s"(t[15]));
 }
 
-// The same for the NARROW last group of a launch (round 6): 4 or 2 clusters
-// per slot block - a wave then takes 4 or 8 blocks, the same 16 accumulators
-// and 32 masked adds per mutation, so that K = 50 costs 6 groups of 8 and a
-// quarter of one instead of 7.  t: [0, KW) = L1, [KW, 2 KW) = L0.
-__device__ __forceinline__ void ll_step4(double (&a)[4],
-                                         const ulonglong2 &m,
-                                         const double (&t)[8])
-{
-    asm volatile(
-        "s_mov_b64 exec, %4\n\t"
-        "v_add_f64 %0, %0, %6\n\t"
-        "v_add_f64 %1, %1, %7\n\t"
-        "v_add_f64 %2, %2, %8\n\t"
-        "v_add_f64 %3, %3, %9\n\t"
-        "s_mov_b64 exec, %5\n\t"
-        "v_add_f64 %0, %0, %10\n\t"
-        "v_add_f64 %1, %1, %11\n\t"
-        "v_add_f64 %2, %2, %12\n\t"
-        "v_add_f64 %3, %3, %13\n\t"
-        "s_mov_b64 exec, -1"
-        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
-        : "s"(m.x), "s"(m.y), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]),
-          "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]));
-}
-
-__device__ __forceinline__ void ll_step2(double (&a)[2],
-                                         const ulonglong2 &m,
-                                         const double (&t)[4])
-{
-    asm volatile(
-        "s_mov_b64 exec, %2\n\t"
-        "v_add_f64 %0, %0, %4\n\t"
-        "v_add_f64 %1, %1, %5\n\t"
-        "s_mov_b64 exec, %3\n\t"
-        "v_add_f64 %0, %0, %6\n\t"
-        "v_add_f64 %1, %1, %7\n\t"
-        "s_mov_b64 exec, -1"
-        : "+v"(a[0]), "+v"(a[1])
-        : "s"(m.x), "s"(m.y), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]));
-}
-
-template <int KW>
-__device__ __forceinline__ void ll_stepk(double (&a)[KW], const ulonglong2 &m,
-                                         const double (&t)[2 * KW])
-{
-    if constexpr (KW == 8) ll_step8(a, m, t);
-    else if constexpr (KW == 4) ll_step4(a, m, t);
-    else ll_step2(a, m, t);
-}
-
 // One mutation for 8 clusters, the table values in VGPRs (every lane holds
 // the same 16 doubles: broadcast LDS reads) - the step of k_ll8_lds.
 __device__ __forceinline__ void ll_step8v(double (&a)[8],
@@ -1303,23 +1240,19 @@ __global__ __launch_bounds__(256) void k_ll8_lds(
 // first sweep, tiles).  SPLIT = true: the mutation-split form for small
 // launches (partial sums + k_ll_combine).  Two symbols, so that per-kernel
 // profiles do not mix millisecond launches with microsecond ones.
-// KW = 8; KW = 4 / 2 (CB = 4 / 8): the narrow LAST group of a launch whose
-// cluster count leaves 1 ... 4 columns over - same table rows (16 doubles per
-// mutation, the group's first KW L1 and L0 entries are read), same order.
-// n_groups: groups this launch covers, from group g_offset on.
-template <int CB, bool SPLIT, int KW = 8>
+template <int CB, bool SPLIT>
 __global__ __launch_bounds__(256) void k_ll8_asm(
     const ulonglong2 *__restrict__ masks, int Mpad, int Mt, long long n,
     long long nblk, const double *__restrict__ T, int K, long long ldo,
     double *__restrict__ out, int xcd_remap, int MS_arg, int m_chunk,
-    const ulonglong2 *masks_pf, const double *T_pf, DoneSignal done,
-    int n_groups, int g_offset)
+    const ulonglong2 *masks_pf, const double *T_pf, DoneSignal done)
 {
     // masks_pf / T_pf: the same two arrays again, or NULL (no prefetch).  The
     // prefetch below hands addresses to inline assembly; were they derived
     // from the __restrict__ parameters, the compiler would have to assume the
     // assembly may write there and would turn every SCALAR load of the kernel
     // into a vector load.
+    constexpr int KW = 8;
     const bool PF = masks_pf != nullptr;
     const int MS = SPLIT ? MS_arg : 1;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1333,8 +1266,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     ll_tile_coords(SPLIT
             ? (unsigned)((nblk + CB - 1) / CB) * (unsigned)MSq
             : (unsigned)((nblk + 4 * CB - 1) / (4 * CB)),
-        (unsigned)n_groups, xcd_remap, bx, g);
-    g += g_offset;
+        (unsigned)((K + KW - 1) / KW), xcd_remap, bx, g);
     const int q = SPLIT ? (int)(bx % MSq) : 0;  // chunk quad of this workgroup
     if (SPLIT) bx /= MSq;
     const int ms = SPLIT ? q * 4 + wave : 0;    // mutation chunk of this wave
@@ -1356,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
         mo[c] = (size_t)((blk0 + c < nblk) ? blk0 + c : blk0) * Mpad
             + (m_len > 0 ? m_begin : 0);
     const size_t t_off = ((size_t)g * Mt + (m_len > 0 ? m_begin : 0))
-        * 16;                           // of this wave's first table stage
+        * (2 * KW);                     // of this wave's first table stage
     const double *__restrict__ tp = T + t_off;
 
     double acc[CB][KW];
@@ -1413,36 +1345,31 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
     }
     if (PF && m_len > 0) PF_BLOCK(0)
 
-    // a mutation's table row is 16 doubles: L1 of the group's 8 clusters,
-    // then L0; a narrow group reads the first KW of each
     ulonglong2 ma[CB], mb[CB];
-    double ta[2 * KW], tb[2 * KW];
-#define T_ROW(DST, BASE)                                                      \
-    _Pragma("unroll") for (int j = 0; j < KW; j++) {                          \
-        DST[j] = tp[(BASE) + j];                                              \
-        DST[KW + j] = tp[(BASE) + 8 + j];                                     \
-    }
+    double ta[16], tb[16];
 #pragma unroll
     for (int c = 0; c < CB; c++) ma[c] = masks[mo[c]];
-    T_ROW(ta, 0)
+#pragma unroll
+    for (int j = 0; j < 16; j++) ta[j] = tp[j];
 
     for (int m = 0; m < m_len; m += 2) {        // chunks are multiples of 8
         if (PF && (m & 63) == 0 && m + 64 < m_len) PF_BLOCK(m + 64)
         __builtin_amdgcn_s_waitcnt(0xC07F);     // stage A landed
 #pragma unroll
         for (int c = 0; c < CB; c++) mb[c] = masks[mo[c] + m + 1];
-        T_ROW(tb, 16)
 #pragma unroll
-        for (int c = 0; c < CB; c++) ll_stepk<KW>(acc[c], ma[c], ta);
+        for (int j = 0; j < 16; j++) tb[j] = tp[16 + j];
+#pragma unroll
+        for (int c = 0; c < CB; c++) ll_step8(acc[c], ma[c], ta);
         __builtin_amdgcn_s_waitcnt(0xC07F);     // stage B landed
 #pragma unroll
         for (int c = 0; c < CB; c++) ma[c] = masks[mo[c] + m + 2];
-        T_ROW(ta, 32)
 #pragma unroll
-        for (int c = 0; c < CB; c++) ll_stepk<KW>(acc[c], mb[c], tb);
+        for (int j = 0; j < 16; j++) ta[j] = tp[32 + j];
+#pragma unroll
+        for (int c = 0; c < CB; c++) ll_step8(acc[c], mb[c], tb);
         tp += 32;
     }
-#undef T_ROW
 #undef PF_BLOCK
 #undef PF_TAB
 
@@ -1464,10 +1391,10 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
             const double s = ((red[0][ck][lane] + red[1][ck][lane])
                 + red[2][ck][lane]) + red[3][ck][lane];
             const long long slot = (blk0 + c) * 64 + lane;
-            if (blk0 + c < nblk && slot < n && g * 8 + j < K) {
+            if (blk0 + c < nblk && slot < n && g * KW + j < K) {
                 double *o = (MSq > 1)
-                    ? out + ((size_t)q * n + slot) * K + (size_t)g * 8
-                    : out + (size_t)slot * ldo + (size_t)g * 8;
+                    ? out + ((size_t)q * n + slot) * K + (size_t)g * KW
+                    : out + (size_t)slot * ldo + (size_t)g * KW;
                 o[j] = s;
             }
         }
@@ -1477,10 +1404,10 @@ __global__ __launch_bounds__(256) void k_ll8_asm(
         for (int c = 0; c < CB; c++) {
             const long long slot = (blk0 + c) * 64 + lane;
             if (blk0 + c < nblk && slot < n) {
-                double *o = out + (size_t)slot * ldo + (size_t)g * 8;
+                double *o = out + (size_t)slot * ldo + (size_t)g * KW;
 #pragma unroll
                 for (int j = 0; j < KW; j++)
-                    if (g * 8 + j < K) o[j] = acc[c][j];
+                    if (g * KW + j < K) o[j] = acc[c][j];
             }
         }
     }
@@ -2472,9 +2399,6 @@ extern "C" int bnpc_destroy(bnpc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    if (c->narrow_stream) (void)hipStreamDestroy(c->narrow_stream);
-    for (hipEvent_t e : c->narrow_ev)
-        if (e) (void)hipEventDestroy(e);
     delete c;
     return 0;
 }
@@ -2729,42 +2653,6 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     const int64_t split2 = ((v.nblk + 1) / 2) * G * MSq;
     const int64_t split1 = v.nblk * G * MSq;
     int planes = MS;
-    // The narrow last group (round 6): K = 50 used to cost 7
-    // groups of 8 columns - 56 computed for 50.  Where the launch is long
-    // enough, the last 1 ... 4 columns go to a kernel of their own - 4 slot
-    // blocks x 4 (or 2) clusters per wave, the same table rows, the same
-    // order - on a second stream beside the groups of 8: the tables are made
-    // first (event 0), the partial planes are complete when both have run
-    // (event 1, before the combine pass).
-    int64_t G_main = G;
-    int narrow_kw = 0;
-    if (KW == 8 && MS > 1 && MSq > 1 && K > 8 && K % 8 >= 1 && K % 8 <= 4
-        && wg2 >= ASM2_MIN_WGS
-        && (c->tun.narrow_any
-            || (double)v.n * (double)K * (double)c->M >= NARROW_MIN_WORK)) {
-        bool ok = c->narrow_stream != nullptr;
-        if (!ok) {
-            int least = 0, greatest = 0;
-            ok = hipDeviceGetStreamPriorityRange(&least, &greatest)
-                    == hipSuccess
-                && hipStreamCreateWithPriority(&c->narrow_stream,
-                       hipStreamNonBlocking, greatest) == hipSuccess
-                && hipEventCreateWithFlags(&c->narrow_ev[0],
-                       hipEventDisableTiming) == hipSuccess
-                && hipEventCreateWithFlags(&c->narrow_ev[1],
-                       hipEventDisableTiming) == hipSuccess;
-            if (!ok) {
-                (void)hipGetLastError();
-                if (c->narrow_stream) (void)hipStreamDestroy(c->narrow_stream);
-                c->narrow_stream = nullptr;
-            }
-        }
-        if (ok) {
-            narrow_kw = K % 8 <= 2 ? 2 : 4;
-            G_main = G - 1;
-        }
-    }
-    const int64_t split2_main = ((v.nblk + 1) / 2) * G_main * MSq;
 #define LAUNCH_ASM(CB_, SPLIT_, GRID_)                                        \
     BNPC_LAUNCH((k_ll8_asm<CB_, SPLIT_>), dim3((unsigned)(GRID_)),     \
                        dim3(256), 0, c->stream,                              \
@@ -2774,17 +2662,7 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
                        dst, xcd, MS, m_chunk,                                \
                        pf ? (const ulonglong2 *)v.masks.p : nullptr,         \
                        pf ? (const double *)c->tabs.p : nullptr,             \
-                       (SPLIT_) && need_planes == 1 ? sig : no_sig,          \
-                       (int)G_main, 0)
-#define LAUNCH_NARROW(KWN_)                                                   \
-    BNPC_LAUNCH((k_ll8_asm<4, true, KWN_>),                                   \
-                dim3((unsigned)(((v.nblk + 3) / 4) * MSq)), dim3(256), 0,     \
-                c->narrow_stream, (const ulonglong2 *)v.masks.p, c->Mpad,     \
-                c->Mt, (long long)v.n, (long long)v.nblk,                     \
-                (const double *)c->tabs.p, (int)K, (long long)ldo, dst, xcd,  \
-                MS, m_chunk, pf ? (const ulonglong2 *)v.masks.p : nullptr,    \
-                pf ? (const double *)c->tabs.p : nullptr, no_sig, 1,          \
-                (int)G_main)
+                       (SPLIT_) && need_planes == 1 ? sig : no_sig)
     // the completion word rides on the LAST kernel of the evaluation: the
     // combine pass, or the split sums kernel itself when a workgroup holds
     // the whole sum (4 chunks); other forms leave it unattached
@@ -2795,24 +2673,11 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
     if (KW == 8 && wg2 >= ASM2_MIN_WGS) {
         if (MS > 1) {
             if (MSq == 1) dst = d_out;  // the workgroup already holds the sum
-            if (narrow_kw) {
-                HIPCHK(hipEventRecord(c->narrow_ev[0], c->stream));
-                HIPCHK(hipStreamWaitEvent(c->narrow_stream, c->narrow_ev[0],
-                                          0));
-                if (narrow_kw == 2) LAUNCH_NARROW(2);
-                else LAUNCH_NARROW(4);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipEventRecord(c->narrow_ev[1], c->narrow_stream));
-            }
-            LAUNCH_ASM(2, true, narrow_kw ? split2_main : split2);
-            if (narrow_kw)
-                HIPCHK(hipStreamWaitEvent(c->stream, c->narrow_ev[1], 0));
+            LAUNCH_ASM(2, true, split2);
             planes = MSq;
             combine = MSq > 1 ? " + k_ll_combine" : "";
             snprintf(c->last_name, sizeof(c->last_name),
-                     "k_ll8_asm<2, true>%s%s", narrow_kw == 2
-                         ? " + k_ll8_asm<4, true, 2>" : narrow_kw == 4
-                         ? " + k_ll8_asm<4, true, 4>" : "", combine);
+                     "k_ll8_asm<2, true>%s", combine);
         } else if (c->Mt >= LDS_TABLE_MIN_M && wg2 >= LDS_TABLE_MIN_WGS) {
             // long mutation streams, enough workgroups to keep every CU's
             // LDS pipeline full: the table through LDS (measured, % of the
@@ -2847,7 +2712,6 @@ static int issue_ll(bnpc_ctx *c, const View &v, int64_t K, int64_t ldo,
         }
     }
 #undef LAUNCH_ASM
-#undef LAUNCH_NARROW
     else {
         snprintf(c->last_name, sizeof(c->last_name), "k_ll<%d>%s", KW,
                  MS > 1 ? " + k_ll_combine" : "");

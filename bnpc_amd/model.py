@@ -95,6 +95,7 @@ def _rowwise(fn, x):
 # tiles in flight a tile also receives the births of the two walked before it:
 # 50 at config 5's start)
 _TILE_SPARE = 160
+_TILES_AHEAD = 2        # tiles of a tiled sweep in flight while one is walked
 
 VIEW_ALL = 0      # identity view: all cells
 VIEW_MOVE = 1     # non-anchor cells of the current split/merge move
@@ -913,8 +914,10 @@ class CRP:
 
             tile_bytes = min(budget,
                 int(_lib.env('BNPC_TILE_BYTES', 256 << 20)))
-            ahead_max = max(1, min(_lib.TILE_SLOTS - 1,
-                int(_lib.env('BNPC_TILES_AHEAD', 2))))
+            # (two tiles in flight while the host walks one: the device sums
+            # t + 2 while the copy engine moves t + 1; one or three measured
+            # slower in round 4 - a constant since round 6)
+            ahead_max = max(1, min(_lib.TILE_SLOTS - 1, _TILES_AHEAD))
             born_log = []       # ids born during this sweep, in order
             tile_hints = _lib.env('BNPC_SWEEP_HINT', '1') != '0' \
                 and hasattr(ctx, 'll_rows_issue_hint')

@@ -157,49 +157,6 @@ def test_every_cluster_tiling_gives_identical_bits(kw, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize('K', [9, 10, 11, 12, 18, 20, 34, 41])
-def test_narrow_last_cluster_group_gives_identical_bits(K, monkeypatch):
-    """a split launch whose cluster count leaves 1 ... 4
-    columns over gives them to the narrow kernel (k_ll8_asm<4, true, 2 | 4>:
-    4 slot blocks x 2 or 4 clusters per wave, on a stream of its own beside
-    the groups of 8) instead of a padded group of 8.  BNPC_KW=16 takes that
-    path at any launch size (by default: from 2e9 cell-cluster-mutations on):
-    the same sums bit for bit as the groups-of-8 launch with the same
-    mutation chunks, on a ragged cell count, twice in a row (the second
-    stream's events), and against the oracle's arithmetic."""
-    rng = np.random.RandomState(100 + K)
-    N, M = 20011, 300
-    data = (rng.random_sample((N, M)) < 0.3).astype(float)
-    data[rng.random_sample(data.shape) < 0.2] = np.nan
-    theta = np.clip(rng.uniform(size=(K, M)), 1e-5, 1 - 1e-5) \
-        .astype(np.float32)
-    ctx = _lib.Context(data=data)
-    monkeypatch.delenv('BNPC_KW', raising=False)
-    monkeypatch.setenv('BNPC_MSPLIT', '8')
-    ctx.reload_options()
-    ref = ctx.ll_theta(0, theta, 0.01, 0.2)
-    name, _, chunks = ctx.last_launch()
-    assert chunks == 8 and 'k_ll8_asm<2, true>' in name, name
-    assert 'k_ll8_asm<4, true' not in name, name
-    monkeypatch.setenv('BNPC_KW', '16')
-    ctx.reload_options()
-    for _ in range(2):
-        got = ctx.ll_theta(0, theta, 0.01, 0.2)
-        name, _, chunks = ctx.last_launch()
-        want_kw = 2 if K % 8 <= 2 else 4
-        assert f'k_ll8_asm<4, true, {want_kw}>' in name and chunks == 8, name
-        assert np.array_equal(got, ref)
-    L1, L0 = host_tables(theta, 0.01, 0.2)
-    rows = rng.choice(N, 40, replace=False)
-    np.testing.assert_allclose(got[rows], table_sums(data[rows], L1, L0),
-        rtol=1e-12)
-    # a cluster count without a narrow remainder is left alone
-    full = np.ascontiguousarray(np.repeat(theta, 2, axis=0)[:16])
-    ctx.ll_theta(0, full, 0.01, 0.2)
-    assert 'k_ll8_asm<4, true' not in ctx.last_launch()[0]
-    ctx.close()
-
-
 # ------------------------------------------------------------- edge cases
 @pytest.mark.parametrize('N,M', [(1, 1), (5, 1), (1, 64), (63, 65),
     (64, 64), (65, 63), (130, 1003), (257, 130)])
@@ -471,12 +428,13 @@ def test_gibbs_sweeps_match_oracle(kind):
     H.test_gibbs_sweeps_match_oracle(kind)
 
 
-@pytest.mark.parametrize('ahead', ['2', '1'])
+@pytest.mark.parametrize('ahead', [2, 1])
 def test_tiled_sweep_on_device(ahead, monkeypatch):
     """Tiny tiles (dozens per sweep) against the oracle, with two tiles in
-    flight while the host walks one (the default) and with one."""
+    flight while the host walks one (the default) and with one.  (The budget
+    is also the parameter batch's: its screens run in slices of 8 rows here.)"""
     monkeypatch.setenv('BNPC_SWEEP_BYTES', '30000')
-    monkeypatch.setenv('BNPC_TILES_AHEAD', ahead)
+    monkeypatch.setattr(P, '_TILES_AHEAD', ahead)
     H.test_gibbs_sweeps_match_oracle('learn')
     H.test_gibbs_opens_many_clusters_in_one_sweep()
     data = H.synth(0, 1000, 200, 10, 0.10)

@@ -8,8 +8,6 @@ cd $GRAFT_REPO_ROOT
 uptime > $out/box_load.log
 timeout 600 python3 -m pytest tests/test_gpu_parity.py -q -x -k "narrow_last or every_cluster_tiling or ll_tables_is_bit_exact" > $out/pytest_narrow.log 2>&1
 tail -n 5 $out/pytest_narrow.log
-python3 tools/narrow_group_bench.py > $out/narrow_group_bench.md 2> $out/narrow_group_bench.err
-cat $out/narrow_group_bench.md; tail -n 3 $out/narrow_group_bench.err
 tools/ubench/h2d_probe > $out/h2d_probe.log 2>&1; cat $out/h2d_probe.log
 args="--cpu-steps 0 --sustained-steps 0 --device-steps 0"
 for i in 1 2 3; do
