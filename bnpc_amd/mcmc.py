@@ -134,11 +134,23 @@ class TraceStore:
     SCALARS = ('ML', 'MAP', 'DP_alpha', 'FN', 'FP')
     GROW_BLOCK = 200
 
+    @staticmethod
+    def _zeros(shape, dtype=float):
+        """np.zeros whose pages EXIST: the large traces (labels: 8 N bytes
+        per step; parameter rows: 4 K M) come from fresh anonymous memory, and
+        the first write to every 4 KiB page is a fault - a megabyte and a half
+        per recorded step at config 5: ~0.1 ms of the step's recording.  Paid
+        here, once, a page at a time (50 ms for config 5's 120 MB)."""
+        a = np.zeros(shape, dtype=dtype)
+        if a.nbytes >= 1 << 20:
+            a.reshape(-1).view(np.uint8)[::4096] = 0
+        return a
+
     def __init__(self, slots, n_cells, n_muts):
         self.n_cells = n_cells
         self.n_muts = n_muts
         self.data = {key: np.zeros(slots) for key in self.SCALARS}
-        self.data['assignments'] = np.zeros((slots, n_cells), dtype=int)
+        self.data['assignments'] = self._zeros((slots, n_cells), dtype=int)
 
     @property
     def slots(self):
@@ -150,7 +162,7 @@ class TraceStore:
         d = self.data
         if with_params and 'params' in d:
             k_max = d['params'].shape[1]
-            d['params'] = np.append(d['params'], np.zeros(
+            d['params'] = np.append(d['params'], self._zeros(
                 (extra, k_max, self.n_muts), dtype=d['params'].dtype), axis=0)
         for key in self.SCALARS:
             d[key] = np.append(d[key], np.zeros(extra))
@@ -208,7 +220,7 @@ class TraceStore:
         live = np.sort(np.fromiter(model.cells_per_cluster.keys(), dtype=int))
         if 'params' not in d:
             self._k_seen = 0
-            d['params'] = np.zeros((self.slots - slot,
+            d['params'] = self._zeros((self.slots - slot,
                 live.size + self.PARAMS_SPARE, self.n_muts), dtype=np.float32)
         wider = live.size - d['params'].shape[1]
         if wider > 0:
