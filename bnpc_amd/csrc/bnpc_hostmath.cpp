@@ -403,6 +403,15 @@ extern "C" int bnpc_team_stress(int64_t jobs, int max_tasks, int ranks,
         const int r = 1 + (int)((x >> 32) % (uint64_t)ranks);
         std::atomic<int64_t> next(0);
         int64_t seen_by[256] = {0};
+        // beside every other team job a job on the aside thread (the walker's
+        // thread: posted, run next to the team, awaited), counting on its own
+        int64_t beside = 0;
+        const int64_t beside_n = (j & 1) ? 1 + (int64_t)(x % 97) : 0;
+        bool posted = false;
+        if (beside_n)
+            posted = bnpc_aside_start([&beside, beside_n]() {
+                for (int64_t i = 0; i < beside_n; i++) beside++;
+            });
         bnpc_team_run(r, [&](int rank) {
             for (;;) {
                 const int64_t t = next.fetch_add(1, std::memory_order_relaxed);
@@ -410,7 +419,9 @@ extern "C" int bnpc_team_stress(int64_t jobs, int max_tasks, int ranks,
                 seen_by[rank]++;        // plain: one writer per rank
             }
         });
-        int64_t got = 0;
+        if (posted) bnpc_aside_wait();
+        int64_t got = posted ? beside : beside_n;
+        want += beside_n;
         for (int i = 0; i < 256; i++) got += seen_by[i];
         total.fetch_add(got, std::memory_order_relaxed);
         want += tasks;

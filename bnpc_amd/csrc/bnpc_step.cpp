@@ -949,6 +949,35 @@ extern "C" int bnpc_chain_step(bnpc_ctx *ctx, const bnpc_host_kernels *k,
         bnpc_set_error("bad argument: the chain was opened for another shape");
         return 2;
     }
+    // BNPC_TIMING=step: the call's own wall time next to what its phase
+    // clocks hold (what is outside them: between the phases, in here)
+    static const bool trace_s = [] {
+        const char *e = getenv("BNPC_TIMING");
+        return e && strstr(e, "step");
+    }();
+    struct StepTrace {
+        bnpc_chain *ch;
+        bool on;
+        Clock::time_point t0;
+        int64_t ns0;
+        int64_t laps() const
+        {
+            int64_t s = 0;
+            for (int i = 0; i < 9; i++) s += ch->clock_ns[i];
+            return s;
+        }
+        StepTrace(bnpc_chain *c, bool o)
+            : ch(c), on(o), t0(Clock::now()), ns0(o ? laps() : 0) {}
+        ~StepTrace()
+        {
+            if (!on) return;
+            const double total = std::chrono::duration_cast<
+                std::chrono::nanoseconds>(Clock::now() - t0).count() / 1e3;
+            fprintf(stderr, "[step] move %d: %.1f us in the call, %.1f in "
+                    "its phases\n", (int)ch->move, total,
+                    (laps() - ns0) / 1e3);
+        }
+    } step_trace(ch, trace_s);
     bnpc_legacy_gauss *gauss = (bnpc_legacy_gauss *)ch->gauss;
     // the binding may have changed anything between two calls
     w.rows_current = false;

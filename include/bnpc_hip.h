@@ -64,9 +64,11 @@ int bnpc_device_info(int device, char *name, int len, int *cus);
 int bnpc_device_pci_bus_id(int device, char *bus_id, int len);
 
 /* Diagnostic: `jobs` team jobs of 1..max_tasks counted tasks each on up to
- * `ranks` ranks (tests/test_native_sweeps.py stress test; the ThreadSanitizer
- * build runs it).  *done receives the number of tasks executed, which must
- * equal *expected. */
+ * `ranks` ranks, and beside every other one a counting job on the process's
+ * aside thread (the thread that takes a parameter batch's draws ahead)
+ * (tests/test_native_sweeps.py stress test; the ThreadSanitizer build runs
+ * it).  *done receives the number of tasks executed, which must equal
+ * *expected. */
 int bnpc_team_stress(int64_t jobs, int max_tasks, int ranks, uint64_t seed,
                      int64_t *done, int64_t *expected);
 /* ranks the host thread team has after growing it to `threads` (fewer when
