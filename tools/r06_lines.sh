@@ -24,3 +24,9 @@ w = j['window']
 print('$f'.split('/')[-1], j['value'], j['config']['K_end'], 'params', w['parameters']['ms_per_call'], 'gibbs', w.get('gibbs', {}).get('ms_per_call'), 'record', w['record']['ms_per_call'], 'other', w['other']['ms_per_step'])"
 done
 tail -n 12 $out/python_overhead_c5.log
+for c in c5 c4; do
+    BNPC_TIMING=gibbs,params python3 bench.py --config $c --steps 100 --warmup 10 $args > $out/bench_traced_$c.json 2> $out/host_phase_trace_$c.log
+    python3 tools/trace_means.py $out/host_phase_trace_$c.log $out/bench_traced_$c.json > $out/host_phase_means_$c.txt 2>&1
+    cat $out/host_phase_means_$c.txt
+done
+uptime >> $out/box_load.log
