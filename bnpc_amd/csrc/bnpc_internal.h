@@ -76,8 +76,16 @@ int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
                         const bnpc_legacy_gauss *g,
                         const std::function<bool(bnpc_mt19937 *,
                                                  bnpc_legacy_gauss *)> &prelude,
-                        int64_t rows, int64_t M, int64_t n_sd, bool *posted);
+                        int64_t rows, int64_t M, int64_t n_sd, bool *posted,
+                        int64_t min_entries = -1);
 void bnpc_mh_ahead_drop(bnpc_ctx *c);
+// ... and the rows of a restricted scan's batch: `uniforms` uniforms lie
+// between the stream as it is and the batch's first draw
+void bnpc_mh_ahead_scan(bnpc_ctx *c, const bnpc_mt19937 *rng, int64_t uniforms,
+                        int64_t rows, int64_t M, int64_t n_sd);
+// bnpc_sweeps.cpp: called by the NEXT bnpc_rg_scan (mode 0) of this thread
+// right after it has drawn its visiting order; consumed by that call.
+void bnpc_rg_scan_order_hook(const std::function<void()> *hook);
 // bnpc_moves.cpp: called by the NEXT bnpc_sm_move of this thread right after
 // the move's last draw of variable length, with the number of uniforms that
 // still follow inside the move (its acceptance test: 0 or 1); consumed by

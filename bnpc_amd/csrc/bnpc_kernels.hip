@@ -179,6 +179,9 @@ struct Tunables {
 #define MH_AHEAD_MIN 16384          // batch entries from which its draws are
                                     // taken ahead (config 3's 10-14 thousand
                                     // cost less than the hand-over)
+#define MH_AHEAD_SCAN_MIN 2048      // ... of a restricted scan's batch (2-3 rows:
+                                    // the walker has the scan's sums and loop,
+                                    // 50 us and more, for 10-35 us of draws)
 #define MH_AHEAD_MAX_ROWS 1024      // ... and rows up to which (a stream state
                                     // is kept per row: 2.5 KB)
 #define HINT_COLS_MAX 32767         // columns of a hinted sweep (int16 in the
@@ -3895,6 +3898,35 @@ static void mh_ahead_drop(bnpc_ctx *c)
     ah->active = false;
 }
 
+// A small batch (the rows of a restricted scan) takes a walker's rows whole:
+// the number adopted (the live stream then stands behind them), 0 if there is
+// no walker or the live stream stands elsewhere.
+static int64_t mh_ahead_adopt(bnpc_ctx *c, bnpc_mt19937 *rng, int64_t G,
+                              int64_t M, int64_t n_sd)
+{
+    MhAhead *ah = c->ahead;
+    if (!ah || !ah->active) return 0;
+    bool ok = rng && ah->M == M && ah->n_sd == n_sd && c->tun.mh_ahead != 3;
+    if (ok) {
+        int known;
+        while ((known = ah->start_known.load(std::memory_order_acquire)) == 0)
+            __builtin_ia32_pause();
+        ok = known == 1 && mt_same_position(ah->start, *rng);
+    }
+    if (!ok) {
+        mh_ahead_drop(c);
+        return 0;
+    }
+    const int64_t rows = std::min<int64_t>(ah->rows, G);
+    while (ah->rows_ready.load(std::memory_order_acquire) < rows)
+        __builtin_ia32_pause();
+    *rng = ah->after_row[(size_t)(rows - 1)];
+    mh_ahead_drop(c);
+    c->ahead_taken++;
+    c->ahead_rows_taken += rows;
+    return rows;
+}
+
 static void mh_ahead_destroy(bnpc_ctx *c)
 {
     mh_ahead_drop(c);
@@ -3958,7 +3990,8 @@ int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
                         const bnpc_legacy_gauss *g,
                         const std::function<bool(bnpc_mt19937 *,
                                                  bnpc_legacy_gauss *)> &prelude,
-                        int64_t rows, int64_t M, int64_t n_sd, bool *posted)
+                        int64_t rows, int64_t M, int64_t n_sd, bool *posted,
+                        int64_t min_entries)
 {
     if (posted) *posted = false;
     if (!c || !rng || !g || rows < 1 || M != c->M || n_sd < 1 || n_sd > 8)
@@ -3966,8 +3999,9 @@ int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
     const int mode = c->tun.mh_ahead;
     const int64_t E = rows * M;
     size_t off[6];
+    if (min_entries < 0) min_entries = MH_AHEAD_MIN;
     if (mode == 0 || !c->tun.mh_screen || rows > MH_AHEAD_MAX_ROWS
-        || E < (mode >= 2 ? MH_SCREEN_MIN : MH_AHEAD_MIN)
+        || E < (mode >= 2 ? MH_SCREEN_MIN : min_entries)
         || mh_pin_offsets((size_t)E, off) > c->tun.mh_pin_max
         || c->any_tile_pending())
         return 0;
@@ -4020,6 +4054,27 @@ int bnpc_mh_ahead_begin(bnpc_ctx *c, const bnpc_mt19937 *rng,
 void bnpc_mh_ahead_drop(bnpc_ctx *c)
 {
     if (c) mh_ahead_drop(c);
+}
+
+// The rows of a restricted scan's parameter batch (bnpc_rg_counts_and_batch)
+// taken ahead: posted by the scan when its visiting order is drawn - exactly
+// `uniforms` uniforms (one per cell) lie between there and the batch.
+void bnpc_mh_ahead_scan(bnpc_ctx *c, const bnpc_mt19937 *rng, int64_t uniforms,
+                        int64_t rows, int64_t M, int64_t n_sd)
+{
+    static const bnpc_legacy_gauss no_gauss = {};
+    const auto way = [uniforms](bnpc_mt19937 *r, bnpc_legacy_gauss *) {
+        for (int64_t left = 2 * uniforms; left > 0;) {
+            if (r->pos >= 624) mt_refill(r);
+            const int64_t take = std::min<int64_t>(624 - r->pos, left);
+            r->pos += (int32_t)take;
+            left -= take;
+        }
+        return true;
+    };
+    bool posted = false;
+    (void)bnpc_mh_ahead_begin(c, rng, &no_gauss, way, rows, M, n_sd, &posted,
+                              MH_AHEAD_SCAN_MIN);
 }
 
 extern "C" int bnpc_mh_ahead_stats(bnpc_ctx *c, int64_t *begun, int64_t *taken,
@@ -4584,9 +4639,19 @@ int bnpc_rg_counts_and_batch(bnpc_ctx *c, const bnpc_host_kernels *k,
     c->cnt_rows = 2;
     const size_t E = (size_t)a->G * M;
     MHPin h, d;
-    if (mh_pin_get(c, E, h, d)) return 1;
-    if (int rc = bnpc_mt_mh_draws(rng, a->G, M, a->n_sd, h.sd_idx, h.U, h.u))
-        return rc;
+    if (mh_pin_get(c, E, h, d, true)) return 1;
+    {
+        // the rows a walker took under the scan's sums and loop (posted when
+        // the scan had drawn its visiting order: one uniform per cell lay
+        // between there and here), the rest by this thread
+        const int64_t got = mh_ahead_adopt(c, rng, a->G, M, a->n_sd);
+        if (got < a->G) {
+            const size_t at = (size_t)got * M;
+            if (int rc = bnpc_mt_mh_draws(rng, a->G - got, M, a->n_sd,
+                                          h.sd_idx + at, h.U + at, h.u + at))
+                return rc;
+        }
+    }
     memcpy(h.theta, a->old_theta, E * 4);
     unsigned done_seq = 0;
     const DoneSignal sig = make_signal(c, 0, &done_seq);

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "bnpc_hip.h"
+#include <functional>
 #include "bnpc_internal.h"
 
 extern "C" double bnpc_mt_random_sample(bnpc_mt19937 *rng)
@@ -1723,6 +1724,15 @@ extern "C" int bnpc_gibbs_sweep(bnpc_gibbs_state *st, bnpc_mt19937 *rng,
 // ---------------------------------------------------------------------------
 // restricted Gibbs 2-way scans (CRP.py:609-632 and :800-820)
 // ---------------------------------------------------------------------------
+// What the NEXT bnpc_rg_scan (mode 0) of this thread calls right after its
+// visiting order is drawn (bnpc_internal.h); consumed by that call.
+static thread_local const std::function<void()> *g_scan_order_hook = nullptr;
+
+void bnpc_rg_scan_order_hook(const std::function<void()> *hook)
+{
+    g_scan_order_hook = hook;
+}
+
 extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
                             const double *ll, double DP_a,
                             int64_t *rg_assignment, const int64_t *target,
@@ -1739,6 +1749,10 @@ extern "C" int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S,
     std::vector<double> prob(S, 0.0);
     if (mode == 0) {
         bnpc_mt_permutation(rng, S, perm.data());
+        // (from here the scan takes exactly one uniform per cell)
+        const std::function<void()> *hook = g_scan_order_hook;
+        g_scan_order_hook = nullptr;
+        if (hook) (*hook)();
     } else {
         for (int64_t s = 0; s < S; s++) perm[s] = s;
     }
@@ -1882,8 +1896,19 @@ int bnpc_rg_scan_step_with(bnpc_ctx *ctx, const bnpc_host_kernels *k,
     // (an unscored scan: no log-probabilities, the loop may take its picks
     // from one exp() per cell)
     double log_prob = 0.0;
+    // The draws of this scan's parameter batch depend on nothing but the
+    // position of the stream, and once the visiting order is drawn exactly S
+    // uniforms lie between here and there: a walker takes them under the
+    // scan's loop (and the counts launch); the fused batch adopts them iff
+    // the live stream arrives where the walker's stood.  (A scored scan's
+    // batch draws into the caller's arrays on the host: no walker.)
+    const std::function<void()> at_order = [&]() {
+        bnpc_mh_ahead_scan(ctx, rng, S, mh->G, mh->M, mh->n_sd);
+    };
+    if (!mh->trans_prob) bnpc_rg_scan_order_hook(&at_order);
     rc = bnpc_rg_scan(rng, 0, S, ll_at + 2, DP_a, rg_assignment, nullptr,
                       mh->trans_prob ? &log_prob : nullptr);
+    bnpc_rg_scan_order_hook(nullptr);
     if (rc) return rc;
 
     // anchors: first slot -> cluster i, last slot -> cluster j
