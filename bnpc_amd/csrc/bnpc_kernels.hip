@@ -176,9 +176,12 @@ struct Tunables {
                                     // (the pinned block of a screened batch
                                     // is at most Tunables::mh_pin_max bytes)
 #define MH_PIN_NO_MEMORY 77         // mh_pin_get: the host refused the block
-#define MH_AHEAD_MIN 16384          // batch entries from which its draws are
-                                    // taken ahead (config 3's 10-14 thousand
-                                    // cost less than the hand-over)
+#define MH_AHEAD_MIN 8192           // batch entries from which its draws are
+                                    // taken ahead (config 3's 10-16 thousand:
+                                    // parameters 0.102 -> 0.090 ms, five
+                                    // interleaved pairs, profiles/r06/
+                                    // c3_walker_ab; config 2's 2000 cost less
+                                    // than the hand-over)
 #define MH_AHEAD_SCAN_MIN 2048      // ... of a restricted scan's batch (2-3 rows:
                                     // the walker has the scan's sums and loop,
                                     // 50 us and more, for 10-35 us of draws)

@@ -1539,7 +1539,7 @@ def test_draws_taken_ahead_change_nothing(mode, kind, pb, knobs, monkeypatch):
     sweep's kernel and loop / under the tail of a move - and adopted by the
     batch iff the live stream stands exactly where the walker's stood
     (bnpc_mh_ahead_begin, MhAhead in bnpc_kernels.hip).  BNPC_MH_AHEAD=2 takes
-    them for a batch of ANY size (the default starts at 16 384 entries), 3
+    them for a batch of ANY size (the default starts at 8192 entries), 3
     takes and then throws them away (the discard path at every step), 0 never
     takes any: after EVERY one of 120 steps the chain is the chain walked
     method by method without a walker - labels, cluster table, parameter
