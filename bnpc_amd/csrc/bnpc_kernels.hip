@@ -4514,7 +4514,8 @@ static int mh_batch_dev_impl(bnpc_ctx *c, const bnpc_host_kernels *k,
         const size_t at = (size_t)g0 * M;
         if (trace) clock_gettime(CLOCK_MONOTONIC, &t_got[p]);
         if (done_seq[p]) {
-            if (int rc = wait_done(c, threaded ? 0 : p, done_seq[p])) return rc;
+            if (int rc = wait_done(c, threaded || one_job ? 0 : p, done_seq[p]))
+                return rc;
         } else {
             HIPCHK(hipEventSynchronize(c->mh_ev[p & 1]));
         }
