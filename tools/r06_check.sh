@@ -4,7 +4,7 @@
 tag=${1:-r06chk}
 out=gpurun_out/$tag
 mkdir -p $out
-cd $GRAFT_REPO_ROOT; echo "snapshot marker: $(cat .snapmarker 2>/dev/null)"
+cd $GRAFT_REPO_ROOT
 uptime > $out/box_load.log
 timeout 2400 python3 -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1
 tail -n 5 $out/pytest_gpu.log
