@@ -553,14 +553,20 @@ def main():
     if args.sustained_steps > 0:
         chain.add_slots(args.sustained_steps + args.device_steps + 1)
         own_window = ranks.own_s
+        clock_s = MoveClock(model)      # (this leg's own phase clocks)
+        clock_s.on = True
         s_el = timed_steps(ranks, lambda i: step(chain, i, False), at + 1,
             at + args.sustained_steps)
+        clock_s.on = False
         ranks.own_s = own_window
         at += args.sustained_steps
         sustained = {'steps': args.sustained_steps,
             'steps_s': round(world * args.sustained_steps / s_el, 3),
             'ms_per_step': round(1e3 * s_el / args.sustained_steps, 4),
-            'K_end': len(model.cells_per_cluster)}
+            'K_end': len(model.cells_per_cluster),
+            # what these steps were made of (every one of them is recorded
+            # with its parameter rows: none is burn-in)
+            'phases': clock_s.report(args.sustained_steps, s_el)}
     if rank == 0 and args.device_steps > 0:
         # per-launch timers (the start / stop timestamps of every kernel
         # dispatch, as rocprofv3's kernel trace reads them): their sum over
