@@ -194,21 +194,36 @@ class TraceStore:
         address of the assignment row, address of the parameter block of the
         slot or 0 - the block does not exist before the first post-burn-in
         sample -, its capacity in clusters)."""
-        from bnpc_amd._lib import ptr
         d = self.data
-        scalars = [ptr(d[key]) + 8 * slot for key in self.SCALARS]
-        labels = d['assignments']
-        if labels.dtype != np.int64 or not labels.flags['C_CONTIGUOUS']:
+        params = d.get('params')
+        # (the base addresses and the checks of the arrays' layouts, made
+        # once per SET of arrays: they are replaced when a trace grows or the
+        # parameter block is re-padded, never changed in place)
+        key = tuple(id(d[k]) for k in self.SCALARS) \
+            + (id(d['assignments']), id(params))
+        cache = self.__dict__.get('_targets')
+        if cache is None or cache[0] != key:
+            from bnpc_amd._lib import ptr
+            labels = d['assignments']
+            labels_ok = labels.dtype == np.int64 \
+                and labels.flags['C_CONTIGUOUS']
+            params_at = 0
+            if params is not None and params.dtype == np.float32 \
+                    and params.flags['C_CONTIGUOUS']:
+                params_at = ptr(params)
+            cache = self._targets = (key, [ptr(d[k]) for k in self.SCALARS],
+                ptr(labels) if labels_ok else 0, params_at)
+        _, bases, labels_at, params_at = cache
+        if not labels_at:
             return None
         block, cap = 0, 0
-        params = d.get('params') if with_params else None
-        if params is not None and params.dtype == np.float32 \
-                and params.flags['C_CONTIGUOUS']:
+        if with_params and params_at:
             row = slot - (self.slots - params.shape[0])
             if 0 <= row < params.shape[0]:
                 cap = params.shape[1]
-                block = ptr(params) + 4 * row * cap * self.n_muts
-        return scalars, ptr(labels) + 8 * slot * self.n_cells, block, cap
+                block = params_at + 4 * row * cap * self.n_muts
+        return [b + 8 * slot for b in bases], \
+            labels_at + 8 * slot * self.n_cells, block, cap
 
     def put_params(self, slot, model):
         """MCMC.py:260-282: parameter rows of the populated clusters, zero
@@ -246,6 +261,7 @@ class TraceStore:
         """Chains return from their workers through a pipe: cluster labels
         travel in the narrowest integer type that holds them."""
         state = self.__dict__.copy()
+        state.pop('_targets', None)     # (addresses of this process's arrays)
         data = dict(state['data'])
         labels = data.get('assignments')
         if isinstance(labels, np.ndarray) and labels.dtype.kind == 'i' \
@@ -285,7 +301,11 @@ class Tally:
         self.counts = {name: np.zeros(2) for name in self.MOVES}
 
     def add(self, name, accepted_declined):
-        self.counts[name] += accepted_declined
+        # (element by element: `array += tuple` converts the tuple first -
+        # 1 us a time, three times a step)
+        c = self.counts[name]
+        c[0] += accepted_declined[0]
+        c[1] += accepted_declined[1]
 
     def report(self, fix_assign, learning_errors):
         from bnpc_amd.io import show_MH_acceptance

@@ -1265,8 +1265,13 @@ class CRP:
         st.sm_steps = knobs['sm_steps']
         st.fix_assign = 1 if fix_assign else 0
         st.learning = 1 if learning else 0
-        st.threads = _lib.host_threads()
-        st.threads_wide = _lib.threads_for(1 << 40)
+        # (the team sizes follow two environment variables: looked up again
+        # only when those have changed - 4 us a step otherwise)
+        team_key = (_lib.env('BNPC_HOST_THREADS'), _lib.env('BNPC_HOST_SHARE'))
+        if getattr(nat, 'team_key', None) != team_key:
+            nat.team_key = team_key
+            nat.teams = (_lib.host_threads(), _lib.threads_for(1 << 40))
+        st.threads, st.threads_wide = nat.teams
         if record is None:
             for i in range(5):
                 st.rec_scalars[i] = None
