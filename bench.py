@@ -555,6 +555,7 @@ def main():
         own_window = ranks.own_s
         clock_s = MoveClock(model)      # (this leg's own phase clocks)
         clock_s.on = True
+        stats_s0 = dict(model.host_stats())
         s_el = timed_steps(ranks, lambda i: step(chain, i, False), at + 1,
             at + args.sustained_steps)
         clock_s.on = False
@@ -566,7 +567,13 @@ def main():
             'K_end': len(model.cells_per_cluster),
             # what these steps were made of (every one of them is recorded
             # with its parameter rows: none is burn-in)
-            'phases': clock_s.report(args.sustained_steps, s_el)}
+            'phases': clock_s.report(args.sustained_steps, s_el),
+            # (steps / moves made as one native call, cells swept / taken in
+            # runs, walkers started / adopted: deltas over this leg)
+            'host': {key: val - stats_s0.get(key, 0)
+                for key, val in model.host_stats().items()
+                if key in ('native_steps', 'native_moves', 'swept',
+                    'stride_used', 'ahead_begun', 'ahead_taken')}}
     if rank == 0 and args.device_steps > 0:
         # per-launch timers (the start / stop timestamps of every kernel
         # dispatch, as rocprofv3's kernel trace reads them): their sum over
