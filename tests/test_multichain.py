@@ -147,6 +147,51 @@ def test_bench_command_reports_a_rank_that_fails():
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
 
 
+def test_record_targets_follow_the_trace_arrays():
+    """TraceStore.record_target (where a natively made step writes what it
+    records) caches the arrays' base addresses per SET of arrays: a trace
+    that grows or whose parameter block is re-padded gets new arrays, and the
+    targets must point into those - slot by slot, row by row."""
+    from bnpc_amd.mcmc import TraceStore
+    from bnpc_amd._lib import ptr
+
+    class Model:
+        cells_per_cluster = {3: 2, 0: 1, 7: 4}
+        parameters = np.arange(8 * 5, dtype=np.float32).reshape(8, 5)
+    tr = TraceStore(6, 7, 5)
+
+    def check(slot, with_params):
+        scalars, labels, block, cap = tr.record_target(slot, with_params)
+        d = tr.data
+        assert scalars == [ptr(d[k]) + 8 * slot for k in tr.SCALARS]
+        assert labels == ptr(d['assignments']) + 8 * slot * 7
+        if with_params and 'params' in d:
+            row = slot - (tr.slots - d['params'].shape[0])
+            if 0 <= row < d['params'].shape[0]:
+                assert cap == d['params'].shape[1]
+                assert block == ptr(d['params']) + 4 * row * cap * 5
+                return
+        assert block == 0 and cap == 0
+    check(2, True)                  # no parameter block yet
+    tr.put_params(3, Model)         # ... now there is (slots 3..5)
+    check(2, True)
+    check(4, True)
+    check(4, False)
+    tr.grow(4, with_params=True)    # new arrays all round
+    check(4, True)
+    check(8, True)
+    Model.cells_per_cluster = {i: 1 for i in range(8)}
+    big = np.arange(8 * 5, dtype=np.float32).reshape(8, 5)
+    Model.parameters = big
+    tr.data['params'] = np.pad(tr.data['params'], [(0, 0), (0, 9), (0, 0)])
+    check(5, True)                  # a re-padded (replaced) parameter block
+    import pickle
+    again = pickle.loads(pickle.dumps(tr))
+    assert '_targets' not in again.__dict__
+    s2, l2, b2, c2 = again.record_target(5, True)
+    assert l2 == ptr(again.data['assignments']) + 8 * 5 * 7
+
+
 def test_lugsail_mode_extends_chains_until_psrf_cutoff(monkeypatch):
     """-ls: chains run max(10, 1/(c^2-1)) steps, then are extended by 200
     steps through the pool until the lugsail PSRF drops under the cutoff
