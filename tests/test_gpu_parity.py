@@ -1561,7 +1561,8 @@ def test_draws_taken_ahead_change_nothing(mode, kind, pb, knobs, monkeypatch):
         # handed back)
         assert begun >= 0.8 * steps, nat[1]
         assert taken >= 0.6 * begun, nat[1]
-        assert nat[1]['ahead_rows'] >= 5 * taken
+        # (rows: a parameter batch's K + 1, a restricted scan's 2 or 3)
+        assert nat[1]['ahead_rows'] >= 3 * taken
     elif mode == '3':
         assert begun >= 0.8 * steps and taken == 0, nat[1]
     else:
