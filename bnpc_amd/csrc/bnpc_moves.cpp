@@ -11,7 +11,7 @@
 // element tables, np.sum's pairwise order, the scalar logs) restated on
 // NumPy's own log loop and SciPy's gammaln, without the interpreter.
 //
-// Whatever this file does not model - moves of at most 4 cells, a parameter
+// Whatever this file does not model - moves of at most 2 cells, a parameter
 // batch with an element the kernel table leaves to SciPy - is handed back:
 // the stream and the cached Gaussian are put back where they were when the
 // call started, nothing else has been modified, *status = 1, and the binding

@@ -1714,7 +1714,7 @@ class CRP:
         test and the writes of an accepted move.  None when the move is not
         done there - no device context / kernel table / native Beta sampler,
         a subclass or an instance that overrides a step of the move, a move
-        of at most 4 cells, an element left to SciPy - with the stream and
+        of at most 2 cells, an element left to SciPy - with the stream and
         the model untouched, and the caller walks the steps itself."""
         ctx = self._dev()
         table = _native_kernels()

@@ -784,7 +784,7 @@ int bnpc_rg_scan(bnpc_mt19937 *rng, int mode, int64_t S, const double *ll,
  *   out: accepted; split: cl_i = the cluster that was split, cl_j = the id
  *        the `moved` cells went to; merge: cl_i = the cluster that remains,
  *        cl_j = the one whose `moved` cells joined it; n_cells, log_A.
- * *status = 1: not done here (a move of at most 4 cells, an element of a
+ * *status = 1: not done here (a move of at most 2 cells, an element of a
  * parameter batch the kernel table leaves to SciPy, no host copy of the rows):
  * the stream and the cached Gaussian are where they were before the call and
  * nothing else was modified - the caller runs the move step by step. */
