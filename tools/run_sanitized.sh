@@ -3,8 +3,9 @@
 # library (CPU only: the GPU pool has no sanitizer support).
 #   tools/run_sanitized.sh thread               # ThreadSanitizer
 #   tools/run_sanitized.sh address,undefined    # ASan + UBSan
-# Extra arguments go to pytest.  (The gloo rank harness is left out: PyTorch's
-# own ProcessGroupGloo reports races under TSan.)  The full 10^5-job team stress:
+# Extra arguments go to pytest.  (The gloo rank harness and the two tests that
+# run `bench.py --gpus 2` over gloo are left out: PyTorch's own ProcessGroupGloo
+# reports races under TSan.)  The full 10^5-job team stress:
 #   BNPC_STRESS_JOBS=100000 tools/run_sanitized.sh thread -k team
 set -e
 SAN=${1:-thread}; shift || true
@@ -25,6 +26,8 @@ cd "$ROOT"
 LD_PRELOAD=$PRE python3 -m pytest tests/test_native_sweeps.py \
     tests/test_host_logic.py tests/test_multichain.py tests/test_fastdist.py \
     --deselect tests/test_multichain.py::test_bench_rank_harness_gloo_world2 \
+    --deselect tests/test_multichain.py::test_bench_command_with_gpus_2 \
+    --deselect tests/test_multichain.py::test_bench_command_reports_a_rank_that_fails \
     -q -p no:cacheprovider "$@" || RC=$?
 echo "sanitizer reports in $LOGDIR: $(ls "$LOGDIR" | wc -l) file(s)"
 cat "$LOGDIR"/* 2>/dev/null | grep -E "^(WARNING|SUMMARY)" | sort | uniq -c
