@@ -178,6 +178,8 @@ SIGNATURES = {
     'bnpc_team_stress': (C.c_int, [_i64, C.c_int, C.c_int, C.c_uint64,
         C.POINTER(_i64), C.POINTER(_i64)]),
     'bnpc_team_size': (C.c_int, [C.c_int]),
+    'bnpc_rows_copy_zero': (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, _i64,
+        _i64, _i64, C.c_int]),
     'bnpc_create': (C.c_int, [C.c_int, _i64, _i64, _pd, C.POINTER(_ctx)]),
     'bnpc_create_codes': (C.c_int, [C.c_int, _i64, _i64,
         C.c_void_p, C.POINTER(_ctx)]),
@@ -1006,6 +1008,27 @@ def threads_for(elements):
     if elements >= MH_WIDE_FROM and env('BNPC_HOST_THREADS') is None:
         n = max(n, min(_default_team(32), _host_cores() // 2))
     return n
+
+
+def rows_copy_zero(dst, src=None):
+    """bnpc_rows_copy_zero: the rows (axis 0) of `dst` - fresh memory, e.g.
+    np.empty - written for the first time on the host team: row r = row r of
+    `src` (the same dtype and number of rows, at most as many bytes per row)
+    followed by zeros; zeros alone without `src`.  Returns dst."""
+    rows = dst.shape[0]
+    if rows == 0 or dst.nbytes == 0:
+        return dst
+    assert dst.flags['C_CONTIGUOUS'] and dst.flags['WRITEABLE']
+    width = dst.nbytes // rows
+    copy = 0
+    if src is not None:
+        assert src.flags['C_CONTIGUOUS'] and src.dtype == dst.dtype \
+            and src.shape[0] == rows and src.nbytes <= dst.nbytes
+        copy = src.nbytes // rows
+    check(load().bnpc_rows_copy_zero(ptr(dst), width,
+        ptr(src) if copy else None, copy, rows, copy, width,
+        threads_for(dst.nbytes)), 'rows_copy_zero')
+    return dst
 
 
 def mh_batch(kernels, old, n1, n0, sd, tmin, tmax, FP, FN, p, q, uniform,

@@ -138,13 +138,29 @@ class TraceStore:
     def _zeros(shape, dtype=float):
         """np.zeros whose pages EXIST: the large traces (labels: 8 N bytes
         per step; parameter rows: 4 K M) come from fresh anonymous memory, and
-        the first write to every 4 KiB page is a fault - a megabyte and a half
-        per recorded step at config 5: ~0.1 ms of the step's recording.  Paid
-        here, once, a page at a time (50 ms for config 5's 120 MB)."""
-        a = np.zeros(shape, dtype=dtype)
-        if a.nbytes >= 1 << 20:
-            a.reshape(-1).view(np.uint8)[::4096] = 0
-        return a
+        the first write to every 4 KiB page is a fault and a page to clear -
+        a megabyte and a half per recorded step at config 5: ~0.1 ms of the
+        step's recording.  Paid here, once, by the host team (one thread:
+        6-16 ms for config 5's 99 MB of parameter rows, inside the step that
+        takes the first post-burn-in sample)."""
+        if len(shape) < 2 or int(np.prod(shape)) * np.dtype(dtype).itemsize \
+                < 1 << 20:
+            return np.zeros(shape, dtype=dtype)
+        from bnpc_amd._lib import rows_copy_zero
+        return rows_copy_zero(np.empty(shape, dtype=dtype))
+
+    @staticmethod
+    def _widened(old, shape):
+        """`old` with rows appended (axis 0) and / or every row zero-padded
+        (axis 1) to `shape` - np.append / np.pad of the reference
+        (MCMC.py:275-279, 289-294) - into fresh memory, on the host team."""
+        from bnpc_amd._lib import rows_copy_zero
+        new = np.empty(shape, dtype=old.dtype)
+        n = old.shape[0]
+        rows_copy_zero(new[:n], old)
+        if shape[0] > n:
+            rows_copy_zero(new[n:])
+        return new
 
     def __init__(self, slots, n_cells, n_muts):
         self.n_cells = n_cells
@@ -161,9 +177,9 @@ class TraceStore:
         extra = extra or min(self.GROW_BLOCK, self.slots)
         d = self.data
         if with_params and 'params' in d:
-            k_max = d['params'].shape[1]
-            d['params'] = np.append(d['params'], self._zeros(
-                (extra, k_max, self.n_muts), dtype=d['params'].dtype), axis=0)
+            old = d['params']
+            d['params'] = self._widened(old,
+                (old.shape[0] + extra,) + old.shape[1:])
         for key in self.SCALARS:
             d[key] = np.append(d[key], np.zeros(extra))
         d['assignments'] = np.append(d['assignments'],
@@ -239,9 +255,9 @@ class TraceStore:
                 live.size + self.PARAMS_SPARE, self.n_muts), dtype=np.float32)
         wider = live.size - d['params'].shape[1]
         if wider > 0:
-            d['params'] = np.pad(d['params'],
-                [(0, 0), (0, wider + self.PARAMS_SPARE), (0, 0)],
-                mode='constant')
+            old = d['params']
+            d['params'] = self._widened(old, (old.shape[0],
+                old.shape[1] + wider + self.PARAMS_SPARE, self.n_muts))
         self._k_seen = max(getattr(self, '_k_seen', 0), live.size)
         row = slot - (self.slots - d['params'].shape[0])
         d['params'][row][:live.size] = model.parameters[live]

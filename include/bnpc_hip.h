@@ -75,6 +75,16 @@ int bnpc_team_stress(int64_t jobs, int max_tasks, int ranks, uint64_t seed,
  * the system refuses threads; capped at 255) */
 int bnpc_team_size(int threads);
 
+/* Rows of a chain's sample trace (the reference's `results['params']`,
+ * libs/MCMC.py:267-282: np.zeros at the first post-burn-in sample, np.pad for
+ * every new largest cluster count, np.append when a run by time grows it)
+ * written for the first time on the host team: row r of dst (dst_stride
+ * bytes apart) = `copy` bytes of row r of src (src_stride apart; src unused if
+ * copy == 0), then zeros up to `width` bytes.  copy <= width <= dst_stride. */
+int bnpc_rows_copy_zero(void *dst, int64_t dst_stride, const void *src,
+                        int64_t src_stride, int64_t rows, int64_t copy,
+                        int64_t width, int threads);
+
 /* ---- context: data of one chain ------------------------------------------
  * Replaces the float64 N x M `self.data` (NaN = missing) of libs/CRP.py:30-31
  * by two bit planes resident in HBM.  data_nan holds 0 | 1 | NaN. */

@@ -192,6 +192,55 @@ def test_record_targets_follow_the_trace_arrays():
     assert l2 == ptr(again.data['assignments']) + 8 * 5 * 7
 
 
+@pytest.mark.parametrize('threads', ['1', '3', '8'])
+def test_large_traces_are_first_written_by_the_team(threads, monkeypatch):
+    """The large sample traces (np.zeros / np.pad / np.append of
+    libs/MCMC.py:267-294) are written for the first time by the host team
+    (bnpc_rows_copy_zero): the arrays must be what NumPy's calls give."""
+    from bnpc_amd.mcmc import TraceStore
+    from bnpc_amd import _lib
+    monkeypatch.setenv('BNPC_HOST_THREADS', threads)
+    rng = np.random.RandomState(5)
+    z = TraceStore._zeros((37, 11, 701), dtype=np.float32)     # > 1 MiB
+    assert z.dtype == np.float32 and z.shape == (37, 11, 701) \
+        and z.flags['C_CONTIGUOUS'] and not z.any()
+    lab = TraceStore._zeros((300, 1000), dtype=int)
+    assert lab.dtype == np.int64 and not lab.any()
+    assert not TraceStore._zeros((3, 5)).any()                  # small: NumPy
+    old = rng.rand(37, 11, 701).astype(np.float32)
+    wide = TraceStore._widened(old, (37, 19, 701))
+    assert np.array_equal(wide, np.pad(old, [(0, 0), (0, 8), (0, 0)]))
+    long = TraceStore._widened(old, (45, 11, 701))
+    assert np.array_equal(long, np.append(old,
+        np.zeros((8, 11, 701), np.float32), axis=0))
+    same = TraceStore._widened(old, old.shape)
+    assert np.array_equal(same, old) and same is not old
+    # one row, a row narrower than a page, nothing at all
+    one = _lib.rows_copy_zero(np.full((1, 9), 7.0), np.ones((1, 4)))
+    assert one.tolist() == [[1.0] * 4 + [0.0] * 5]
+    assert _lib.rows_copy_zero(np.empty((0, 4))).shape == (0, 4)
+    with pytest.raises(AssertionError):
+        _lib.rows_copy_zero(np.empty((4, 4)), np.ones((3, 4)))
+    # a trace that records, re-pads and grows keeps its samples
+    class Model:
+        cells_per_cluster = {3: 2, 0: 1, 7: 4}
+        parameters = rng.rand(40, 300).astype(np.float32)
+    tr = TraceStore(1200, 7, 300)
+    tr.put_params(5, Model)
+    first = tr.data['params'][0, :3].copy()
+    assert np.array_equal(first, Model.parameters[[0, 3, 7]])
+    Model.cells_per_cluster = {i: 1 for i in range(3 + tr.PARAMS_SPARE + 1)}
+    tr.put_params(6, Model)
+    assert tr.data['params'].shape[1] == 3 + 2 * tr.PARAMS_SPARE + 1
+    assert np.array_equal(tr.data['params'][0, :3], first) \
+        and not tr.data['params'][0, 3:].any() \
+        and not tr.data['params'][2:].any()
+    tr.grow(50, with_params=True)
+    assert tr.data['params'].shape[0] == 1200 - 5 + 50
+    assert np.array_equal(tr.data['params'][0, :3], first) \
+        and not tr.data['params'][2:].any()
+
+
 def test_lugsail_mode_extends_chains_until_psrf_cutoff(monkeypatch):
     """-ls: chains run max(10, 1/(c^2-1)) steps, then are extended by 200
     steps through the pool until the lugsail PSRF drops under the cutoff
