@@ -155,6 +155,7 @@ class TraceStore:
         (axis 1) to `shape` - np.append / np.pad of the reference
         (MCMC.py:275-279, 289-294) - into fresh memory, on the host team."""
         from bnpc_amd._lib import rows_copy_zero
+        old = np.ascontiguousarray(old)
         new = np.empty(shape, dtype=old.dtype)
         n = old.shape[0]
         rows_copy_zero(new[:n], old)
